@@ -1,0 +1,55 @@
+"""Parity cases shared by ``gen_golden.py`` (which runs the REAL reference on them), the CPU tests
+(oracle vs golden) and the GPU tests (HIP vs oracle, HIP vs golden).  Test infrastructure only.
+
+Everything is regenerated from seeds (weights: ``synth.synthetic_state_dict``; utterances:
+``synth.synthetic_batch``; noise: ``synth.synthetic_noise``) so a fixture only has to carry the reference's
+OUTPUTS plus a few weight checksums that prove both sides rebuilt the same checkpoint.
+"""
+from __future__ import annotations
+
+import torch
+
+from bert_vits2_amd import hparams as H, synth
+
+# the fixed symbol sequence of reference onnx_infer.py:17-49 — the closest thing the reference has to a fixture
+ONNX_INFER_SYMBOLS = [0, 97, 0, 8, 0, 78, 0, 8, 0, 76, 0, 37, 0, 40, 0, 97, 0, 8, 0, 23, 0, 8, 0, 74, 0, 26, 0, 104, 0]
+
+INFER_KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.5, length_scale=1.0)   # webui defaults, webui.py:443-454
+
+CASES = {
+    # name: hp overrides, lengths, languages, sids, weight seed, infer kwargs
+    "zh_b1_t24": dict(hp={}, lengths=[24], languages=[0], sids=[0], seed=0, kw=INFER_KW),
+    "mix_b2_ragged": dict(hp={}, lengths=[20, 13], languages=[1, 2], sids=[5, 700], seed=0, kw=INFER_KW),
+    "onnx_fixture": dict(hp={}, lengths=[len(ONNX_INFER_SYMBOLS)], languages=[0], sids=[0], seed=0,
+                         kw=dict(noise_scale=0.667, noise_scale_w=0.8, sdp_ratio=0.0, length_scale=1.0),
+                         symbols=ONNX_INFER_SYMBOLS),
+    "wn_b1_t16": dict(hp=dict(use_transformer_flow=False), lengths=[16], languages=[0], sids=[11], seed=0,
+                      kw=dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=1.0, length_scale=1.2)),
+    "short_b3": dict(hp={}, lengths=[3, 9, 1], languages=[0, 1, 2], sids=[1, 2, 3], seed=0, kw=INFER_KW),
+}
+
+T_Y_CAP = 1024     # noise_z is generated for this many frames and sliced to the realised T_y
+
+
+def build_case(name: str):
+    c = CASES[name]
+    hp = H.default_v23(**c["hp"])
+    batch = synth.synthetic_batch(c["lengths"], c["languages"], c["sids"])
+    if "symbols" in c:
+        s = torch.tensor(c["symbols"], dtype=torch.int64)
+        batch["x"][0, : len(s)] = s
+        batch["tone"][0] = 0
+    B, T = batch["x"].shape
+    noise_w, noise_z = synth.synthetic_noise(B, T, T_Y_CAP, hp.inter_channels)
+    return hp, c["seed"], batch, noise_w, noise_z, dict(c["kw"])
+
+
+CHECKSUM_KEYS = ["enc_p.emb.weight", "dec.resblocks.4.convs1.1.weight_v", "flow.flows.2.post.weight", "emb_g.weight"]
+
+
+def weight_checksums(sd):
+    return {k: float(sd[k].double().sum()) for k in CHECKSUM_KEYS if k in sd}
+
+
+GOLDEN_KEYS = ["o", "z", "z_p", "m_p", "logs_p", "enc_x", "enc_m", "enc_logs", "logw", "logw_sdp", "logw_dp", "w_ceil",
+               "y_mask", "attn"]

@@ -1,0 +1,137 @@
+"""Import the REAL reference (``/root/reference``) — build-container only, test infrastructure.
+
+``/root/reference`` does not exist on the GPU box, so nothing that runs there may call this.
+It is used by ``oracle/gen_golden.py`` (fixture generation) and by the CPU-only tests that
+re-validate the restatement against the live reference when it happens to be present.
+
+Two ``sys.modules`` stubs are needed: ``monotonic_align`` (numba is absent,
+training only) and ``text`` (its ``__init__`` downloads BERT models at import).  The reference's source is
+imported from where it lies; nothing is copied.
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import torch
+
+REF = os.environ.get("BV2_REFERENCE", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(REF, "models.py"))
+
+
+_models = None
+
+
+def reference_models():
+    """Return the reference ``models`` module (unmodified source)."""
+    global _models
+    if _models is not None:
+        return _models
+    if not available():
+        raise RuntimeError("reference not present at %s" % REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.modules.setdefault("monotonic_align", types.ModuleType("monotonic_align"))
+    spec = importlib.util.spec_from_file_location("text.symbols", os.path.join(REF, "text", "symbols.py"))
+    sym = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sym)
+    text = types.ModuleType("text")
+    text.__path__ = []
+    for k in dir(sym):
+        if not k.startswith("__"):
+            setattr(text, k, getattr(sym, k))
+    sys.modules["text"] = text
+    sys.modules["text.symbols"] = sym
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import models  # noqa: the reference's models.py
+    _models = models
+    return models
+
+
+def reference_config() -> dict:
+    with open(os.path.join(REF, "configs", "config.json"), "r", encoding="utf-8") as f:
+        return json.load(f)
+
+
+def build_reference_net(hp, state_dict):
+    """Reference ``SynthesizerTrn`` (as reference infer.py:95-101 builds it) loaded with ``state_dict``."""
+    import warnings
+    models = reference_models()
+    cfg = reference_config()
+    model_kwargs = dict(cfg["model"])
+    model_kwargs["use_transformer_flow"] = hp.use_transformer_flow
+    model_kwargs["n_flow_layer"] = hp.n_flow_layer
+    model_kwargs["n_layers_trans_flow"] = hp.n_layers_trans_flow
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = models.SynthesizerTrn(hp.n_vocab, hp.spec_channels, hp.segment_size,
+                                    n_speakers=hp.n_speakers, **model_kwargs).eval()
+    missing, unexpected = net.load_state_dict(state_dict, strict=False)
+    bad = [k for k in missing if not (k.startswith("enc_q.") or k.startswith("sdp.post_"))]
+    if bad or unexpected:
+        raise RuntimeError(f"schema mismatch: missing={bad[:8]} unexpected={list(unexpected)[:8]}")
+    return net
+
+
+@contextlib.contextmanager
+def injected_noise(noise_w: torch.Tensor, noise_z: torch.Tensor):
+    """Hand the reference's two RNG draws pre-generated buffers: the first
+    ``torch.randn`` call inside ``infer`` (models.py:248-251) gets ``noise_w``; the ``torch.randn_like`` at
+    models.py:1071 gets ``noise_z[:, :, :T_y]``."""
+    real_randn, real_like = torch.randn, torch.randn_like
+    state = {"w": 0, "z": 0}
+
+    def fake_randn(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+        assert shape == tuple(noise_w.shape), (shape, noise_w.shape)
+        state["w"] += 1
+        return noise_w.clone()
+
+    def fake_like(t, **kw):
+        assert t.shape[:2] == noise_z.shape[:2] and t.shape[2] <= noise_z.shape[2], (t.shape, noise_z.shape)
+        state["z"] += 1
+        return noise_z[:, :, : t.shape[2]].clone()
+
+    torch.randn, torch.randn_like = fake_randn, fake_like
+    try:
+        yield state
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+
+
+@torch.no_grad()
+def reference_infer(net, batch, noise_w, noise_z, **kw):
+    """Run the reference's own ``infer`` with injected noise; returns its tuple plus hook taps."""
+    taps = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            taps[name] = out
+        return f
+
+    hs = [net.enc_p.register_forward_hook(hook("enc_p")), net.sdp.register_forward_hook(hook("sdp")),
+          net.dp.register_forward_hook(hook("dp"))]
+    try:
+        with injected_noise(noise_w, noise_z) as st:
+            o, attn, y_mask, (z, z_p, m_p, logs_p) = net.infer(
+                batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"],
+                batch["bert"], batch["ja_bert"], batch["en_bert"], **kw)
+        assert st["w"] == 1 and st["z"] == 1, st
+    finally:
+        for h in hs:
+            h.remove()
+    ex, em, el, xm = taps["enc_p"]
+    sdp_ratio = kw.get("sdp_ratio", 0)
+    logw = taps["sdp"] * sdp_ratio + taps["dp"] * (1 - sdp_ratio)
+    w_ceil = torch.ceil(torch.exp(logw) * xm * kw.get("length_scale", 1))
+    return dict(o=o, attn=attn, y_mask=y_mask, z=z, z_p=z_p, m_p=m_p, logs_p=logs_p, enc_x=ex, enc_m=em,
+                enc_logs=el, x_mask=xm, logw=logw, logw_sdp=taps["sdp"], logw_dp=taps["dp"], w_ceil=w_ceil)
