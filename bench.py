@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds/sec on the SynthesizerTrn.infer() hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full ``infer()`` (phase A + the reference's one host sync + phase B) over one batch of synthetic
+utterances already resident in HBM.  N=1 workload = BASELINE config 2: B=1, T=128 symbols, fp32, durations pinned to
+3 frames/symbol (T_y=384, 196 608 samples = 4.458 s of 44.1 kHz audio).  N>1: utterances are independent units, so each
+rank runs the same per-GPU workload on its own utterance (weak scaling, no data-path collective); the only collective is
+the one-time RCCL broadcast of the packed weight blob from rank 0, timed separately.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from bert_vits2_amd import hparams as H, models, sharding, synth  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix = fp32 vector peak
+GEN_FLOP_PER_FRAME = 651.6e6       # Generator algorithmic FLOPs per latent frame
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (config 2: 1)")
+    ap.add_argument("--symbols", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel family")
+    return ap.parse_args()
+
+
+def cpu_baseline(hp, sd, batch, kw, iters):
+    """The oracle restatement (same aten CPU kernels and per-call weight_norm fold as the reference's infer) timed on
+    this box's host cores — a reported baseline, kind "port" (the Python reference cannot travel to the GPU box)."""
+    from oracle import bv2_oracle as O
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    B, T = batch["x"].shape
+    nw, nz = synth.synthetic_noise(B, T, 3 * T + 8, hp.inter_channels)
+    run = lambda: O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"],
+                          batch["bert"], batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, **kw)
+    out = run()
+    run()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        out = run()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    audio_s = float(out["y_lengths"].sum()) * hp.total_upsample / hp.sampling_rate
+    return dict(value=audio_s / med, unit="audio-seconds/sec", cores=nthreads, kind="port",
+                sample=f"{iters} timed runs (median) of the same workload (B={B}, T={T}, T_y={int(out['y_lengths'].max())}, "
+                       f"{audio_s:.3f} s audio) after 2 warm-ups, torch CPU fp32", ms_per_step=med * 1e3)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback for the product path"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # RCCL
+
+    hp = H.default_v23()
+    B, T = args.batch, args.symbols
+    kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
+
+    # ---- weights: rank 0 folds/packs the seeded synthetic checkpoint, every other rank receives the blob over RCCL
+    model = models.from_hparams(hp)
+    sd = None
+    if rank == 0:
+        sd = synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5)
+        model.load_state_dict(sd, strict=False)
+    t_bcast = sharding.distribute_weights(model, dev, src=0)
+
+    # ---- this rank's utterances (weak scaling: same per-GPU work, different utterances)
+    batch = synth.synthetic_batch([T] * B, first_index=rank * B)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    call = lambda: model.infer(dbatch["x"], dbatch["x_lengths"], dbatch["sid"], dbatch["tone"], dbatch["language"],
+                               dbatch["bert"], dbatch["ja_bert"], dbatch["en_bert"], **kw)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = call()
+    model.profile(2)                   # HIP events around the Generator's kernel launches only (dominant family)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(args.steps):
+        o, attn, y_mask, _rest = call()
+        frames += y_mask.shape[2] * B              # pinned durations: every frame of every utterance is valid
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = model.profile_report()
+    model.profile(0)
+    Ty = y_mask.shape[2]
+
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        ftot = torch.tensor([frames], dtype=torch.float64, device=dev)
+        dist.all_reduce(ftot, op=dist.ReduceOp.SUM)
+        frames = float(ftot.item())
+    audio_s = frames * hp.total_upsample / hp.sampling_rate
+    value = audio_s / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (the MFMA implicit-GEMM conv that runs the Generator)
+        roof = None
+        if prof:
+            dom = max(prof, key=lambda r: r["total_ms"])
+            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            gen_ms = sum(r["total_ms"] for r in prof) / args.steps
+            roof = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        launches_per_step=dom["launches"] / args.steps,
+                        avg_launch_us=round(dom["total_ms"] * 1e3 / dom["launches"], 2),
+                        flops_per_launch=dom["flops"] / dom["launches"],
+                        generator_ms_per_step=round(gen_ms, 4),
+                        generator_tflops=round(sum(r["flops"] for r in prof) / args.steps / (gen_ms * 1e-3) / 1e12, 3),
+                        families=[dict(name=r["name"], launches=r["launches"] / args.steps,
+                                       ms_per_step=round(r["total_ms"] / args.steps, 4),
+                                       tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 3),
+                                       alg_GBps=round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)) for r in prof])
+        full = None
+        if args.full_profile:
+            model.profile(1)
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            full = [dict(name=r["name"], launches=r["launches"] / 3, ms_per_step=round(r["total_ms"] / 3, 4),
+                         tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 3)) for r in model.profile_report()]
+            model.profile(0)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(hp, sd, batch, kw, args.cpu_iters)
+        line = dict(
+            metric="audio-seconds/sec (44.1 kHz), SynthesizerTrn.infer(), 128-phoneme utterance", value=round(value, 2),
+            unit="audio-seconds/sec", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+            dtype="f32", data="synthetic",
+            config=dict(workload=f"BASELINE config 2: B={B} x T={T} symbols per GPU, fp32, T_y={Ty} frames "
+                                 f"({Ty * hp.total_upsample} samples, {Ty * hp.total_upsample / hp.sampling_rate:.3f} s) per utterance, "
+                                 f"transformer flow, synthetic seeded weights, durations pinned to 3 frames/symbol",
+                        utterances_per_gpu=B, symbols=T, frames=Ty, parallelism=f"utterance-sharded x{world}",
+                        rtf=round(dt / audio_s, 6), x_realtime_per_gpu=round(value / world, 2),
+                        weight_broadcast_ms=round(t_bcast * 1e3, 3)),
+            roofline=roof, cpu_baseline=cpu)
+        if full:
+            line["kernel_families_untimed_pass"] = full
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,336 @@
+// bv2_api.cpp — the extern "C" surface declared in include/bv2.h.
+#include <cstring>
+#include <new>
+
+#include "bv2_internal.h"
+
+using namespace bv2;
+
+static thread_local std::string g_create_err;
+
+#define BV2_TRY try {
+#define BV2_CATCH(h_)                                                                  \
+  } catch (const std::exception& e) {                                                  \
+    if (h_) (h_)->err = std::string("exception: ") + e.what();                         \
+    return -100;                                                                       \
+  } catch (...) {                                                                      \
+    if (h_) (h_)->err = "unknown exception";                                           \
+    return -100;                                                                       \
+  }
+
+extern "C" {
+
+int bv2_abi_version(void) { return BV2_ABI_VERSION; }
+
+int bv2_create(const bv2_config* cfg, bv2_handle** out) {
+  if (!cfg || !out) { g_create_err = "bv2_create: null argument"; return -1; }
+  bv2_handle* h = nullptr;
+  try {
+    h = new bv2_handle();
+    std::memset(&h->model.cfg, 0, sizeof(bv2_config));
+    if (cfg->struct_bytes != (int32_t)sizeof(bv2_config)) {
+      g_create_err = "bv2_create: bv2_config.struct_bytes mismatch (ABI drift)";
+      delete h;
+      return -1;
+    }
+    h->model.cfg = *cfg;
+    std::string err;
+    if (int rc = build_layout(h->model, err)) {
+      g_create_err = "bv2_create: " + err;
+      delete h;
+      return rc;
+    }
+  } catch (...) {
+    delete h;
+    g_create_err = "bv2_create: out of memory";
+    return -100;
+  }
+  *out = h;
+  return 0;
+}
+
+void bv2_destroy(bv2_handle* h) {
+  if (!h) return;
+  for (auto& r : h->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  delete h;
+}
+
+const char* bv2_last_error(const bv2_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+static float half_to_float(uint16_t v) {
+  const uint32_t sign = (uint32_t)(v & 0x8000) << 16;
+  uint32_t exp = (v >> 10) & 0x1f, man = v & 0x3ff, bits;
+  if (exp == 0) {
+    if (man == 0) bits = sign;
+    else {
+      exp = 127 - 15 + 1;
+      while (!(man & 0x400)) { man <<= 1; --exp; }
+      man &= 0x3ff;
+      bits = sign | (exp << 23) | (man << 13);
+    }
+  } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+  else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+
+int bv2_load_tensor(bv2_handle* h, const char* key, const void* host_ptr, const int64_t* shape, int ndim, int dtype) {
+  if (!h) return -1;
+  BV2_TRY
+  if (!key || !host_ptr || ndim < 0 || ndim > 8 || (ndim && !shape)) { h->err = "bv2_load_tensor: bad argument"; return -1; }
+  if (!key_in_schema(h->model, key)) return 1;     // training-only tensors (enc_q.*, sdp.post_*): ignored
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+  t.data.resize((size_t)n);
+  if (dtype == BV2_F32) std::memcpy(t.data.data(), host_ptr, sizeof(float) * (size_t)n);
+  else if (dtype == BV2_F16) {             // compress_model.py:49-53 "release" checkpoints are .half()
+    const uint16_t* s = static_cast<const uint16_t*>(host_ptr);
+    for (int64_t i = 0; i < n; ++i) t.data[(size_t)i] = half_to_float(s[i]);
+  } else if (dtype == BV2_BF16) {
+    const uint16_t* s = static_cast<const uint16_t*>(host_ptr);
+    for (int64_t i = 0; i < n; ++i) { uint32_t b = (uint32_t)s[i] << 16; std::memcpy(&t.data[(size_t)i], &b, 4); }
+  } else { h->err = "bv2_load_tensor: unknown dtype"; return -1; }
+  h->tensors[key] = std::move(t);
+  return 0;
+  BV2_CATCH(h)
+}
+
+int64_t bv2_packed_bytes(const bv2_handle* h) { return h ? h->model.total_floats * (int64_t)sizeof(float) : -1; }
+
+int bv2_pack_weights(bv2_handle* h, void* host_blob, int64_t bytes) {
+  if (!h) return -1;
+  BV2_TRY
+  if (!host_blob || bytes < bv2_packed_bytes(h)) { h->err = "bv2_pack_weights: buffer too small"; return -1; }
+  return pack_blob(h->model, h->tensors, static_cast<float*>(host_blob), h->err);
+  BV2_CATCH(h)
+}
+
+int bv2_attach_weights(bv2_handle* h, const void* dev_blob, int64_t bytes) {
+  if (!h) return -1;
+  BV2_TRY
+  if (!dev_blob || bytes < bv2_packed_bytes(h)) { h->err = "bv2_attach_weights: blob too small for this config"; return -1; }
+  uint32_t hdr[8];
+  if (hipMemcpy(hdr, dev_blob, sizeof(hdr), hipMemcpyDeviceToHost) != hipSuccess) {
+    h->err = "bv2_attach_weights: cannot read the blob header (is this a device pointer on the current GPU?)";
+    return -6;
+  }
+  int64_t tf;
+  std::memcpy(&tf, hdr + 4, sizeof(tf));
+  if (hdr[0] != kBlobMagic || hdr[1] != BV2_ABI_VERSION || hdr[2] != h->model.cfg_hash || tf != h->model.total_floats) {
+    h->err = "bv2_attach_weights: blob header does not match this handle's config (not packed, or packed for another model)";
+    return -7;
+  }
+  h->blob = static_cast<const float*>(dev_blob);
+  return 0;
+  BV2_CATCH(h)
+}
+
+int64_t bv2_workspace_bytes(const bv2_handle* h, int B, int T, int Ty_max) {
+  if (!h || B < 1 || T < 1 || Ty_max < 1) return -1;
+  return workspace_bytes(h->model, B, T, Ty_max);
+}
+
+static int ready(bv2_handle* h, const void* ws) {
+  if (!h) return -1;
+  if (!h->blob) { h->err = "no weights attached (call bv2_pack_weights + bv2_attach_weights first)"; return -8; }
+  if (!ws) { h->err = "workspace is null"; return -5; }
+  return 0;
+}
+
+int bv2_encode_durations(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* out,
+                         void* ws, int64_t wsb) {
+  if (int rc = ready(h, ws)) return rc;
+  BV2_TRY
+  if (!in || !out || in->B < 1 || in->T < 1) { h->err = "bv2_encode_durations: bad argument"; return -1; }
+  if (!in->x || !in->x_lengths || !in->sid || !in->tone || !in->language || !in->bert || !in->ja_bert || !in->en_bert ||
+      !in->noise_w || !out->g || !out->x || !out->m_p || !out->logs_p || !out->x_mask || !out->logw || !out->w_ceil ||
+      !out->y_lengths) { h->err = "bv2_encode_durations: null tensor pointer"; return -1; }
+  return run_encode(h, static_cast<hipStream_t>(stream), *in, *out, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_decode(bv2_handle* h, bv2_stream stream, const bv2_decode_in* in, const bv2_decode_out* out, void* ws, int64_t wsb) {
+  if (int rc = ready(h, ws)) return rc;
+  BV2_TRY
+  if (!in || !out || in->B < 1 || in->T < 1 || in->Ty < 1) { h->err = "bv2_decode: bad argument"; return -1; }
+  if (!in->m_p || !in->logs_p || !in->x_mask || !in->w_ceil || !in->y_lengths || !in->g || !in->noise_z || !out->o) {
+    h->err = "bv2_decode: null tensor pointer"; return -1;
+  }
+  return run_decode(h, static_cast<hipStream_t>(stream), *in, *out, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_stage_flow(bv2_handle* h, bv2_stream stream, int B, int Ty, const float* z_p, const int64_t* y_lengths,
+                   const float* g, float* z, void* ws, int64_t wsb) {
+  if (int rc = ready(h, ws)) return rc;
+  BV2_TRY
+  if (B < 1 || Ty < 1 || !z_p || !y_lengths || !g || !z) { h->err = "bv2_stage_flow: bad argument"; return -1; }
+  return run_flow(h, static_cast<hipStream_t>(stream), B, Ty, z_p, y_lengths, g, z, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_stage_generator(bv2_handle* h, bv2_stream stream, int B, int Ty, int L, const float* z, const int64_t* y_lengths,
+                        const float* g, float* o, void* ws, int64_t wsb) {
+  if (int rc = ready(h, ws)) return rc;
+  BV2_TRY
+  if (B < 1 || Ty < 1 || !z || !y_lengths || !g || !o) { h->err = "bv2_stage_generator: bad argument"; return -1; }
+  return run_generator(h, static_cast<hipStream_t>(stream), B, Ty, L, z, y_lengths, g, o, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* enc_out,
+              const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, float noise_scale, int32_t max_len,
+              int32_t Ty_cap, const bv2_decode_out* dec_out, int32_t* Ty_out, void* ws, int64_t wsb) {
+  if (int rc = bv2_encode_durations(h, stream, in, enc_out, ws, wsb)) return rc;
+  BV2_TRY
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<int64_t> yl((size_t)in->B);
+  // the reference's one host sync (commons.py:120-122: length.max() feeds torch.arange)
+  if (hipMemcpyAsync(yl.data(), enc_out->y_lengths, sizeof(int64_t) * (size_t)in->B, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) { h->err = "bv2_infer: reading y_lengths failed"; return -6; }
+  int64_t Ty = 1;
+  for (int64_t v : yl) Ty = v > Ty ? v : Ty;
+  if (Ty_out) *Ty_out = (int32_t)Ty;
+  if (Ty > Ty_cap) { h->err = "bv2_infer: realised T_y exceeds Ty_cap"; return -3; }
+  bv2_decode_in d;
+  std::memset(&d, 0, sizeof(d));
+  d.B = in->B; d.T = in->T; d.Ty = (int32_t)Ty; d.max_len = max_len;
+  d.m_p = enc_out->m_p; d.logs_p = enc_out->logs_p; d.x_mask = enc_out->x_mask; d.w_ceil = enc_out->w_ceil;
+  d.y_lengths = enc_out->y_lengths; d.g = enc_out->g;
+  d.noise_z = noise_z; d.nz_bstride = nz_bstride; d.nz_cstride = nz_cstride; d.noise_scale = noise_scale;
+  return bv2_decode(h, stream, &d, dec_out, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_set_tap(bv2_handle* h, const char* name, float* dev_dst, int64_t cap) {
+  if (!h) return -1;
+  BV2_TRY
+  if (!name) { h->taps.clear(); return 0; }
+  if (!dev_dst || cap <= 0) { h->taps.erase(name); return 0; }
+  h->taps[name] = Tap{dev_dst, cap};
+  return 0;
+  BV2_CATCH(h)
+}
+
+int bv2_profile_enable(bv2_handle* h, int on) {
+  if (!h) return -1;
+  BV2_TRY
+  if (on && h->prof_pool.empty()) {
+    h->prof_pool.resize(8192);
+    for (auto& r : h->prof_pool) {
+      if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) {
+        h->err = "bv2_profile_enable: hipEventCreate failed";
+        return -6;
+      }
+    }
+  }
+  h->prof_on = on != 0;
+  h->prof_mode = on == 2 ? 2 : 1;
+  return 0;
+  BV2_CATCH(h)
+}
+
+int bv2_profile_reset(bv2_handle* h) {
+  if (!h) return -1;
+  h->prof_used = 0;
+  return 0;
+}
+
+int bv2_profile_report(bv2_handle* h, bv2_profile_row* rows, int max_rows) {
+  if (!h || !rows) return -1;
+  BV2_TRY
+  const int nf = (int)h->prof_names.size();
+  std::vector<bv2_profile_row> acc((size_t)nf);
+  for (int i = 0; i < nf; ++i) {
+    std::memset(&acc[i], 0, sizeof(bv2_profile_row));
+    std::strncpy(acc[i].name, h->prof_names[i].c_str(), sizeof(acc[i].name) - 1);
+  }
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    const ProfileRec& r = h->prof_pool[i];
+    if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    bv2_profile_row& a = acc[(size_t)r.fam];
+    a.launches += 1; a.total_ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+  }
+  int n = 0;
+  for (int i = 0; i < nf && n < max_rows; ++i)
+    if (acc[i].launches) rows[n++] = acc[i];
+  return n;
+  BV2_CATCH(h)
+}
+
+}  // extern "C"
+
+// ================================================================================================================
+// test-only kernel entry points (include/bv2_testing.h)
+#include "../../include/bv2_testing.h"
+
+extern "C" {
+
+static inline int t_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+int64_t bv2_test_conv_pack_floats(int cin, int cout, int k) {
+  return (int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32);
+}
+
+int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const float* bias_host, float* out, float* wpack_dev,
+                    int B, int cin, int cout, int k, int dil, int pad_left, int L, int tile, float lrelu_slope, int relu,
+                    const float* res, int res_mode, const float* in_mask, const float* out_mask, int mask_pre,
+                    int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale) {
+  try {
+    const int cin_pad = t_round_up(cin, 16), ld = t_round_up(cout, 128), cout_pad = t_round_up(cout, 32);
+    std::vector<float> pk((size_t)bv2_test_conv_pack_floats(cin, cout, k), 0.f);
+    for (int j = 0; j < k; ++j)
+      for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+          pk[((size_t)j * cin_pad + ci) * ld + co] = w_host[((size_t)co * cin + ci) * k + j];
+    const size_t boff = (size_t)k * cin_pad * ld;
+    if (bias_host) for (int co = 0; co < cout; ++co) pk[boff + co] = bias_host[co];
+    if (hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
+    ConvLaunch cl;
+    std::memset(&cl, 0, sizeof(cl));
+    ConvProb& p = cl.p[0];
+    p.x[0] = x; p.x[1] = x1; p.x[2] = x2; p.nsrc = nsrc; p.in_scale = in_scale;
+    p.x_bstride = (int64_t)cin * L; p.x_rstride = L; p.Lin = L;
+    p.in_mask = in_mask; p.in_mask_bstride = L; p.out_mask = out_mask; p.out_mask_bstride = L;
+    p.w = wpack_dev; p.bias = bias_host ? wpack_dev + boff : nullptr;
+    p.bias2 = bias2; p.bias2_bstride = cout;
+    p.out = out; p.out_bstride = (int64_t)cout * L; p.out_rstride = L; p.out_tstride = 1; p.out_toff = 0;
+    p.res = res; p.res_bstride = p.out_bstride; p.res_mode = res_mode;
+    p.cin = cin; p.cin_pad = cin_pad; p.cout = cout; p.cout_pad = cout_pad; p.w_ld = ld; p.k = k; p.dil = dil;
+    p.pad_left = pad_left < 0 ? ((k - 1) / 2) * dil : pad_left;
+    p.pre_act = lrelu_slope != 0.f ? PRE_LRELU : PRE_NONE; p.slope = lrelu_slope;
+    p.act = relu ? ACT_RELU : ACT_NONE; p.mask_pre = mask_pre; p.mask_post = mask_post;
+    cl.nprob = 1; cl.B = B; cl.L = L;
+    const char* vn = nullptr;
+    return launch_conv1d(static_cast<hipStream_t>(stream), cl, tile, &vn);
+  } catch (...) { return -100; }
+}
+
+int bv2_test_attention(void* stream, const float* qkv, const float* mask, const float* erk, const float* erv, float* out,
+                       int B, int H, int D, int T, int W) {
+  AttnArgs a;
+  a.qkv = qkv; a.mask = mask; a.erk = erk; a.erv = erv; a.out = out; a.B = B; a.H = H; a.D = D; a.T = T; a.W = W;
+  return launch_attention(static_cast<hipStream_t>(stream), a);
+}
+
+int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode, const float* dww, const float* dwb, int dil,
+                       const float* in_mask, const float* gamma, const float* beta, int post_gelu, const float* res,
+                       const float* vec, const float* mask, float* out, int B, int C, int T) {
+  LnArgs l;
+  std::memset(&l, 0, sizeof(l));
+  l.a = a; l.add = add; l.mode = mode; l.dww = dww; l.dwb = dwb; l.dil = dil; l.in_mask = in_mask;
+  l.gamma = gamma; l.beta = beta; l.eps = 1e-5f; l.post_gelu = post_gelu; l.res = res; l.vec = vec; l.vec_bstride = C;
+  l.mask = mask; l.out = out; l.B = B; l.C = C; l.T = T;
+  return launch_layernorm(static_cast<hipStream_t>(stream), l);
+}
+
+int bv2_test_spline(void* stream, float* z, int src, int dst, const float* params, int prow, const float* mask,
+                    float sqrt_fc, float tail, int B, int T) {
+  return launch_spline(static_cast<hipStream_t>(stream), z, src, dst, params, prow, mask, sqrt_fc, tail, B, T);
+}
+
+}  // extern "C"

@@ -1,0 +1,581 @@
+// bv2_exec.cpp — the host executor: SynthesizerTrn.infer() (reference models.py:1026-1074) as a fixed sequence of
+// kernel launches on the caller's stream.  No allocation, no host sync, no device->host copy happens in here
+// (the one data-dependent size, T_y, is read by the CALLER between run_encode and run_decode — the same single
+// sync the reference has at commons.py:120-122), so each phase is hipGraph-capturable.
+#include <cmath>
+#include <cstring>
+
+#include "bv2_internal.h"
+
+namespace bv2 {
+
+namespace {
+
+struct Arena {
+  char* base;
+  int64_t off = 0, cap;
+  Arena(void* b, int64_t c) : base(static_cast<char*>(b)), cap(c) {}
+  template <class T> T* get(int64_t n) {
+    const int64_t bytes = (n * (int64_t)sizeof(T) + 255) / 256 * 256;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += bytes;
+    return p;
+  }
+  bool ok() const { return base == nullptr || off <= cap; }
+};
+
+struct Ctx {
+  bv2_handle* h;
+  hipStream_t s;
+  const Model& m;
+  const float* blob;
+  int rc = 0;
+  const float* W(int64_t off) const { return off < 0 ? nullptr : blob + off; }
+
+  void fail(const char* what, int code) {
+    if (!rc) { rc = code ? code : -1; h->err = std::string("kernel launch failed: ") + what; }
+  }
+
+  // ---- profiling: HIP events on the caller's stream around one kernel family launch
+  int prof_begin(const char* tag) {
+    if (!h->prof_on || h->prof_used >= h->prof_pool.size()) return -1;
+    if (h->prof_mode == 2 && std::strncmp(tag, "dec.", 4) != 0) return -1;   // Generator kernels only
+    const int i = (int)h->prof_used++;
+    (void)hipEventRecord(h->prof_pool[i].e0, s);
+    return i;
+  }
+  void prof_end(int i, const char* name, double flops, double bytes) {
+    if (i < 0) return;
+    (void)hipEventRecord(h->prof_pool[i].e1, s);
+    int fam = -1;
+    for (size_t k = 0; k < h->prof_names.size(); ++k)
+      if (h->prof_names[k] == name) fam = (int)k;
+    if (fam < 0) { fam = (int)h->prof_names.size(); h->prof_names.push_back(name); }
+    h->prof_pool[i].fam = fam; h->prof_pool[i].flops = flops; h->prof_pool[i].bytes = bytes;
+  }
+
+  void tap(const char* name, const float* src, int64_t n) {
+    if (h->taps.empty()) return;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return;
+    const int64_t c = n < it->second.cap ? n : it->second.cap;
+    (void)hipMemcpyAsync(it->second.dst, src, sizeof(float) * (size_t)c, hipMemcpyDeviceToDevice, s);
+  }
+
+  // conv problem with the defaults of a "same"-padded Conv1d on a dense [B,C,L] tensor
+  ConvProb prob(const ConvW& w, const float* x, float* out, int L, int dil = 1) const {
+    ConvProb p;
+    std::memset(&p, 0, sizeof(p));
+    p.x[0] = x; p.nsrc = 1; p.in_scale = 1.f;
+    p.x_bstride = (int64_t)w.cin * L; p.x_rstride = L; p.Lin = L;
+    p.in_mask_bstride = L; p.out_mask_bstride = L;
+    p.w = W(w.w_off); p.bias = W(w.b_off);
+    p.out = out; p.out_bstride = (int64_t)w.cout * L; p.out_rstride = L; p.out_tstride = 1; p.out_toff = 0;
+    p.res_bstride = p.out_bstride;
+    p.cin = w.cin; p.cin_pad = w.cin_pad; p.cout = w.cout; p.cout_pad = w.cout_pad; p.w_ld = w.w_ld;
+    p.k = w.k; p.dil = dil; p.pad_left = ((w.k - 1) / 2) * dil;
+    p.slope = 0.1f;
+    return p;
+  }
+  void conv(ConvLaunch& L, const char* tag) {
+    if (rc) return;
+    const char* vn = "conv1d_mfma";
+    const int pi = prof_begin(tag);
+    const int r = launch_conv1d(s, L, TILE_AUTO, &vn);
+    prof_end(pi, vn, conv_flops(L), conv_bytes(L));
+    if (r) fail(tag, r);
+  }
+  void conv1(const ConvProb& p, int B, int L, const char* tag) {
+    ConvLaunch cl;
+    cl.p[0] = p; cl.nprob = 1; cl.B = B; cl.L = L;
+    conv(cl, tag);
+  }
+  void ln(const LnArgs& a, const char* tag) {
+    if (rc) return;
+    if (int r = launch_layernorm(s, a)) fail(tag, r);
+  }
+  void chk(int r, const char* tag) { if (r && !rc) fail(tag, r); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// attentions.Encoder.forward (reference attentions.py:103-120): 5 launches per layer
+//   qkv = W_qkv x                         (fused 1x1, MFMA)
+//   att = relpos_attention(qkv)           (flash-style, MFMA)
+//   s   = x + W_o att                     (MFMA, residual in the epilogue)
+//   x   = LN1(s)
+//   f   = relu(conv_k(x*mask))            (MFMA, input mask + ReLU fused)
+//   s   = conv_k(f*mask)*mask + x         (MFMA, masks + residual fused)
+//   x   = LN2(s) [ + spk, *mask when the NEXT layer is the conditioning layer; *mask after the last layer ]
+struct EncBufs { float *x, *s, *att, *qkv, *f1; };
+
+void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask, const float* spk, int spk_bstride,
+                 int B, int T, const char* tapname) {
+  const int H = e.hidden;
+  // cond_layer_idx == 2 > 0: the speaker add always rides on the previous layer's LN2 epilogue
+  for (int i = 0; i < e.n_layers; ++i) {
+    const EncLayerW& L = e.layer[i];
+    ConvProb p = c.prob(L.qkv, b.x, b.qkv, T);
+    c.conv1(p, B, T, "enc.qkv");
+    AttnArgs a;
+    a.qkv = b.qkv; a.mask = mask; a.erk = c.W(L.erk.off); a.erv = c.W(L.erv.off); a.out = b.att;
+    a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow;
+    if (!c.rc) {
+      const int pi = c.prof_begin("attention");
+      const int r = launch_attention(c.s, a);
+      c.prof_end(pi, "attention_relpos", attention_flops(a), 4.0 * B * 4 * H * (double)T);
+      if (r) c.fail("attention", r);
+    }
+    p = c.prob(L.o, b.att, b.s, T);
+    p.res = b.x; p.res_mode = RES_ADD;
+    c.conv1(p, B, T, "enc.o");
+    LnArgs l;
+    std::memset(&l, 0, sizeof(l));
+    l.a = b.s; l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T;
+    c.ln(l, "enc.ln1");
+    p = c.prob(L.ffn1, b.x, b.f1, T);
+    p.in_mask = mask; p.act = ACT_RELU;
+    c.conv1(p, B, T, "enc.ffn1");
+    p = c.prob(L.ffn2, b.f1, b.s, T);
+    p.in_mask = mask; p.out_mask = mask; p.mask_pre = 1; p.res = b.x; p.res_mode = RES_ADD;
+    c.conv1(p, B, T, "enc.ffn2");
+    l.a = b.s; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off);
+    if (i + 1 == kCondLayer && i + 1 < e.n_layers) { l.vec = spk; l.vec_bstride = spk_bstride; l.mask = mask; }
+    if (i + 1 == e.n_layers) l.mask = mask;
+    c.ln(l, "enc.ln2");
+    if (tapname) {
+      const std::string tn = std::string(tapname) + ".layer." + std::to_string(i);
+      c.tap(tn.c_str(), b.x, (int64_t)B * H * T);
+    }
+  }
+}
+
+// modules.DDSConv.forward (reference modules.py:118-130), 3 launches per layer:
+//   y1 = gelu(LN1(dwconv_k3,dil(x*mask)))   y2 = W_1x1 y1 (MFMA)   x = x + gelu(LN2(y2))   [*mask after the last]
+void run_dds(Ctx& c, const DDSW& d, float* x, float* y1, float* y2, const float* mask, int B, int C, int T) {
+  for (int i = 0; i < kSdpLayers; ++i) {
+    const DDSLayerW& L = d.l[i];
+    LnArgs l;
+    std::memset(&l, 0, sizeof(l));
+    l.a = x; l.mode = 1; l.dww = c.W(L.dww.off); l.dwb = c.W(L.dwb.off); l.dil = L.dil; l.in_mask = mask;
+    l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.post_gelu = 1; l.out = y1; l.B = B; l.C = C; l.T = T;
+    c.ln(l, "dds.ln1");
+    ConvProb p = c.prob(L.c1x1, y1, y2, T);
+    c.conv1(p, B, T, "dds.1x1");
+    std::memset(&l, 0, sizeof(l));
+    l.a = y2; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off); l.eps = 1e-5f; l.post_gelu = 1; l.res = x; l.out = x;
+    l.B = B; l.C = C; l.T = T;
+    if (i + 1 == kSdpLayers) l.mask = mask;
+    c.ln(l, "dds.ln2");
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct PlanA {
+  float *gv, *bsum, *dp0, *dp1, *dp2, *logw_dp, *sdp_h, *sdp_x, *y1, *y2, *z, *params, *logw_sdp;
+  EncBufs enc;
+};
+PlanA plan_a(Arena& A, const Model& m, int B, int T) {
+  const bv2_config& c = m.cfg;
+  const int64_t H = c.hidden_channels, BT = (int64_t)B * T;
+  PlanA p;
+  p.gv = A.get<float>((int64_t)B * 3 * H);
+  p.bsum = A.get<float>(BT * H);
+  p.enc.x = nullptr;   // encoder state lives in out.x
+  p.enc.s = A.get<float>(BT * H);
+  p.enc.att = A.get<float>(BT * H);
+  p.enc.qkv = A.get<float>(BT * 3 * H);
+  p.enc.f1 = A.get<float>(BT * c.filter_channels);
+  p.dp0 = A.get<float>(BT * H);
+  p.dp1 = A.get<float>(BT * kDpFilter);
+  p.dp2 = A.get<float>(BT * kDpFilter);
+  p.logw_dp = A.get<float>(BT);
+  p.logw_sdp = A.get<float>(BT);
+  p.sdp_h = A.get<float>(BT * H);
+  p.sdp_x = A.get<float>(BT * H);
+  p.y1 = A.get<float>(BT * H);
+  p.y2 = A.get<float>(BT * H);
+  p.z = A.get<float>(BT * 2);
+  p.params = A.get<float>(BT * 32);
+  return p;
+}
+
+struct PlanB {
+  float *gv, *zp, *z, *h, *xin, *acts, *rs, *outacc, *pre, *ymask;
+  int* fidx;
+  EncBufs enc;
+  float* set[2][7];
+  int gv_stride;
+};
+int64_t gen_unit(const Model& m) {      // max over stages of C_i * (samples per frame at stage i)
+  int64_t best = 0, up = 1;
+  for (int i = 0; i < m.n_ups; ++i) {
+    up *= m.ups[i].u;
+    const int64_t v = (int64_t)m.ups[i].cout * up;
+    best = v > best ? v : best;
+  }
+  return best;
+}
+PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
+  const bv2_config& c = m.cfg;
+  const int64_t H = c.hidden_channels, BT = (int64_t)B * Ty;
+  PlanB p;
+  std::memset(&p, 0, sizeof(p));
+  p.gv_stride = c.upsample_initial_channel +
+                (c.use_transformer_flow ? m.n_coupling * (int)H : m.n_coupling * 2 * (int)H * c.n_flow_layer);
+  p.gv = A.get<float>((int64_t)B * p.gv_stride);
+  p.fidx = A.get<int>(BT);
+  p.ymask = A.get<float>(BT);
+  p.zp = A.get<float>(BT * c.inter_channels);
+  p.z = A.get<float>(BT * c.inter_channels);
+  p.h = A.get<float>(BT * H);
+  if (c.use_transformer_flow) {
+    p.enc.x = p.h;
+    p.enc.s = A.get<float>(BT * H);
+    p.enc.att = A.get<float>(BT * H);
+    p.enc.qkv = A.get<float>(BT * 3 * H);
+    p.enc.f1 = A.get<float>(BT * c.filter_channels);
+  } else {
+    p.xin = A.get<float>(BT * 2 * H);
+    p.acts = A.get<float>(BT * H);
+    p.rs = A.get<float>(BT * 2 * H);
+    p.outacc = A.get<float>(BT * H);
+  }
+  p.pre = A.get<float>(BT * c.upsample_initial_channel);
+  const int64_t unit = gen_unit(m) * BT;
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 7; ++i) p.set[s][i] = A.get<float>(unit);
+  return p;
+}
+
+}  // namespace
+
+int64_t workspace_bytes(const Model& m, int B, int T, int Ty) {
+  Arena a(nullptr, 0), b(nullptr, 0);
+  plan_a(a, m, B, T);
+  plan_b(b, m, B, Ty);
+  return (a.off > b.off ? a.off : b.off) + 256;
+}
+
+// ===============================================================================================================
+// phase A: emb_g, enc_p, sdp, dp, durations
+int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_encode_out& out, void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  const bv2_config& cf = m.cfg;
+  const int B = in.B, T = in.T, H = cf.hidden_channels, C = cf.inter_channels;
+  Arena A(ws, wsb);
+  PlanA P = plan_a(A, m, B, T);
+  if (!A.ok()) { h->err = "workspace too small for bv2_encode_durations"; return -5; }
+  P.enc.x = out.x;
+  Ctx c{h, s, m, h->blob};
+  const float* mask = out.x_mask;
+
+  // g = emb_g(sid); x_mask; every g-conditioned vector of this phase in ONE GEMV launch
+  c.chk(launch_gather_rows(s, c.W(m.emb_g.off), in.sid, out.g, B, cf.gin_channels, cf.n_speakers), "emb_g");
+  c.chk(launch_seq_mask(s, in.x_lengths, out.x_mask, B, T), "x_mask");
+  float *spk = P.gv, *sdp_c = P.gv + H, *dp_c = P.gv + 2 * H;
+  {
+    GemvLaunch G;
+    std::memset(&G, 0, sizeof(G));
+    const GemvW* gw[3] = {&m.enc.spk, &m.sdp_cond, &m.dp_cond};
+    float* go[3] = {spk, sdp_c, dp_c};
+    for (int i = 0; i < 3; ++i) {
+      G.p[i].w = c.W(gw[i]->w_off); G.p[i].bias = c.W(gw[i]->b_off); G.p[i].out = go[i];
+      G.p[i].cout = gw[i]->cout; G.p[i].cin = gw[i]->cin; G.p[i].out_bstride = 3 * H;
+    }
+    G.nprob = 3; G.B = B; G.g = out.g; G.g_bstride = cf.gin_channels;
+    c.chk(launch_gemv(s, G), "gemv.A");
+  }
+
+  // ---- TextEncoder (reference models.py:377-400)
+  const float* berts[3] = {in.bert, in.ja_bert, in.en_bert};
+  for (int i = 0; i < 3; ++i) {
+    ConvProb p = c.prob(m.bert[i], berts[i], P.bsum, T);
+    if (i > 0) { p.res = P.bsum; p.res_mode = RES_ADD; }
+    c.conv1(p, B, T, "enc_p.bert_proj");
+  }
+  {
+    EmbedArgs e;
+    e.x = in.x; e.tone = in.tone; e.lang = in.language;
+    e.emb = c.W(m.emb.off); e.tone_emb = c.W(m.tone_emb.off); e.lang_emb = c.W(m.lang_emb.off);
+    e.n_vocab = cf.n_vocab; e.n_tones = cf.n_tones; e.n_langs = cf.n_languages;
+    e.bsum = P.bsum; e.mask = mask; e.out = out.x; e.scale = (float)std::sqrt((double)H); e.B = B; e.C = H; e.T = T;
+    c.chk(launch_embed(s, e), "embed");
+  }
+  c.tap("enc.x0", out.x, (int64_t)B * H * T);
+  run_encoder(c, m.enc, P.enc, mask, spk, 3 * H, B, T, "enc");
+  {
+    ConvLaunch cl;
+    cl.nprob = 2; cl.B = B; cl.L = T;
+    cl.p[0] = c.prob(m.proj_m, out.x, out.m_p, T);
+    cl.p[1] = c.prob(m.proj_logs, out.x, out.logs_p, T);
+    for (int i = 0; i < 2; ++i) { cl.p[i].out_mask = mask; cl.p[i].mask_post = 1; }
+    c.conv(cl, "enc_p.proj");
+  }
+
+  // ---- DurationPredictor (reference models.py:285-299)
+  c.chk(launch_add_vec_mask(s, out.x, dp_c, 3 * H, nullptr, P.dp0, B, H, T), "dp.cond");
+  {
+    ConvProb p = c.prob(m.dp_c1, P.dp0, P.dp1, T);
+    p.in_mask = mask; p.act = ACT_RELU;
+    c.conv1(p, B, T, "dp.conv_1");
+    LnArgs l;
+    std::memset(&l, 0, sizeof(l));
+    l.a = P.dp1; l.gamma = c.W(m.dp_g1.off); l.beta = c.W(m.dp_b1.off); l.eps = 1e-5f; l.out = P.dp1;
+    l.B = B; l.C = kDpFilter; l.T = T;
+    c.ln(l, "dp.norm_1");
+    p = c.prob(m.dp_c2, P.dp1, P.dp2, T);
+    p.in_mask = mask; p.act = ACT_RELU;
+    c.conv1(p, B, T, "dp.conv_2");
+    l.a = P.dp2; l.gamma = c.W(m.dp_g2.off); l.beta = c.W(m.dp_b2.off); l.out = P.dp2;
+    c.ln(l, "dp.norm_2");
+    p = c.prob(m.dp_proj, P.dp2, P.logw_dp, T);
+    p.in_mask = mask; p.out_mask = mask; p.mask_post = 1;
+    c.conv1(p, B, T, "dp.proj");
+  }
+
+  // ---- StochasticDurationPredictor, reverse (reference models.py:197-204, 245-256)
+  {
+    ConvProb p = c.prob(m.sdp_pre, out.x, P.sdp_h, T);
+    p.bias2 = sdp_c; p.bias2_bstride = 3 * H;                 // x = pre(x) + cond(g)
+    c.conv1(p, B, T, "sdp.pre");
+    run_dds(c, m.sdp_convs, P.sdp_h, P.y1, P.y2, mask, B, H, T);
+    p = c.prob(m.sdp_proj, P.sdp_h, P.sdp_x, T);
+    p.out_mask = mask; p.mask_post = 1;
+    c.conv1(p, B, T, "sdp.proj");
+    c.tap("sdp.x", P.sdp_x, (int64_t)B * H * T);
+    c.chk(launch_scale(s, in.noise_w, P.z, in.noise_scale_w, (int64_t)B * 2 * T), "sdp.noise");
+    // Flip, CF, Flip, CF, Flip, CF, Flip, EA: the 2-channel flips are index swaps (src/dst), never data movement
+    for (int i = 0; i < kSdpFlowsUsed; ++i) {
+      const int src = (i % 2 == 0) ? 1 : 0, dst = 1 - src;
+      const ConvFlowW& F = m.cf[i];
+      c.chk(launch_convflow_pre(s, P.z, src, c.W(F.pre_w.off), c.W(F.pre_b.off), P.sdp_x, P.sdp_h, B, H, T), "cf.pre");
+      run_dds(c, F.convs, P.sdp_h, P.y1, P.y2, mask, B, H, T);
+      p = c.prob(F.proj, P.sdp_h, P.params, T);
+      p.out_bstride = (int64_t)32 * T;
+      p.out_mask = mask; p.mask_post = 1;
+      c.conv1(p, B, T, "cf.proj");
+      c.chk(launch_spline(s, P.z, src, dst, P.params, 32, mask, (float)std::sqrt((double)H), 5.0f, B, T), "cf.spline");
+      const std::string tn = "sdp.z." + std::to_string(i);
+      c.tap(tn.c_str(), P.z, (int64_t)B * 2 * T);
+    }
+  }
+  {
+    DurArgs d;
+    d.z = P.z; d.ea_m = c.W(m.ea_m.off); d.ea_logs = c.W(m.ea_logs.off);
+    d.logw_dp = P.logw_dp; d.mask = mask;
+    d.sdp_ratio = in.sdp_ratio; d.one_minus_ratio = (float)(1.0 - (double)in.sdp_ratio); d.length_scale = in.length_scale;
+    d.logw_sdp = out.logw_sdp ? out.logw_sdp : P.logw_sdp; d.logw = out.logw; d.w_ceil = out.w_ceil; d.y_lengths = out.y_lengths;
+    d.B = B; d.T = T;
+    c.chk(launch_durations(s, d), "durations");
+  }
+  if (out.logw_dp && !c.rc)
+    (void)hipMemcpyAsync(out.logw_dp, P.logw_dp, sizeof(float) * (size_t)B * T, hipMemcpyDeviceToDevice, s);
+  (void)C;
+  return c.rc;
+}
+
+// ===============================================================================================================
+// flow reverse (reference models.py:138-145 / 438-445); z is updated in place
+static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, const float* g, int B, int Ty) {
+  const Model& m = c.m;
+  const bv2_config& cf = m.cfg;
+  const int H = cf.hidden_channels, C = cf.inter_channels, half = C / 2;
+  float* gv_flow = P.gv + cf.upsample_initial_channel;
+  for (int a = 0; a < m.n_coupling; ++a) {
+    const CouplingW& K = m.coupling[a];
+    float* x0 = z + (K.flipped ? (int64_t)half * Ty : 0);
+    float* x1 = z + (K.flipped ? 0 : (int64_t)half * Ty);
+    ConvProb p = c.prob(K.pre, x0, P.h, Ty);
+    p.x_bstride = (int64_t)C * Ty;
+    p.out_mask = ymask; p.mask_post = 1;
+    c.conv1(p, B, Ty, "flow.pre");
+    const float* hres = P.h;
+    if (cf.use_transformer_flow) {
+      run_encoder(c, K.enc, P.enc, ymask, gv_flow + a * H, P.gv_stride, B, Ty, nullptr);
+    } else {
+      const int nl = K.wn_layers;
+      const float* gl = gv_flow + (int64_t)a * 2 * H * nl;
+      for (int i = 0; i < nl; ++i) {
+        p = c.prob(K.wn_in[i], P.h, P.xin, Ty);
+        p.bias2 = gl + (int64_t)i * 2 * H; p.bias2_bstride = P.gv_stride;
+        c.conv1(p, B, Ty, "wn.in");
+        c.chk(launch_wn_gate(c.s, P.xin, P.acts, B, H, Ty), "wn.gate");
+        p = c.prob(K.wn_rs[i], P.acts, P.rs, Ty);
+        c.conv1(p, B, Ty, "wn.res_skip");
+        c.chk(launch_wn_res_skip(c.s, P.rs, P.h, P.outacc, ymask, B, H, Ty, i == nl - 1, i == 0), "wn.rs");
+      }
+      hres = P.outacc;
+    }
+    {
+      const std::string tn = "flow." + std::to_string(a) + ".enc";
+      c.tap(tn.c_str(), hres, (int64_t)B * H * Ty);
+    }
+    p = c.prob(K.post, hres, x1, Ty);                          // x1 = (x1 - post(h)) * mask, written in place
+    p.out_bstride = (int64_t)C * Ty; p.res = x1; p.res_bstride = (int64_t)C * Ty; p.res_mode = RES_RSUB;
+    p.out_mask = ymask; p.mask_post = 1;
+    c.conv1(p, B, Ty, "flow.post");
+    {
+      const std::string tn = "flow." + std::to_string(a) + ".z";
+      c.tap(tn.c_str(), z, (int64_t)B * C * Ty);
+    }
+  }
+}
+
+// Generator.forward (reference models.py:538-557)
+static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, const float* ymask, int B, int L, float* o) {
+  const Model& m = c.m;
+  const bv2_config& cf = m.cfg;
+  const int C = cf.inter_channels, c0 = cf.upsample_initial_channel;
+  {
+    // conv_pre((z*y_mask)[:, :, :L]) + cond(g)
+    ConvProb p = c.prob(m.conv_pre, z, P.pre, L);
+    p.x_bstride = (int64_t)C * z_rstride; p.x_rstride = z_rstride; p.Lin = L;
+    p.in_mask = ymask; p.in_mask_bstride = z_rstride;
+    p.bias2 = P.gv; p.bias2_bstride = P.gv_stride;
+    c.conv1(p, B, L, "dec.conv_pre");
+  }
+  c.tap("dec.pre", P.pre, (int64_t)B * c0 * L);
+  const float* src[3] = {P.pre, nullptr, nullptr};
+  int nsrc = 1;
+  int Lc = L;
+  for (int i = 0; i < m.n_ups; ++i) {
+    const UpW& U = m.ups[i];
+    float* const* S = P.set[i & 1];
+    float* x = S[0];
+    const int Lo = Lc * U.u;
+    {
+      // x = ConvTranspose1d(leaky_relu(mean of the previous stage's branches)) as U.u polyphase stride-1 convs
+      ConvLaunch cl;
+      cl.nprob = U.u; cl.B = B; cl.L = Lc;
+      for (int ph = 0; ph < U.u; ++ph) {
+        ConvProb p = c.prob(U.phase[ph], src[0], x, Lc);
+        p.x[1] = src[1]; p.x[2] = src[2]; p.nsrc = nsrc; p.in_scale = 1.f / (float)nsrc;
+        p.pre_act = PRE_LRELU; p.slope = 0.1f;
+        p.pad_left = U.pad_left[ph];
+        p.out_bstride = (int64_t)U.cout * Lo; p.out_rstride = Lo; p.out_tstride = U.u; p.out_toff = ph;
+        cl.p[ph] = p;
+      }
+      c.conv(cl, "dec.ups");
+    }
+    {
+      const std::string tn = "dec.ups." + std::to_string(i);
+      c.tap(tn.c_str(), x, (int64_t)B * U.cout * Lo);
+    }
+    // the n_rbk ResBlock1 branches run side by side: 2 launches per dilation step, each carrying all branches
+    const int nb = m.n_rbk;
+    for (int d = 0; d < m.n_rbd; ++d) {
+      ConvLaunch c1, c2;
+      c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
+      for (int jj = 0; jj < nb; ++jj) {
+        const int j = nb - 1 - jj;                              // widest kernel first: longest workgroups start first
+        float* cur = S[1 + j];
+        float* tmp = S[1 + nb + j];
+        const float* xin = d == 0 ? x : cur;
+        ConvProb p = c.prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
+        p.pre_act = PRE_LRELU; p.slope = 0.1f;
+        c1.p[jj] = p;
+        p = c.prob(m.rb[i][j][d][1], tmp, cur, Lo, 1);
+        p.pre_act = PRE_LRELU; p.slope = 0.1f;
+        p.res = xin; p.res_mode = RES_ADD;
+        c2.p[jj] = p;
+      }
+      c.conv(c1, "dec.resblock.convs1");
+      c.conv(c2, "dec.resblock.convs2");
+    }
+    for (int j = 0; j < nb; ++j) {
+      const std::string tn = "dec.rb." + std::to_string(i) + "." + std::to_string(j);
+      c.tap(tn.c_str(), S[1 + j], (int64_t)B * U.cout * Lo);
+    }
+    for (int j = 0; j < 3; ++j) src[j] = j < nb ? S[1 + j] : nullptr;
+    nsrc = nb;
+    Lc = Lo;
+  }
+  ConvPostArgs a;
+  std::memset(&a, 0, sizeof(a));
+  for (int j = 0; j < 3; ++j) a.x[j] = src[j];
+  a.nsrc = nsrc; a.in_scale = 1.f / (float)nsrc; a.x_bstride = (int64_t)m.post_c * Lc; a.x_rstride = Lc;
+  a.w = c.W(m.conv_post.off); a.out = o; a.out_bstride = Lc; a.C = m.post_c; a.k = m.post_k; a.L = Lc; a.B = B;
+  a.slope = 0.01f;                                            // F.leaky_relu default (models.py:553)
+  c.chk(launch_conv_post(c.s, a), "dec.conv_post");
+}
+
+static void phase_b_gemv(Ctx& c, const PlanB& P, const float* g, int B) {
+  const Model& m = c.m;
+  const bv2_config& cf = m.cfg;
+  GemvLaunch G;
+  std::memset(&G, 0, sizeof(G));
+  int n = 0;
+  auto add = [&](const GemvW& w, float* out) {
+    G.p[n].w = c.W(w.w_off); G.p[n].bias = c.W(w.b_off); G.p[n].out = out; G.p[n].cout = w.cout; G.p[n].cin = w.cin;
+    G.p[n].out_bstride = P.gv_stride;
+    ++n;
+  };
+  add(m.dec_cond, P.gv);
+  float* gf = P.gv + cf.upsample_initial_channel;
+  for (int a = 0; a < m.n_coupling; ++a) {
+    if (cf.use_transformer_flow) add(m.coupling[a].enc.spk, gf + a * cf.hidden_channels);
+    else add(m.coupling[a].wn_cond, gf + (int64_t)a * 2 * cf.hidden_channels * cf.n_flow_layer);
+  }
+  G.nprob = n; G.B = B; G.g = g; G.g_bstride = cf.gin_channels;
+  c.chk(launch_gemv(c.s, G), "gemv.B");
+}
+
+int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_decode_out& out, void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  const bv2_config& cf = m.cfg;
+  const int B = in.B, T = in.T, Ty = in.Ty, C = cf.inter_channels;
+  Arena A(ws, wsb);
+  PlanB P = plan_b(A, m, B, Ty);
+  if (!A.ok()) { h->err = "workspace too small for bv2_decode"; return -5; }
+  Ctx c{h, s, m, h->blob};
+  float* z = out.z ? out.z : P.z;
+  float* ymask = out.y_mask ? out.y_mask : P.ymask;
+
+  ExpandArgs e;
+  std::memset(&e, 0, sizeof(e));
+  e.w_ceil = in.w_ceil; e.x_mask = in.x_mask; e.y_lengths = in.y_lengths; e.m_p = in.m_p; e.logs_p = in.logs_p;
+  e.noise = in.noise_z; e.nz_bstride = in.nz_bstride; e.nz_cstride = in.nz_cstride; e.noise_scale = in.noise_scale;
+  e.frame_idx = P.fidx; e.attn = out.attn; e.y_mask = ymask; e.z_p = z; e.m_e = out.m_p; e.logs_e = out.logs_p;
+  e.B = B; e.C = C; e.T = T; e.Ty = Ty;
+  c.chk(launch_expand(s, e), "expand");
+  if (out.z_p && !c.rc)
+    (void)hipMemcpyAsync(out.z_p, z, sizeof(float) * (size_t)B * C * Ty, hipMemcpyDeviceToDevice, s);
+  phase_b_gemv(c, P, in.g, B);
+  flow_core(c, P, z, ymask, in.g, B, Ty);
+  const int L = (in.max_len > 0 && in.max_len < Ty) ? in.max_len : Ty;
+  gen_core(c, P, z, Ty, ymask, B, L, out.o);
+  return c.rc;
+}
+
+int run_flow(bv2_handle* h, hipStream_t s, int B, int Ty, const float* z_p, const int64_t* y_lengths, const float* g,
+             float* z, void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  Arena A(ws, wsb);
+  PlanB P = plan_b(A, m, B, Ty);
+  if (!A.ok()) { h->err = "workspace too small for bv2_stage_flow"; return -5; }
+  Ctx c{h, s, m, h->blob};
+  float* ymask = P.ymask;
+  c.chk(launch_seq_mask(s, y_lengths, ymask, B, Ty), "y_mask");
+  if (z != z_p)
+    (void)hipMemcpyAsync(z, z_p, sizeof(float) * (size_t)B * m.cfg.inter_channels * Ty, hipMemcpyDeviceToDevice, s);
+  phase_b_gemv(c, P, g, B);
+  flow_core(c, P, z, ymask, g, B, Ty);
+  return c.rc;
+}
+
+int run_generator(bv2_handle* h, hipStream_t s, int B, int Ty, int L, const float* z, const int64_t* y_lengths,
+                  const float* g, float* o, void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  if (L < 1 || L > Ty) { h->err = "bv2_stage_generator: need 1 <= L <= Ty"; return -1; }
+  Arena A(ws, wsb);
+  PlanB P = plan_b(A, m, B, Ty);
+  if (!A.ok()) { h->err = "workspace too small for bv2_stage_generator"; return -5; }
+  Ctx c{h, s, m, h->blob};
+  float* ymask = P.ymask;
+  c.chk(launch_seq_mask(s, y_lengths, ymask, B, Ty), "y_mask");
+  phase_b_gemv(c, P, g, B);
+  gen_core(c, P, z, Ty, ymask, B, L, o);
+  return c.rc;
+}
+
+}  // namespace bv2

@@ -1,0 +1,136 @@
+// bv2_internal.h — host-side model description (packed-weight layout), handle, and executor interfaces of libbv2.so.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bv2.h"
+#include "bv2_kernels.h"
+
+namespace bv2 {
+
+constexpr int kAttnWindow = 4;       // reference attentions.py:46
+constexpr int kCondLayer = 2;        // reference attentions.py:69-71
+constexpr int kSdpLayers = 3;        // DDSConv n_layers, reference models.py:171-173
+constexpr int kSdpKernel = 3;
+constexpr int kSdpBins = 10;
+constexpr int kSdpFlowsUsed = 3;     // ConvFlows applied at inference (the 4th is the dropped "useless vflow")
+constexpr int kDpFilter = 256;       // reference models.py:929-931
+constexpr int kDpKernel = 3;
+constexpr int kFlowKernel = 5;       // reference models.py:903-924
+constexpr int kMaxLayers = 16;
+constexpr int kMaxFlows = 8;
+constexpr uint32_t kBlobMagic = 0x32765642u;  // "BVv2"
+constexpr int kBlobHeaderFloats = 64;
+
+// ---- packed-weight descriptors: offsets are in floats from the start of the blob ----
+struct ConvW {
+  int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, w_ld = 0, k = 1;
+  int64_t w_off = -1, b_off = -1;    // b_off < 0: no bias
+};
+struct VecW { int64_t off = -1; int64_t n = 0; };
+struct GemvW { int cout = 0, cin = 0; int64_t w_off = -1, b_off = -1; };
+
+struct EncLayerW {
+  ConvW qkv, o, ffn1, ffn2;
+  VecW erk, erv, g1, b1, g2, b2;
+};
+struct EncoderW {
+  int n_layers = 0, ksize = 1, hidden = 0, filter = 0, heads = 0;
+  GemvW spk;
+  EncLayerW layer[kMaxLayers];
+};
+struct DDSLayerW { VecW dww, dwb; ConvW c1x1; VecW g1, b1, g2, b2; int dil = 1; };
+struct DDSW { DDSLayerW l[kSdpLayers]; };
+struct ConvFlowW { VecW pre_w, pre_b; DDSW convs; ConvW proj; };
+
+struct CouplingW {
+  bool flipped = false;              // channel Flip folded into pre/post weight permutations
+  ConvW pre, post;
+  EncoderW enc;                      // transformer flow
+  GemvW wn_cond;                     // residual (WN) flow
+  ConvW wn_in[kMaxLayers], wn_rs[kMaxLayers];
+  int wn_layers = 0;
+};
+
+struct UpW {
+  int u = 1, k = 1, cin = 0, cout = 0, ntaps = 1;
+  ConvW phase[BV2_MAX_UPS];          // one conv problem per output phase (polyphase ConvTranspose1d)
+  int pad_left[BV2_MAX_UPS];
+};
+
+struct Model {
+  bv2_config cfg;
+  // enc_p
+  VecW emb, tone_emb, lang_emb;
+  ConvW bert[3];
+  EncoderW enc;
+  ConvW proj_m, proj_logs;
+  // durations
+  ConvW sdp_pre, sdp_proj;
+  GemvW sdp_cond;
+  DDSW sdp_convs;
+  ConvFlowW cf[kSdpFlowsUsed];       // application order: flows.7, flows.5, flows.3
+  VecW ea_m, ea_logs;
+  GemvW dp_cond;
+  ConvW dp_c1, dp_c2, dp_proj;
+  VecW dp_g1, dp_b1, dp_g2, dp_b2;
+  VecW emb_g;
+  // flow: application order (reverse pass): a = 0 is reference flows.{2(n-1)}
+  int n_coupling = 0;
+  CouplingW coupling[kMaxFlows];
+  // dec
+  ConvW conv_pre;
+  GemvW dec_cond;
+  int n_ups = 0, n_rbk = 0, n_rbd = 0;
+  UpW ups[BV2_MAX_UPS];
+  ConvW rb[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS][BV2_MAX_RESBLOCK_DILATIONS][2];
+  VecW conv_post;
+  int post_c = 0, post_k = 7;
+  int total_up = 1;
+  int64_t total_floats = 0;
+  uint32_t cfg_hash = 0;
+};
+
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+
+struct ProfileRec { hipEvent_t e0, e1; int fam; double flops, bytes; };
+
+struct Tap { float* dst; int64_t cap; };
+
+}  // namespace bv2
+
+struct bv2_handle {
+  bv2::Model model;
+  std::map<std::string, bv2::HostTensor> tensors;
+  const float* blob = nullptr;       // device
+  std::string err;
+  std::map<std::string, bv2::Tap> taps;
+  // profiling
+  bool prof_on = false;
+  int prof_mode = 1;                 // 1: every MFMA kernel launch, 2: Generator (dec.*) launches only
+  std::vector<bv2::ProfileRec> prof_pool;
+  size_t prof_used = 0;
+  std::vector<std::string> prof_names;
+};
+
+namespace bv2 {
+
+// bv2_model.cpp
+int build_layout(Model& m, std::string& err);                       // fills every descriptor + total_floats
+int pack_blob(const Model& m, const std::map<std::string, HostTensor>& t, float* blob, std::string& err);
+bool key_in_schema(const Model& m, const std::string& key);
+
+// bv2_exec.cpp
+int64_t workspace_bytes(const Model& m, int B, int T, int Ty);
+int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_encode_out& out, void* ws, int64_t wsb);
+int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_decode_out& out, void* ws, int64_t wsb);
+int run_flow(bv2_handle* h, hipStream_t s, int B, int Ty, const float* z_p, const int64_t* y_lengths, const float* g,
+             float* z, void* ws, int64_t wsb);
+int run_generator(bv2_handle* h, hipStream_t s, int B, int Ty, int L, const float* z, const int64_t* y_lengths,
+                  const float* g, float* o, void* ws, int64_t wsb);
+
+}  // namespace bv2

@@ -1,0 +1,166 @@
+// bv2_kernels.h — launcher interface between the host executor (bv2_exec.cpp) and the gfx950 kernels (kernels/*.hip).
+// Every launcher is asynchronous on `stream`, allocates nothing, and is hipGraph-capturable.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace bv2 {
+
+// --------------------------------------------------------------------------------------------------------------
+// conv1d as implicit GEMM on fp32 MFMA (kernels/conv_mfma.hip)
+//
+//   out[b][co][t*out_tstride + out_toff] = epilogue( bias[co] + bias2[b][co]
+//        + sum_{ci<cin, j<k} Wp[j][ci][co] * pre( in_scale * sum_s x_s[b][ci][t - pad_left + j*dil] * in_mask[b][.] ) )
+//
+// Wp is the PACKED weight: [k][cin_pad][w_ld] fp32, co fastest (cin_pad % 16 == 0; w_ld % 128 == 0 is the row stride, so
+// any tile height may read a full row; rows >= cout are zero; cout_pad = cout rounded up to 32 bounds the tiling),
+// which makes both MFMA operands natural, conflict-free LDS row reads.  One launch can carry several problems
+// (blockIdx.z) that share B and L: the three ResBlock branches of a Generator stage, the u polyphase branches of a
+// ConvTranspose1d, or the m_p / logs_p halves of enc_p.proj.
+enum { PRE_NONE = 0, PRE_LRELU = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1 };
+enum { RES_NONE = 0, RES_ADD = 1, RES_RSUB = 2 };   // v += res  |  v = res - v
+
+struct ConvProb {
+  const float* x[3];        // input sources (summed); x[1], x[2] may be null
+  int nsrc;
+  float in_scale;
+  int64_t x_bstride;        // floats between batches
+  int x_rstride;            // floats between channels (row stride)
+  int Lin;                  // valid input length (reads outside [0,Lin) are zero padding)
+  const float* in_mask;     // [b*in_mask_bstride + t] or null
+  int in_mask_bstride;
+  const float* w;           // packed weights
+  const float* bias;        // [cout_pad] or null
+  const float* bias2;       // [B][bias2_bstride] per-batch bias or null
+  int bias2_bstride;
+  float* out;
+  int64_t out_bstride;
+  int out_rstride, out_tstride, out_toff;
+  const float* res;         // residual, indexed like out (own batch stride)
+  int64_t res_bstride;
+  const float* out_mask;    // [b*out_mask_bstride + t] or null
+  int out_mask_bstride;
+  int cin, cin_pad, cout, cout_pad, w_ld, k, dil, pad_left;
+  int pre_act;  float slope;
+  int act;                  // applied to acc+bias
+  int mask_pre;             // multiply by out_mask before the residual op
+  int res_mode;
+  int mask_post;            // multiply by out_mask after the residual op
+};
+
+#define BV2_MAX_PROBS 8
+struct ConvLaunch {
+  ConvProb p[BV2_MAX_PROBS];
+  int nprob;
+  int B;
+  int L;                    // output positions per problem (index t)
+};
+
+// tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
+enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5 };
+int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
+double conv_flops(const ConvLaunch& L);
+double conv_bytes(const ConvLaunch& L);
+
+// --------------------------------------------------------------------------------------------------------------
+// conv_post + tanh (kernels/misc.hip): out[b][t] = tanh( sum_{c,j} w[c][j] * lrelu_slope( in_scale*sum_s x_s[b][c][t-pad+j] ) )
+struct ConvPostArgs {
+  const float* x[3]; int nsrc; float in_scale; int64_t x_bstride; int x_rstride;
+  const float* w;           // [C][k] fp32 (unpadded)
+  float* out; int64_t out_bstride;
+  int C, k, L, B; float slope;
+};
+int launch_conv_post(hipStream_t stream, const ConvPostArgs& a);
+
+// --------------------------------------------------------------------------------------------------------------
+// channel LayerNorm family (kernels/layernorm.hip)
+//   v[c][t]   = a[b][c][t] (+ add[b][c][t])                         mode 0
+//             = dwb[c] + sum_j dww[c][j] * a[b][c][t+(j-1)*dil]*in_mask[b][.]   mode 1 (depthwise k=3, DDSConv)
+//   y         = (v - mean_c) * rsqrt(var_c + eps) * gamma[c] + beta[c];  y = gelu(y) if post_gelu
+//   out       = ((res ? res : 0) + y + (vec ? vec[b][c] : 0)) * (mask ? mask[b][t] : 1)
+struct LnArgs {
+  const float* a; const float* add;
+  int mode; const float* dww; const float* dwb; int dil; const float* in_mask;
+  const float* gamma; const float* beta; float eps;
+  int post_gelu;
+  const float* res; const float* vec; int vec_bstride; const float* mask;
+  float* out;
+  int B, C, T;
+};
+int launch_layernorm(hipStream_t stream, const LnArgs& a);
+
+// --------------------------------------------------------------------------------------------------------------
+// windowed relative-position multi-head attention (kernels/attention.hip), reference attentions.py:273-322
+struct AttnArgs {
+  const float* qkv;         // [B][3*H*D][T]: q rows [0,HD), k rows [HD,2HD), v rows [2HD,3HD); head h = rows h*D..h*D+D-1
+  const float* mask;        // [B][T]
+  const float* erk;         // [2W+1][D]
+  const float* erv;         // [2W+1][D]
+  float* out;               // [B][H*D][T]
+  int B, H, D, T, W;
+};
+int launch_attention(hipStream_t stream, const AttnArgs& a);
+double attention_flops(const AttnArgs& a);
+
+// --------------------------------------------------------------------------------------------------------------
+// small kernels (kernels/misc.hip)
+struct GemvProb { const float* w; const float* bias; float* out; int cout, cin; int out_bstride; };  // w [cout][cin]
+struct GemvLaunch { GemvProb p[16]; int nprob; int B; const float* g; int g_bstride; };
+int launch_gemv(hipStream_t stream, const GemvLaunch& L);            // out[b][co] = bias[co] + w[co][:]·g[b][:]
+
+int launch_gather_rows(hipStream_t stream, const float* table, const int64_t* idx, float* out, int B, int C, int nrows);
+int launch_seq_mask(hipStream_t stream, const int64_t* lengths, float* mask, int B, int T);
+
+// text-encoder front: out[b][c][t] = (emb[x][c] + tone_emb[tone][c] + lang_emb[lang][c] + bsum[b][c][t]) * scale * mask
+struct EmbedArgs {
+  const int64_t* x; const int64_t* tone; const int64_t* lang;
+  const float* emb; const float* tone_emb; const float* lang_emb;
+  int n_vocab, n_tones, n_langs;
+  const float* bsum; const float* mask; float* out; float scale; int B, C, T;
+};
+int launch_embed(hipStream_t stream, const EmbedArgs& a);
+
+// out[b][c][t] = (a[b][c][t] + vec[b][c]) * mask[b][t]     (vec / mask may be null)
+int launch_add_vec_mask(hipStream_t stream, const float* a, const float* vec, int vec_bstride, const float* mask,
+                        float* out, int B, int C, int T);
+
+// --- stochastic duration predictor glue (reference models.py:245-256, modules.py:486-516, transforms.py) ---
+int launch_scale(hipStream_t stream, const float* in, float* out, float s, int64_t n);
+// h[b][c][t] = w[c]*z[b][src][t] + bias[c] + g[b][c][t]       (ConvFlow.pre + the `x + g` of DDSConv)
+int launch_convflow_pre(hipStream_t stream, const float* z, int src, const float* w, const float* bias, const float* g,
+                        float* h, int B, int C, int T);
+// z[b][dst][t] = mask * rq_spline_inverse(z[b][dst][t]; params[b][0:29][t]);  z[b][src][t] *= mask
+int launch_spline(hipStream_t stream, float* z, int src, int dst, const float* params, int params_rows,
+                  const float* mask, float sqrt_fc, float tail_bound, int B, int T);
+// ElementwiseAffine^-1, logw mix, exp/ceil, cumsum, y_lengths (reference modules.py:397-399, models.py:1052-1057)
+struct DurArgs {
+  const float* z;           // [B][2][T] sdp state; logw_sdp = (z[:,0]-m0)*exp(-logs0)*mask
+  const float* ea_m; const float* ea_logs;   // device, [2] each (sdp.flows.0.m / .logs)
+  const float* logw_dp;     // [B][T]
+  const float* mask;
+  float sdp_ratio, one_minus_ratio, length_scale;   // one_minus_ratio = (float)(1.0 - (double)sdp_ratio)
+  float* logw_sdp; float* logw; float* w_ceil; int64_t* y_lengths;
+  int B, T;
+};
+int launch_durations(hipStream_t stream, const DurArgs& a);
+
+// --- length regulation (reference models.py:1058-1071, commons.py:126-140) ---
+struct ExpandArgs {
+  const float* w_ceil; const float* x_mask; const int64_t* y_lengths;
+  const float* m_p; const float* logs_p;             // [B][C][T]
+  const float* noise; int64_t nz_bstride, nz_cstride; float noise_scale;
+  int* frame_idx;                                     // [B][Ty] scratch
+  float* attn; float* y_mask; float* z_p; float* m_e; float* logs_e;   // outputs (attn/y_mask/m_e/logs_e may be null)
+  int B, C, T, Ty;
+};
+int launch_expand(hipStream_t stream, const ExpandArgs& a);
+
+// --- WN gate / res-skip (reference commons.py:98-105, modules.py:192-210) ---
+// acts[b][c][t] = tanh(xin[b][c][t]) * sigmoid(xin[b][c+H][t])        (g_l already added by the conv's bias2)
+int launch_wn_gate(hipStream_t stream, const float* xin, float* acts, int B, int H, int T);
+// not last: x = (x + rs[:, :H]) * mask ; outacc (+)= rs[:, H:]   | last: outacc (+)= rs ; finally outacc *= mask
+int launch_wn_res_skip(hipStream_t stream, const float* rs, float* x, float* outacc, const float* mask,
+                       int B, int H, int T, int last, int first);
+
+}  // namespace bv2

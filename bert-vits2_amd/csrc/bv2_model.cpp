@@ -1,0 +1,387 @@
+// bv2_model.cpp — packed-weight layout and the host-side packer.
+//
+// What the reference does on EVERY forward and we do ONCE at load:
+//   * weight_norm fold  w = g * v / ||v||  over all dims but 0 (dim 0 = C_out for Conv1d, C_in for ConvTranspose1d;
+//     reference models.py:513, modules.py:160-182, 226-292) — also accepts already folded `.weight` checkpoints
+//     (Generator.remove_weight_norm, models.py:559-564);
+// and what only a from-scratch layout can do:
+//   * conv weights re-laid as [tap][C_in pad16][C_out ld128] (C_out fastest) = the MFMA A-operand order;
+//   * conv_q/k/v fused into one 3*hidden-row projection;
+//   * ConvTranspose1d split into its u polyphase stride-1 convolutions (k/u taps each);
+//   * the flows' channel Flip (modules.py:374-381) folded into input/output channel permutations of pre/post,
+//     so no flip ever touches HBM;
+//   * enc_p.proj split into its m / logs halves (models.py:397-399).
+// The layout is a pure function of bv2_config, so every rank derives identical offsets and the blob can be broadcast.
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+#include "bv2_internal.h"
+
+namespace bv2 {
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+namespace {
+
+struct Packer {
+  const std::map<std::string, HostTensor>* T = nullptr;   // null => layout only
+  float* blob = nullptr;
+  int64_t cursor = kBlobHeaderFloats;
+  std::vector<std::string> missing;
+
+  bool fill() const { return blob != nullptr; }
+
+  int64_t alloc(int64_t n) {
+    const int64_t off = cursor;
+    cursor += (n + 63) / 64 * 64;                          // 256-byte alignment
+    if (fill()) std::memset(blob + off, 0, sizeof(float) * (size_t)((n + 63) / 64 * 64));
+    return off;
+  }
+
+  const HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape) {
+    if (!fill()) return nullptr;
+    auto it = T->find(key);
+    if (it == T->end()) { missing.push_back(key); return nullptr; }
+    std::vector<int64_t> want(shape);
+    if (it->second.shape != want) {
+      std::string s = key + " (shape mismatch: got [";
+      for (auto d : it->second.shape) s += std::to_string(d) + ",";
+      s += "] want [";
+      for (auto d : want) s += std::to_string(d) + ",";
+      s += "])";
+      missing.push_back(s);
+      return nullptr;
+    }
+    return &it->second;
+  }
+  bool has(const std::string& key) const { return fill() && T->count(key); }
+
+  // folded weight [d0][d1][k] of a (possibly weight-normed) conv; norm over all dims but 0
+  bool folded(const std::string& p, int d0, int d1, int k, std::vector<float>& w) {
+    if (!fill()) return false;
+    if (has(p + ".weight_v") || !has(p + ".weight")) {
+      const HostTensor* v = get(p + ".weight_v", {d0, d1, k});
+      const HostTensor* g = get(p + ".weight_g", {d0, 1, 1});
+      if (!v || !g) return false;
+      w.resize(v->data.size());
+      const int64_t inner = (int64_t)d1 * k;
+      for (int a = 0; a < d0; ++a) {
+        double ss = 0;
+        for (int64_t i = 0; i < inner; ++i) { const double x = v->data[a * inner + i]; ss += x * x; }
+        // torch computes the norm in fp32; a double sqrt rounded to fp32 agrees to <= 1 ulp
+        const float nrm = (float)std::sqrt(ss);
+        const float sc = g->data[a] / nrm;
+        for (int64_t i = 0; i < inner; ++i) w[a * inner + i] = v->data[a * inner + i] * sc;
+      }
+      return true;
+    }
+    const HostTensor* t = get(p + ".weight", {d0, d1, k});
+    if (!t) return false;
+    w = t->data;
+    return true;
+  }
+
+  VecW vec(const std::string& key, std::initializer_list<int64_t> shape) {
+    int64_t n = 1;
+    for (auto d : shape) n *= d;
+    VecW v; v.n = n; v.off = alloc(n);
+    if (const HostTensor* t = get(key, shape)) std::memcpy(blob + v.off, t->data.data(), sizeof(float) * (size_t)n);
+    return v;
+  }
+
+  // generic conv packer: src(co, ci, j) gives the folded weight, bsrc(co) the bias
+  ConvW conv(int cout, int cin, int k, bool bias, const std::function<float(int, int, int)>& src,
+             const std::function<float(int)>& bsrc, bool ok) {
+    ConvW c;
+    c.cin = cin; c.cout = cout; c.k = k;
+    c.cin_pad = round_up(cin, 16); c.cout_pad = round_up(cout, 32); c.w_ld = round_up(cout, 128);
+    c.w_off = alloc((int64_t)k * c.cin_pad * c.w_ld);
+    c.b_off = bias ? alloc(c.cout_pad) : -1;
+    if (fill() && ok) {
+      for (int j = 0; j < k; ++j)
+        for (int ci = 0; ci < cin; ++ci) {
+          float* row = blob + c.w_off + ((int64_t)j * c.cin_pad + ci) * c.w_ld;
+          for (int co = 0; co < cout; ++co) row[co] = src(co, ci, j);
+        }
+      if (bias)
+        for (int co = 0; co < cout; ++co) blob[c.b_off + co] = bsrc(co);
+    }
+    return c;
+  }
+
+  // plain nn.Conv1d `p` ([cout][cin][k] + bias), optional row range / channel permutations
+  ConvW conv1d(const std::string& p, int cout, int cin, int k, bool bias = true, bool wn = false, int row0 = 0,
+               int rows = -1, bool rev_in = false, bool rev_out = false) {
+    if (rows < 0) rows = cout;
+    std::vector<float> w;
+    const HostTensor* wt = nullptr;
+    bool ok = true;
+    if (fill()) {
+      if (wn) ok = folded(p, cout, cin, k, w);
+      else { wt = get(p + ".weight", {cout, cin, k}); ok = wt != nullptr; }
+    }
+    const float* wd = wn ? w.data() : (wt ? wt->data.data() : nullptr);
+    const HostTensor* bt = bias ? get(p + ".bias", {cout}) : nullptr;
+    if (bias && fill() && !bt) ok = false;
+    auto src = [&](int co, int ci, int j) {
+      const int sco = row0 + (rev_out ? rows - 1 - co : co);
+      const int sci = rev_in ? cin - 1 - ci : ci;
+      return wd[((int64_t)sco * cin + sci) * k + j];
+    };
+    auto bsrc = [&](int co) { return bt->data[row0 + (rev_out ? rows - 1 - co : co)]; };
+    return conv(rows, cin, k, bias, src, bsrc, ok);
+  }
+
+  GemvW gemv(const std::string& p, int cout, int cin, bool conv_shape, bool wn = false) {
+    GemvW g; g.cout = cout; g.cin = cin;
+    g.w_off = alloc((int64_t)cout * cin);
+    g.b_off = alloc(cout);
+    if (fill()) {
+      std::vector<float> w;
+      const float* wd = nullptr;
+      if (wn) { if (folded(p, cout, cin, 1, w)) wd = w.data(); }
+      else if (conv_shape) { if (auto* t = get(p + ".weight", {cout, cin, 1})) wd = t->data.data(); }
+      else { if (auto* t = get(p + ".weight", {cout, cin})) wd = t->data.data(); }
+      if (wd) std::memcpy(blob + g.w_off, wd, sizeof(float) * (size_t)cout * cin);
+      if (auto* b = get(p + ".bias", {cout})) std::memcpy(blob + g.b_off, b->data.data(), sizeof(float) * cout);
+    }
+    return g;
+  }
+};
+
+EncoderW pack_encoder(Packer& P, const std::string& p, int hidden, int filter, int heads, int layers, int ksize, int gin) {
+  EncoderW e;
+  e.n_layers = layers; e.ksize = ksize; e.hidden = hidden; e.filter = filter; e.heads = heads;
+  const int dk = hidden / heads, nr = 2 * kAttnWindow + 1;
+  e.spk = P.gemv(p + ".spk_emb_linear", hidden, gin, /*conv_shape=*/false);
+  for (int i = 0; i < layers; ++i) {
+    EncLayerW& L = e.layer[i];
+    const std::string a = p + ".attn_layers." + std::to_string(i);
+    // fused q/k/v projection (reference attentions.py:264-266 runs three 1x1 convs)
+    const HostTensor *wq = P.get(a + ".conv_q.weight", {hidden, hidden, 1}), *wk = P.get(a + ".conv_k.weight", {hidden, hidden, 1}),
+                     *wv = P.get(a + ".conv_v.weight", {hidden, hidden, 1});
+    const HostTensor *bq = P.get(a + ".conv_q.bias", {hidden}), *bk = P.get(a + ".conv_k.bias", {hidden}),
+                     *bv = P.get(a + ".conv_v.bias", {hidden});
+    const bool ok = wq && wk && wv && bq && bk && bv;
+    const HostTensor* ws[3] = {wq, wk, wv};
+    const HostTensor* bs[3] = {bq, bk, bv};
+    L.qkv = P.conv(3 * hidden, hidden, 1, true,
+                   [&](int co, int ci, int) { return ws[co / hidden]->data[(int64_t)(co % hidden) * hidden + ci]; },
+                   [&](int co) { return bs[co / hidden]->data[co % hidden]; }, ok);
+    L.o = P.conv1d(a + ".conv_o", hidden, hidden, 1);
+    L.erk = P.vec(a + ".emb_rel_k", {1, nr, dk});
+    L.erv = P.vec(a + ".emb_rel_v", {1, nr, dk});
+    L.g1 = P.vec(p + ".norm_layers_1." + std::to_string(i) + ".gamma", {hidden});
+    L.b1 = P.vec(p + ".norm_layers_1." + std::to_string(i) + ".beta", {hidden});
+    const std::string f = p + ".ffn_layers." + std::to_string(i);
+    L.ffn1 = P.conv1d(f + ".conv_1", filter, hidden, ksize);
+    L.ffn2 = P.conv1d(f + ".conv_2", hidden, filter, ksize);
+    L.g2 = P.vec(p + ".norm_layers_2." + std::to_string(i) + ".gamma", {hidden});
+    L.b2 = P.vec(p + ".norm_layers_2." + std::to_string(i) + ".beta", {hidden});
+  }
+  return e;
+}
+
+DDSW pack_dds(Packer& P, const std::string& p, int c) {
+  DDSW d;
+  int dil = 1;
+  for (int i = 0; i < kSdpLayers; ++i) {
+    DDSLayerW& L = d.l[i];
+    const std::string si = std::to_string(i);
+    L.dil = dil; dil *= kSdpKernel;
+    L.dww = P.vec(p + ".convs_sep." + si + ".weight", {c, 1, kSdpKernel});
+    L.dwb = P.vec(p + ".convs_sep." + si + ".bias", {c});
+    L.c1x1 = P.conv1d(p + ".convs_1x1." + si, c, c, 1);
+    L.g1 = P.vec(p + ".norms_1." + si + ".gamma", {c});
+    L.b1 = P.vec(p + ".norms_1." + si + ".beta", {c});
+    L.g2 = P.vec(p + ".norms_2." + si + ".gamma", {c});
+    L.b2 = P.vec(p + ".norms_2." + si + ".beta", {c});
+  }
+  return d;
+}
+
+uint32_t hash_cfg(const bv2_config& c) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(&c);
+  uint32_t h = 2166136261u;
+  for (size_t i = 0; i < sizeof(c); ++i) { h ^= p[i]; h *= 16777619u; }
+  return h;
+}
+
+int pack_all(Model& m, Packer& P) {
+  const bv2_config& c = m.cfg;
+  const int hid = c.hidden_channels, inter = c.inter_channels, filt = c.filter_channels, gin = c.gin_channels;
+  const int half = inter / 2;
+
+  // ---- enc_p (reference models.py:333-400)
+  m.emb = P.vec("enc_p.emb.weight", {c.n_vocab, hid});
+  m.tone_emb = P.vec("enc_p.tone_emb.weight", {c.n_tones, hid});
+  m.lang_emb = P.vec("enc_p.language_emb.weight", {c.n_languages, hid});
+  const char* bn[3] = {"enc_p.bert_proj", "enc_p.ja_bert_proj", "enc_p.en_bert_proj"};
+  for (int i = 0; i < 3; ++i) m.bert[i] = P.conv1d(bn[i], hid, c.bert_dim, 1);
+  m.enc = pack_encoder(P, "enc_p.encoder", hid, filt, c.n_heads, c.n_layers, c.kernel_size, gin);
+  m.proj_m = P.conv1d("enc_p.proj", 2 * inter, hid, 1, true, false, 0, inter);
+  m.proj_logs = P.conv1d("enc_p.proj", 2 * inter, hid, 1, true, false, inter, inter);
+
+  // ---- sdp (reference models.py:148-204, 245-256)
+  m.sdp_pre = P.conv1d("sdp.pre", hid, hid, 1);
+  m.sdp_proj = P.conv1d("sdp.proj", hid, hid, 1);
+  m.sdp_cond = P.gemv("sdp.cond", hid, gin, true);
+  m.sdp_convs = pack_dds(P, "sdp.convs", hid);
+  const int cf_idx[kSdpFlowsUsed] = {7, 5, 3};      // reversed(flows) minus the "useless vflow" (models.py:246-247)
+  for (int i = 0; i < kSdpFlowsUsed; ++i) {
+    const std::string p = "sdp.flows." + std::to_string(cf_idx[i]);
+    m.cf[i].pre_w = P.vec(p + ".pre.weight", {hid, 1, 1});
+    m.cf[i].pre_b = P.vec(p + ".pre.bias", {hid});
+    m.cf[i].convs = pack_dds(P, p + ".convs", hid);
+    m.cf[i].proj = P.conv1d(p + ".proj", 3 * kSdpBins - 1, hid, 1);
+  }
+  m.ea_m = P.vec("sdp.flows.0.m", {2, 1});
+  m.ea_logs = P.vec("sdp.flows.0.logs", {2, 1});
+
+  // ---- dp (reference models.py:259-299)
+  m.dp_cond = P.gemv("dp.cond", hid, gin, true);
+  m.dp_c1 = P.conv1d("dp.conv_1", kDpFilter, hid, kDpKernel);
+  m.dp_g1 = P.vec("dp.norm_1.gamma", {kDpFilter});
+  m.dp_b1 = P.vec("dp.norm_1.beta", {kDpFilter});
+  m.dp_c2 = P.conv1d("dp.conv_2", kDpFilter, kDpFilter, kDpKernel);
+  m.dp_g2 = P.vec("dp.norm_2.gamma", {kDpFilter});
+  m.dp_b2 = P.vec("dp.norm_2.beta", {kDpFilter});
+  m.dp_proj = P.conv1d("dp.proj", 1, kDpFilter, 1);
+
+  m.emb_g = P.vec("emb_g.weight", {c.n_speakers, gin});
+
+  // ---- flow, in APPLICATION order of the reverse pass (reference models.py:143-144 / 443-444)
+  m.n_coupling = c.use_transformer_flow ? c.n_flow_layer : 4;
+  for (int a = 0; a < m.n_coupling; ++a) {
+    CouplingW& C = m.coupling[a];
+    const int f = m.n_coupling - 1 - a;
+    const std::string p = "flow.flows." + std::to_string(2 * f);
+    C.flipped = (a % 2) == 0;                      // a+1 Flips have been applied before coupling a
+    C.pre = P.conv1d(p + ".pre", hid, half, 1, true, false, 0, -1, /*rev_in=*/C.flipped, false);
+    if (c.use_transformer_flow) {
+      C.enc = pack_encoder(P, p + ".enc", hid, filt, c.n_heads, c.n_layers_trans_flow, kFlowKernel, gin);
+    } else {
+      const int nl = c.n_flow_layer;
+      C.wn_layers = nl;
+      C.wn_cond = P.gemv(p + ".enc.cond_layer", 2 * hid * nl, gin, true, /*wn=*/true);
+      for (int i = 0; i < nl; ++i) {
+        C.wn_in[i] = P.conv1d(p + ".enc.in_layers." + std::to_string(i), 2 * hid, hid, kFlowKernel, true, true);
+        const int rs = i < nl - 1 ? 2 * hid : hid;
+        C.wn_rs[i] = P.conv1d(p + ".enc.res_skip_layers." + std::to_string(i), rs, hid, 1, true, true);
+      }
+    }
+    C.post = P.conv1d(p + ".post", half, hid, 1, true, false, 0, -1, false, /*rev_out=*/C.flipped);
+  }
+
+  // ---- dec (reference models.py:490-564)
+  const int c0 = c.upsample_initial_channel;
+  m.conv_pre = P.conv1d("dec.conv_pre", c0, inter, 7);
+  m.dec_cond = P.gemv("dec.cond", c0, gin, true);
+  m.n_ups = c.n_upsamples; m.n_rbk = c.n_resblock_kernels; m.n_rbd = c.n_resblock_dilations;
+  m.total_up = 1;
+  int ch = c0;
+  for (int i = 0; i < m.n_ups; ++i) {
+    UpW& U = m.ups[i];
+    U.u = c.upsample_rates[i]; U.k = c.upsample_kernel_sizes[i];
+    U.cin = c0 >> i; U.cout = c0 >> (i + 1);
+    U.ntaps = U.k / U.u;
+    const int pad = (U.k - U.u) / 2;
+    m.total_up *= U.u;
+    std::vector<float> w;                          // folded ConvTranspose1d weight [cin][cout][k]
+    const bool ok = P.folded("dec.ups." + std::to_string(i), U.cin, U.cout, U.k, w);
+    const HostTensor* bt = P.get("dec.ups." + std::to_string(i) + ".bias", {U.cout});
+    for (int ph = 0; ph < U.u; ++ph) {
+      // output n = u*s + ph gathers x[s + shift - mtap] * W[ci][co][pp + u*mtap]   
+      const int pp = (ph + pad) % U.u, shift = (ph + pad) / U.u;
+      U.pad_left[ph] = (U.ntaps - 1) - shift;
+      const int nt = U.ntaps, uu = U.u, kk = U.k, cout = U.cout;
+      U.phase[ph] = P.conv(U.cout, U.cin, nt, true,
+                           [&, pp, nt, uu, kk, cout](int co, int ci, int j) {
+                             return w[((int64_t)ci * cout + co) * kk + pp + uu * (nt - 1 - j)];
+                           },
+                           [&](int co) { return bt->data[co]; }, ok && bt);
+    }
+    ch = U.cout;
+    for (int j = 0; j < m.n_rbk; ++j) {
+      const int k = c.resblock_kernel_sizes[j];
+      const std::string rp = "dec.resblocks." + std::to_string(i * m.n_rbk + j);
+      for (int d = 0; d < m.n_rbd; ++d) {
+        m.rb[i][j][d][0] = P.conv1d(rp + ".convs1." + std::to_string(d), ch, ch, k, true, true);
+        m.rb[i][j][d][1] = P.conv1d(rp + ".convs2." + std::to_string(d), ch, ch, k, true, true);
+      }
+    }
+  }
+  m.post_c = ch;
+  m.conv_post = P.vec("dec.conv_post.weight", {1, ch, m.post_k});
+  m.total_floats = P.cursor;
+  return 0;
+}
+
+int validate(const bv2_config& c, std::string& err) {
+  auto bad = [&](const char* s) { err = s; return -1; };
+  if (c.struct_bytes != (int32_t)sizeof(bv2_config)) return bad("bv2_config.struct_bytes does not match this library");
+  if (c.n_heads < 1 || c.hidden_channels % c.n_heads) return bad("hidden_channels must be divisible by n_heads (attentions.py:223)");
+  const int dk = c.hidden_channels / c.n_heads;
+  if (dk % 32 || dk > 128) return bad("head dim must be a multiple of 32, <= 128");
+  if (c.hidden_channels > 256 || c.hidden_channels % 16) return bad("hidden_channels must be a multiple of 16, <= 256");
+  if (c.inter_channels % 32) return bad("inter_channels must be a multiple of 32");
+  if (c.n_layers < 1 || c.n_layers > kMaxLayers || c.n_layers_trans_flow > kMaxLayers) return bad("too many encoder layers");
+  if (c.n_layers <= kCondLayer) return bad("n_layers must exceed cond_layer_idx=2 (attentions.py:73-75)");
+  if (c.use_transformer_flow && c.n_layers_trans_flow <= kCondLayer) return bad("n_layers_trans_flow must exceed cond_layer_idx=2");
+  if (c.n_flow_layer < 1 || c.n_flow_layer > kMaxFlows) return bad("n_flow_layer out of range");
+  if (c.gin_channels < 1 || c.n_speakers < 1) return bad("gin_channels and n_speakers must be >= 1 (ReferenceEncoder path is out of scope)");
+  if (c.n_upsamples < 1 || c.n_upsamples > BV2_MAX_UPS) return bad("n_upsamples out of range");
+  if (c.n_resblock_kernels < 1 || c.n_resblock_kernels > 3) return bad("1..3 resblock kernels supported");
+  if (c.n_resblock_dilations < 1 || c.n_resblock_dilations > BV2_MAX_RESBLOCK_DILATIONS) return bad("resblock dilations out of range");
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+    if (u < 1 || u > BV2_MAX_UPS || k < u || k % u || (k - u) % 2) return bad("upsample kernel must be a multiple of its rate with even (k-u)");
+    if ((c.upsample_initial_channel >> (i + 1)) < 1) return bad("upsample_initial_channel too small");
+  }
+  if ((c.upsample_initial_channel >> c.n_upsamples) % 16) return bad("final Generator width must be a multiple of 16");
+  for (int j = 0; j < c.n_resblock_kernels; ++j)
+    if (c.resblock_kernel_sizes[j] % 2 == 0) return bad("resblock kernels must be odd");
+  if (c.kernel_size % 2 == 0) return bad("FFN kernel_size must be odd");
+  return 0;
+}
+
+}  // namespace
+
+int build_layout(Model& m, std::string& err) {
+  if (int rc = validate(m.cfg, err)) return rc;
+  Packer P;
+  pack_all(m, P);
+  m.cfg_hash = hash_cfg(m.cfg);
+  return 0;
+}
+
+int pack_blob(const Model& m_in, const std::map<std::string, HostTensor>& t, float* blob, std::string& err) {
+  Model m = m_in;
+  Packer P;
+  P.T = &t;
+  P.blob = blob;
+  std::memset(blob, 0, sizeof(float) * kBlobHeaderFloats);
+  pack_all(m, P);
+  if (!P.missing.empty()) {
+    err = "missing/invalid tensors (" + std::to_string(P.missing.size()) + "): ";
+    for (size_t i = 0; i < P.missing.size() && i < 12; ++i) err += P.missing[i] + "; ";
+    return -2;
+  }
+  if (m.total_floats != m_in.total_floats) { err = "internal: layout drift between passes"; return -4; }
+  uint32_t* hdr = reinterpret_cast<uint32_t*>(blob);
+  hdr[0] = kBlobMagic; hdr[1] = BV2_ABI_VERSION; hdr[2] = m_in.cfg_hash; hdr[3] = 0;
+  int64_t tf = m.total_floats;
+  std::memcpy(hdr + 4, &tf, sizeof(tf));
+  return 0;
+}
+
+bool key_in_schema(const Model& m, const std::string& key) {
+  (void)m;
+  static const char* ignored[] = {"enc_q.", "sdp.post_", "sdp.flows.1."};
+  for (const char* p : ignored)
+    if (key.compare(0, std::strlen(p), p) == 0) return false;
+  return true;
+}
+
+}  // namespace bv2

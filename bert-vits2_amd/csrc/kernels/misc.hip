@@ -1,0 +1,396 @@
+// misc.hip — the small, HBM/latency-bound kernels of the path: conv_post+tanh, speaker GEMVs, embeddings, masks,
+// the stochastic-duration-predictor glue (ConvFlow pre, inverse rational-quadratic spline, ElementwiseAffine^-1),
+// duration -> length regulation, WN gate / res-skip.  All fp32, all coalesced along time.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <cmath>
+#include "../bv2_kernels.h"
+
+namespace bv2 {
+
+#define BV2_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -1)
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv_post (C -> 1, k taps, no bias) + tanh, fed by leaky_relu(mean of the three ResBlock branches)
+// reference models.py:553-555 (NOTE slope 0.01 = F.leaky_relu default, not LRELU_SLOPE).
+__global__ void __launch_bounds__(256) conv_post_kernel(const ConvPostArgs A) {
+  extern __shared__ float ws[];                     // [C*k]
+  for (int i = threadIdx.x; i < A.C * A.k; i += 256) ws[i] = A.w[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= A.L) return;
+  const int pad = (A.k - 1) / 2;
+  float acc = 0.f;
+  for (int c = 0; c < A.C; ++c) {
+    const int64_t roff = (int64_t)b * A.x_bstride + (int64_t)c * A.x_rstride;
+    for (int j = 0; j < A.k; ++j) {
+      const int tt = t - pad + j;
+      if (tt < 0 || tt >= A.L) continue;
+      float v = A.x[0][roff + tt];
+      if (A.nsrc > 1) v += A.x[1][roff + tt];
+      if (A.nsrc > 2) v += A.x[2][roff + tt];
+      v *= A.in_scale;
+      v = v > 0.f ? v : v * A.slope;
+      acc += ws[c * A.k + j] * v;
+    }
+  }
+  A.out[(int64_t)b * A.out_bstride + t] = tanhf(acc);
+}
+
+int launch_conv_post(hipStream_t stream, const ConvPostArgs& a) {
+  dim3 grid((a.L + 255) / 256, a.B);
+  hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), sizeof(float) * a.C * a.k, stream, a);
+  return BV2_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// speaker-conditioning GEMVs: out[b][co] = bias[co] + W[co][:]·g[b][:]   (all the 1x1 convs / Linear applied to
+// g [B,gin,1]: Encoder.spk_emb_linear attentions.py:108, sdp.cond models.py:201-203, dp.cond :288-289,
+// dec.cond :541, WN.cond_layer modules.py:189-190).  One wave per output row, all problems in one launch.
+__global__ void __launch_bounds__(256) gemv_kernel(const GemvLaunch L) {
+  const GemvProb& P = L.p[blockIdx.y];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wid;
+  if (row >= P.cout) return;
+  const float* w = P.w + (int64_t)row * P.cin;
+  for (int b = 0; b < L.B; ++b) {
+    const float* g = L.g + (int64_t)b * L.g_bstride;
+    float acc = 0.f;
+    for (int k = lane; k < P.cin; k += 64) acc += w[k] * g[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) P.out[(int64_t)b * P.out_bstride + row] = acc + (P.bias ? P.bias[row] : 0.f);
+  }
+}
+
+int launch_gemv(hipStream_t stream, const GemvLaunch& L) {
+  if (L.nprob < 1 || L.nprob > 16) return -1;
+  int maxc = 0;
+  for (int i = 0; i < L.nprob; ++i) maxc = L.p[i].cout > maxc ? L.p[i].cout : maxc;
+  dim3 grid((maxc + 3) / 4, L.nprob);
+  hipLaunchKernelGGL(gemv_kernel, grid, dim3(256), 0, stream, L);
+  return BV2_CHECK_LAUNCH();
+}
+
+// g = emb_g(sid)  (models.py:1046)
+__global__ void gather_rows_kernel(const float* table, const int64_t* idx, float* out, int C, int nrows) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  int64_t r = idx[b];
+  r = r < 0 ? 0 : (r >= nrows ? nrows - 1 : r);
+  out[(int64_t)b * C + c] = table[r * C + c];
+}
+int launch_gather_rows(hipStream_t stream, const float* table, const int64_t* idx, float* out, int B, int C, int nrows) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, table, idx, out, C, nrows);
+  return BV2_CHECK_LAUNCH();
+}
+
+// x_mask = sequence_mask(x_lengths, T)  (commons.py:119-123)
+__global__ void seq_mask_kernel(const int64_t* lengths, float* mask, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < T) mask[(int64_t)b * T + t] = (int64_t)t < lengths[b] ? 1.f : 0.f;
+}
+int launch_seq_mask(hipStream_t stream, const int64_t* lengths, float* mask, int B, int T) {
+  hipLaunchKernelGGL(seq_mask_kernel, dim3((T + 255) / 256, B), dim3(256), 0, stream, lengths, mask, T);
+  return BV2_CHECK_LAUNCH();
+}
+
+// TextEncoder front (models.py:381-396): three embedding lookups + the summed BERT projections, * sqrt(hidden), * mask
+__global__ void embed_kernel(const EmbedArgs A) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= A.T) return;
+  const int64_t bt = (int64_t)b * A.T + t;
+  int64_t xi = A.x[bt], ti = A.tone[bt], li = A.lang[bt];
+  xi = xi < 0 ? 0 : (xi >= A.n_vocab ? A.n_vocab - 1 : xi);
+  ti = ti < 0 ? 0 : (ti >= A.n_tones ? A.n_tones - 1 : ti);
+  li = li < 0 ? 0 : (li >= A.n_langs ? A.n_langs - 1 : li);
+  const int64_t off = ((int64_t)b * A.C + c) * A.T + t;
+  float v = A.emb[xi * A.C + c] + A.tone_emb[ti * A.C + c];
+  v += A.lang_emb[li * A.C + c];
+  v += A.bsum[off];
+  A.out[off] = v * A.scale * A.mask[bt];
+}
+int launch_embed(hipStream_t stream, const EmbedArgs& a) {
+  hipLaunchKernelGGL(embed_kernel, dim3((a.T + 255) / 256, a.C, a.B), dim3(256), 0, stream, a);
+  return BV2_CHECK_LAUNCH();
+}
+
+__global__ void add_vec_mask_kernel(const float* a, const float* vec, int vec_bstride, const float* mask, float* out,
+                                    int C, int T) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int64_t off = ((int64_t)b * C + c) * T + t;
+  float v = a[off];
+  if (vec) v += vec[(int64_t)b * vec_bstride + c];
+  if (mask) v *= mask[(int64_t)b * T + t];
+  out[off] = v;
+}
+int launch_add_vec_mask(hipStream_t stream, const float* a, const float* vec, int vec_bstride, const float* mask,
+                        float* out, int B, int C, int T) {
+  hipLaunchKernelGGL(add_vec_mask_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, stream, a, vec, vec_bstride, mask,
+                     out, C, T);
+  return BV2_CHECK_LAUNCH();
+}
+
+__global__ void scale_kernel(const float* in, float* out, float s, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[i] * s;
+}
+int launch_scale(hipStream_t stream, const float* in, float* out, float s, int64_t n) {
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, s, n);
+  return BV2_CHECK_LAUNCH();
+}
+
+// ConvFlow.pre (1 -> C, k=1) fused with DDSConv's `x = x + g` (modules.py:488-489, 119-120)
+__global__ void convflow_pre_kernel(const float* z, int src, const float* w, const float* bias, const float* g, float* h,
+                                    int C, int T) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int64_t off = ((int64_t)b * C + c) * T + t;
+  h[off] = w[c] * z[((int64_t)b * 2 + src) * T + t] + bias[c] + g[off];
+}
+int launch_convflow_pre(hipStream_t stream, const float* z, int src, const float* w, const float* bias, const float* g,
+                        float* h, int B, int C, int T) {
+  hipLaunchKernelGGL(convflow_pre_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, stream, z, src, w, bias, g, h, C, T);
+  return BV2_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// inverse piecewise rational-quadratic spline with linear tails, K = 10 bins, one thread per (b, t); always fp32.
+// reference transforms.py:49-96 (tails) and :99-187 (inverse branch :160-173); op order kept (softmax, min-width
+// affine, sequential cumsum, knots forced to +-tail, widths as knot differences, searchsorted with +1e-6 on the last knot).
+constexpr int SPK = 10;
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__device__ void spline_knots(const float* u, float lo, float hi, float minw, float wscale, float* cum /*K+1*/,
+                             float* wd /*K*/) {
+  float mx = u[0];
+#pragma unroll
+  for (int i = 1; i < SPK; ++i) mx = fmaxf(mx, u[i]);
+  float e[SPK], sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < SPK; ++i) { e[i] = expf(u[i] - mx); sum += e[i]; }
+  float c = 0.f;
+  cum[0] = lo;
+#pragma unroll
+  for (int i = 0; i < SPK; ++i) {
+    const float w = minw + wscale * (e[i] / sum);
+    c += w;
+    cum[i + 1] = (hi - lo) * c + lo;
+  }
+  cum[SPK] = hi;
+#pragma unroll
+  for (int i = 0; i < SPK; ++i) wd[i] = cum[i + 1] - cum[i];
+}
+
+__global__ void spline_kernel(float* z, int src, int dst, const float* params, int prow, const float* mask,
+                              float sqrt_fc, float tail, float cst, float wscale, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 128 + threadIdx.x;
+  if (t >= T) return;
+  const float mk = mask[(int64_t)b * T + t];
+  const float* p = params + (int64_t)b * prow * T + t;
+  float uw[SPK], uh[SPK], ud[SPK + 1];
+#pragma unroll
+  for (int i = 0; i < SPK; ++i) { uw[i] = p[(int64_t)i * T] / sqrt_fc; uh[i] = p[(int64_t)(SPK + i) * T] / sqrt_fc; }
+  ud[0] = cst; ud[SPK] = cst;
+#pragma unroll
+  for (int i = 1; i < SPK; ++i) ud[i] = p[(int64_t)(2 * SPK + i - 1) * T];
+
+  float* zs = z + ((int64_t)b * 2 + src) * T + t;
+  float* zd = z + ((int64_t)b * 2 + dst) * T + t;
+  const float y = *zd;
+  float outv = y;
+  if (y >= -tail && y <= tail) {
+    float cw[SPK + 1], w[SPK], ch[SPK + 1], hh[SPK];
+    spline_knots(uw, -tail, tail, 1e-3f, wscale, cw, w);
+    spline_knots(uh, -tail, tail, 1e-3f, wscale, ch, hh);
+    int bin = -1;
+#pragma unroll
+    for (int i = 0; i <= SPK; ++i) {
+      const float kn = (i == SPK) ? ch[i] + 1e-6f : ch[i];
+      bin += (y >= kn) ? 1 : 0;
+    }
+    bin = bin < 0 ? 0 : (bin > SPK - 1 ? SPK - 1 : bin);
+    float icw = 0, iw = 0, ich = 0, ih = 0, d0 = 0, d1 = 0;
+#pragma unroll
+    for (int i = 0; i < SPK; ++i)
+      if (i == bin) { icw = cw[i]; iw = w[i]; ich = ch[i]; ih = hh[i]; d0 = 1e-3f + softplus_f(ud[i]); d1 = 1e-3f + softplus_f(ud[i + 1]); }
+    const float idl = ih / iw;
+    const float tt = y - ich;
+    const float s = d0 + d1 - 2.f * idl;
+    const float a = tt * s + ih * (idl - d0);
+    const float bq = ih * d0 - tt * s;
+    const float cq = -idl * tt;
+    const float disc = bq * bq - 4.f * a * cq;
+    const float root = (2.f * cq) / (-bq - sqrtf(disc));
+    outv = root * iw + icw;
+  }
+  *zd = outv * mk;
+  *zs = *zs * mk;
+}
+int launch_spline(hipStream_t stream, float* z, int src, int dst, const float* params, int params_rows,
+                  const float* mask, float sqrt_fc, float tail_bound, int B, int T) {
+  // constants the reference evaluates in Python doubles before they meet fp32 tensors (transforms.py:71, :128)
+  const float cst = (float)std::log(std::exp(1.0 - 1e-3) - 1.0);
+  const float wscale = (float)(1.0 - 1e-3 * SPK);
+  hipLaunchKernelGGL(spline_kernel, dim3((T + 127) / 128, B), dim3(128), 0, stream, z, src, dst, params, params_rows,
+                     mask, sqrt_fc, tail_bound, cst, wscale, T);
+  return BV2_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// durations: ElementwiseAffine^-1 on channel 0, mix sdp/dp, exp * mask * length_scale, ceil, sum -> y_lengths
+// reference modules.py:397-399, models.py:1052-1057.  One workgroup per utterance.
+__global__ void __launch_bounds__(256) durations_kernel(const DurArgs A) {
+  __shared__ float part[256];
+  const int b = blockIdx.x;
+  const float m0 = A.ea_m[0], il0 = expf(-A.ea_logs[0]);
+  float s = 0.f;
+  for (int t = threadIdx.x; t < A.T; t += 256) {
+    const int64_t bt = (int64_t)b * A.T + t;
+    const float mk = A.mask[bt];
+    const float ls = (A.z[((int64_t)b * 2) * A.T + t] - m0) * il0 * mk;
+    const float ld = A.logw_dp[bt];
+    const float lw = ls * A.sdp_ratio + ld * A.one_minus_ratio;
+    const float w = expf(lw) * mk * A.length_scale;
+    const float wc = ceilf(w);
+    if (A.logw_sdp) A.logw_sdp[bt] = ls;
+    A.logw[bt] = lw;
+    A.w_ceil[bt] = wc;
+    s += wc;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float tot = part[0];
+    A.y_lengths[b] = tot < 1.f ? 1 : (int64_t)tot;
+  }
+}
+int launch_durations(hipStream_t stream, const DurArgs& a) {
+  hipLaunchKernelGGL(durations_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  return BV2_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// length regulation.  Reference: generate_path builds a one-hot [B,Ty,T] matrix from cumsum(w_ceil) and multiplies
+// m_p / logs_p by it (commons.py:126-140, models.py:1061-1069); here frame j looks its symbol up directly:
+// symbol i owns frames [cum[i-1], cum[i]).  Pass 1 (one workgroup per utterance): scan + scatter frame->symbol.
+// Pass 2: gather + prior sampling z_p = m + noise*exp(logs)*noise_scale (models.py:1071).
+__global__ void __launch_bounds__(256) frame_index_kernel(const ExpandArgs A) {
+  __shared__ int part[256];
+  __shared__ int carry_s;
+  const int b = blockIdx.x;
+  const int ylen = (int)A.y_lengths[b];
+  int* fi = A.frame_idx + (int64_t)b * A.Ty;
+  for (int j = threadIdx.x; j < A.Ty; j += 256) {
+    fi[j] = -1;
+    if (A.y_mask) A.y_mask[(int64_t)b * A.Ty + j] = j < ylen ? 1.f : 0.f;
+  }
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  // symbols in chunks of 256: inclusive scan of durations, then each symbol writes its own frames
+  for (int base = 0; base < A.T; base += 256) {
+    const int i = base + threadIdx.x;
+    int d = 0;
+    if (i < A.T) d = (int)(A.w_ceil[(int64_t)b * A.T + i] * (A.x_mask[(int64_t)b * A.T + i] != 0.f ? 1.f : 0.f));
+    part[threadIdx.x] = d;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int end = carry_s + part[threadIdx.x];
+    const int start = end - d;
+    for (int j = start; j < end && j < ylen && j < A.Ty; ++j) fi[j] = i;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = end;
+    __syncthreads();
+  }
+}
+
+__global__ void expand_kernel(const ExpandArgs A) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= A.Ty) return;
+  const int i = A.frame_idx[(int64_t)b * A.Ty + j];
+  float m = 0.f, lg = 0.f;
+  if (i >= 0) {
+    m = A.m_p[((int64_t)b * A.C + c) * A.T + i];
+    lg = A.logs_p[((int64_t)b * A.C + c) * A.T + i];
+  }
+  const int64_t off = ((int64_t)b * A.C + c) * A.Ty + j;
+  const float nz = A.noise[(int64_t)b * A.nz_bstride + (int64_t)c * A.nz_cstride + j];
+  A.z_p[off] = m + nz * expf(lg) * A.noise_scale;
+  if (A.m_e) A.m_e[off] = m;
+  if (A.logs_e) A.logs_e[off] = lg;
+}
+
+__global__ void attn_path_kernel(const int* frame_idx, float* attn, int T, int Ty) {
+  const int b = blockIdx.z, j = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T) return;
+  attn[((int64_t)b * Ty + j) * T + i] = (frame_idx[(int64_t)b * Ty + j] == i) ? 1.f : 0.f;
+}
+
+int launch_expand(hipStream_t stream, const ExpandArgs& a) {
+  hipLaunchKernelGGL(frame_index_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(expand_kernel, dim3((a.Ty + 255) / 256, a.C, a.B), dim3(256), 0, stream, a);
+  if (a.attn)
+    hipLaunchKernelGGL(attn_path_kernel, dim3((a.T + 255) / 256, a.Ty, a.B), dim3(256), 0, stream, a.frame_idx, a.attn,
+                       a.T, a.Ty);
+  return BV2_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// WN gated activation and res/skip bookkeeping (reference commons.py:98-105, modules.py:192-210)
+__global__ void wn_gate_kernel(const float* xin, float* acts, int H, int T) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float a = xin[((int64_t)b * 2 * H + c) * T + t];
+  const float s = xin[((int64_t)b * 2 * H + H + c) * T + t];
+  acts[((int64_t)b * H + c) * T + t] = tanhf(a) * (1.f / (1.f + expf(-s)));
+}
+int launch_wn_gate(hipStream_t stream, const float* xin, float* acts, int B, int H, int T) {
+  hipLaunchKernelGGL(wn_gate_kernel, dim3((T + 255) / 256, H, B), dim3(256), 0, stream, xin, acts, H, T);
+  return BV2_CHECK_LAUNCH();
+}
+
+__global__ void wn_res_skip_kernel(const float* rs, float* x, float* outacc, const float* mask, int H, int T, int last,
+                                   int first) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int64_t off = ((int64_t)b * H + c) * T + t;
+  const float mk = mask[(int64_t)b * T + t];
+  if (!last) {
+    const int64_t r0 = ((int64_t)b * 2 * H + c) * T + t;
+    x[off] = (x[off] + rs[r0]) * mk;
+    const float sk = rs[r0 + (int64_t)H * T];
+    outacc[off] = first ? sk : outacc[off] + sk;
+  } else {
+    const float sk = rs[off];
+    outacc[off] = ((first ? 0.f : outacc[off]) + sk) * mk;
+  }
+}
+int launch_wn_res_skip(hipStream_t stream, const float* rs, float* x, float* outacc, const float* mask, int B, int H, int T,
+                       int last, int first) {
+  hipLaunchKernelGGL(wn_res_skip_kernel, dim3((T + 255) / 256, H, B), dim3(256), 0, stream, rs, x, outacc, mask, H, T,
+                     last, first);
+  return BV2_CHECK_LAUNCH();
+}
+
+}  // namespace bv2

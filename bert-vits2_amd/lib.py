@@ -1,0 +1,150 @@
+"""ctypes binding of ``libbv2.so`` (C ABI in ``include/bv2.h``) — the stub a reference maintainer would add.
+
+There is no fallback: if the library cannot be built/loaded this raises, loudly.  Nothing in here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+from . import hparams as H
+
+MAX_UPS = 8
+MAX_RBK = 4
+MAX_RBD = 4
+
+F32, F16, BF16 = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32),
+        ("n_vocab", C.c_int32), ("n_tones", C.c_int32), ("n_languages", C.c_int32), ("bert_dim", C.c_int32),
+        ("inter_channels", C.c_int32), ("hidden_channels", C.c_int32), ("filter_channels", C.c_int32),
+        ("n_heads", C.c_int32), ("n_layers", C.c_int32), ("kernel_size", C.c_int32),
+        ("gin_channels", C.c_int32), ("n_speakers", C.c_int32),
+        ("use_transformer_flow", C.c_int32), ("n_flow_layer", C.c_int32), ("n_layers_trans_flow", C.c_int32),
+        ("n_upsamples", C.c_int32),
+        ("upsample_rates", C.c_int32 * MAX_UPS),
+        ("upsample_kernel_sizes", C.c_int32 * MAX_UPS),
+        ("upsample_initial_channel", C.c_int32),
+        ("n_resblock_kernels", C.c_int32),
+        ("resblock_kernel_sizes", C.c_int32 * MAX_RBK),
+        ("n_resblock_dilations", C.c_int32),
+        ("resblock_dilation_sizes", (C.c_int32 * MAX_RBD) * MAX_RBK),
+    ]
+
+
+class EncodeIn(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32),
+        ("x", C.c_void_p), ("x_lengths", C.c_void_p), ("sid", C.c_void_p), ("tone", C.c_void_p), ("language", C.c_void_p),
+        ("bert", C.c_void_p), ("ja_bert", C.c_void_p), ("en_bert", C.c_void_p), ("noise_w", C.c_void_p),
+        ("noise_scale_w", C.c_float), ("sdp_ratio", C.c_float), ("length_scale", C.c_float),
+    ]
+
+
+class EncodeOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("g", "x", "m_p", "logs_p", "x_mask", "logw_sdp", "logw_dp", "logw", "w_ceil", "y_lengths")]
+
+
+class DecodeIn(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("Ty", C.c_int32), ("max_len", C.c_int32),
+        ("m_p", C.c_void_p), ("logs_p", C.c_void_p), ("x_mask", C.c_void_p), ("w_ceil", C.c_void_p),
+        ("y_lengths", C.c_void_p), ("g", C.c_void_p), ("noise_z", C.c_void_p),
+        ("nz_bstride", C.c_int64), ("nz_cstride", C.c_int64), ("noise_scale", C.c_float),
+    ]
+
+
+class DecodeOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("o", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")]
+
+
+class ProfileRow(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+# every symbol include/bv2.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("bv2_abi_version", C.c_int, []),
+    ("bv2_create", C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    ("bv2_destroy", None, [_P]),
+    ("bv2_last_error", C.c_char_p, [_P]),
+    ("bv2_load_tensor", C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int, C.c_int]),
+    ("bv2_packed_bytes", C.c_int64, [_P]),
+    ("bv2_pack_weights", C.c_int, [_P, _P, C.c_int64]),
+    ("bv2_attach_weights", C.c_int, [_P, _P, C.c_int64]),
+    ("bv2_workspace_bytes", C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
+    ("bv2_encode_durations", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64]),
+    ("bv2_decode", C.c_int, [_P, _P, C.POINTER(DecodeIn), C.POINTER(DecodeOut), _P, C.c_int64]),
+    ("bv2_stage_flow", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
+    ("bv2_stage_generator", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
+    ("bv2_infer", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.c_int64, C.c_float,
+                            C.c_int32, C.c_int32, C.POINTER(DecodeOut), C.POINTER(C.c_int32), _P, C.c_int64]),
+    ("bv2_set_tap", C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    ("bv2_profile_enable", C.c_int, [_P, C.c_int]),
+    ("bv2_profile_reset", C.c_int, [_P]),
+    ("bv2_profile_report", C.c_int, [_P, C.POINTER(ProfileRow), C.c_int]),
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load libbv2.so (building it with hipcc first if the sources changed).  Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and _build.needs_build():
+        _build.build(verbose=False)
+    if not os.path.exists(_build.LIB):
+        raise RuntimeError(f"{_build.LIB} is missing: the HIP extension must be built (python -m bert_vits2_amd.build); "
+                           "there is no CPU fallback")
+    lib = C.CDLL(_build.LIB)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)         # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bv2_abi_version() != 1:
+        raise RuntimeError("libbv2.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def make_config(hp: H.HParams) -> Config:
+    hp.validate()
+    c = Config()
+    c.struct_bytes = C.sizeof(Config)
+    c.n_vocab, c.n_tones, c.n_languages, c.bert_dim = hp.n_vocab, hp.n_tones, hp.n_languages, H.BERT_DIM
+    c.inter_channels, c.hidden_channels, c.filter_channels = hp.inter_channels, hp.hidden_channels, hp.filter_channels
+    c.n_heads, c.n_layers, c.kernel_size = hp.n_heads, hp.n_layers, hp.kernel_size
+    c.gin_channels, c.n_speakers = hp.gin_channels, hp.n_speakers
+    c.use_transformer_flow = int(bool(hp.use_transformer_flow))
+    c.n_flow_layer, c.n_layers_trans_flow = hp.n_flow_layer, hp.n_layers_trans_flow
+    ups, uks = list(hp.upsample_rates), list(hp.upsample_kernel_sizes)
+    if len(ups) != len(uks) or len(ups) > MAX_UPS:
+        raise ValueError("bad upsample configuration")
+    c.n_upsamples = len(ups)
+    for i, (u, k) in enumerate(zip(ups, uks)):
+        c.upsample_rates[i], c.upsample_kernel_sizes[i] = int(u), int(k)
+    c.upsample_initial_channel = hp.upsample_initial_channel
+    rk, rd = list(hp.resblock_kernel_sizes), [list(d) for d in hp.resblock_dilation_sizes]
+    if len(rk) > MAX_RBK or len(rd) != len(rk) or any(len(d) != len(rd[0]) or len(d) > MAX_RBD for d in rd):
+        raise ValueError("bad resblock configuration")
+    c.n_resblock_kernels = len(rk)
+    c.n_resblock_dilations = len(rd[0])
+    for j, k in enumerate(rk):
+        c.resblock_kernel_sizes[j] = int(k)
+        for d, v in enumerate(rd[j]):
+            c.resblock_dilation_sizes[j][d] = int(v)
+    return c

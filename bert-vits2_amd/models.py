@@ -1,0 +1,332 @@
+"""Drop-in ``SynthesizerTrn`` whose ``infer()`` runs on the hand-written gfx950 kernels of ``libbv2.so``.
+
+Mirrors the surface of reference ``models.SynthesizerTrn`` that its callers use
+(reference infer.py:84-104, 301-314; train_ms.py:772-784; utils.py:65-120):
+
+* the constructor signature (reference models.py:816-842), unknown ``**kwargs`` swallowed;
+* ``.to(device)`` / ``.eval()`` / ``.state_dict()`` / ``.load_state_dict(strict=False)`` with the reference's key
+  schema, so reference ``utils.load_checkpoint`` works unchanged;
+* ``.infer(x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_scale=.667, length_scale=1,
+  noise_scale_w=0.8, max_len=None, sdp_ratio=0, y=None)`` → ``(o, attn, y_mask, (z, z_p, m_p, logs_p))``
+  (reference models.py:1026-1074), same shapes/dtypes.
+
+This module is host plumbing only: PyTorch supplies device memory, the current HIP stream and the RNG; every FLOP of
+``infer()`` happens inside the C-ABI library.  There is deliberately NO PyTorch/CPU fallback: without a GPU or without
+the built library ``infer()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import hparams as H
+from . import lib as L
+from .schema import param_shapes
+
+
+class _Node(nn.Module):
+    """A bare namespace module: only there so that parameters carry the reference's dotted names."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise NotImplementedError("bert_vits2_amd exposes SynthesizerTrn.infer() only; sub-modules are parameter holders")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class SynthesizerTrn(nn.Module):
+    """Synthesizer (inference path) — see module docstring."""
+
+    def __init__(self, n_vocab, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes,
+                 upsample_rates, upsample_initial_channel, upsample_kernel_sizes, n_speakers=256, gin_channels=256,
+                 use_sdp=True, n_flow_layer=4, n_layers_trans_flow=4, flow_share_parameter=False,
+                 use_transformer_flow=True, **kwargs):
+        super().__init__()
+        self.hp = H.from_ctor(
+            n_vocab, spec_channels, segment_size, inter_channels=inter_channels, hidden_channels=hidden_channels,
+            filter_channels=filter_channels, n_heads=n_heads, n_layers=n_layers, kernel_size=kernel_size,
+            p_dropout=p_dropout, resblock=resblock, resblock_kernel_sizes=list(resblock_kernel_sizes),
+            resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes], upsample_rates=list(upsample_rates),
+            upsample_initial_channel=upsample_initial_channel, upsample_kernel_sizes=list(upsample_kernel_sizes),
+            n_speakers=n_speakers, gin_channels=gin_channels, use_sdp=use_sdp, n_flow_layer=n_flow_layer,
+            n_layers_trans_flow=n_layers_trans_flow, flow_share_parameter=flow_share_parameter,
+            use_transformer_flow=use_transformer_flow)
+        self.hp.validate()
+        # attributes the reference exposes and callers read
+        self.n_vocab, self.spec_channels, self.segment_size = n_vocab, spec_channels, segment_size
+        self.inter_channels, self.hidden_channels, self.filter_channels = inter_channels, hidden_channels, filter_channels
+        self.n_heads, self.n_layers, self.kernel_size, self.p_dropout = n_heads, n_layers, kernel_size, p_dropout
+        self.n_speakers, self.gin_channels = n_speakers, gin_channels
+        self.use_sdp = use_sdp
+        for key, shape in param_shapes(self.hp).items():
+            self._register(key, torch.zeros(shape, dtype=torch.float32))
+        self._lib = None
+        self._handle = C.c_void_p()
+        self._blob: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+        self._taps: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ parameter tree
+    def _register(self, key: str, value: torch.Tensor) -> None:
+        node = self
+        parts = key.split(".")
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        node.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._blob = None
+        if not strict:
+            # the reference loads with strict=False and tolerates training-only keys (enc_q.*, sdp.post_*)
+            own = set(k for k, _ in self.named_parameters())
+            state_dict = {k: v for k, v in state_dict.items() if k in own}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _apply(self, fn, *a, **k):
+        if getattr(self, "_blob", None) is not None:
+            self._blob = None
+        self._ws = None
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward() is out of scope; this class accelerates infer() only")
+
+    # ------------------------------------------------------------------ native handle / weights
+    @property
+    def device(self) -> torch.device:
+        # a rank that only received the packed blob (sharding.distribute_weights) runs where the blob lives
+        if self._blob is not None:
+            return self._blob.device
+        return next(self.parameters()).device
+
+    def _ensure_handle(self):
+        if self._lib is None:
+            self._lib = L.load()
+            cfg = L.make_config(self.hp)
+            rc = self._lib.bv2_create(C.byref(cfg), C.byref(self._handle))
+            if rc:
+                raise RuntimeError("bv2_create failed: " + self._lib.bv2_last_error(None).decode())
+        return self._lib
+
+    def _check(self, rc: int, what: str):
+        if rc:
+            raise RuntimeError(f"{what} failed ({rc}): {self._lib.bv2_last_error(self._handle).decode()}")
+
+    def __del__(self):
+        try:
+            if self._lib is not None and self._handle:
+                self._lib.bv2_destroy(self._handle)
+        except Exception:
+            pass
+
+    def pack_host_blob(self) -> torch.Tensor:
+        """Fold weight-norm / repack every tensor into the library's blob (host, uint8).  CPU-only: usable without a GPU."""
+        lib = self._ensure_handle()
+        for key, p in self.named_parameters():
+            t = p.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            rc = lib.bv2_load_tensor(self._handle, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(), L.F32)
+            if rc < 0:                         # rc == 1: a key the inference path ignores (e.g. sdp.flows.1.*)
+                self._check(rc, "bv2_load_tensor(" + key + ")")
+        n = lib.bv2_packed_bytes(self._handle)
+        blob = torch.empty(n, dtype=torch.uint8)
+        self._check(lib.bv2_pack_weights(self._handle, C.c_void_p(blob.data_ptr()), n), "bv2_pack_weights")
+        return blob
+
+    def attach_blob(self, dev_blob: torch.Tensor) -> None:
+        """Use an already packed blob resident on this GPU (e.g. received through an RCCL broadcast)."""
+        lib = self._ensure_handle()
+        assert dev_blob.is_cuda and dev_blob.dtype == torch.uint8 and dev_blob.is_contiguous()
+        self._check(lib.bv2_attach_weights(self._handle, C.c_void_p(dev_blob.data_ptr()), dev_blob.numel()),
+                    "bv2_attach_weights")
+        self._blob = dev_blob
+
+    def repack(self) -> None:
+        """(Re)build the packed device weights from the current parameters (call after editing parameters in place)."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("bert_vits2_amd.SynthesizerTrn.infer needs the model on a GPU (model.to('cuda')); "
+                               "there is no CPU fallback")
+        with torch.cuda.device(dev):
+            self.attach_blob(self.pack_host_blob().to(dev))
+
+    def _workspace(self, B: int, T: int, Ty: int) -> torch.Tensor:
+        n = self._lib.bv2_workspace_bytes(self._handle, B, T, Ty)
+        if n < 0:
+            raise RuntimeError("bv2_workspace_bytes failed")
+        if self._ws is None or self._ws.numel() < n or self._ws.device != self.device:
+            self._ws = torch.empty(int(n * 1.25), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def set_tap(self, name: Optional[str], tensor: Optional[torch.Tensor] = None) -> None:
+        """Debug: copy a named intermediate into ``tensor`` (fp32, CUDA) during the next calls."""
+        lib = self._ensure_handle()
+        if name is None:
+            self._taps.clear()
+            lib.bv2_set_tap(self._handle, None, None, 0)
+            return
+        if tensor is None:
+            self._taps.pop(name, None)
+            lib.bv2_set_tap(self._handle, name.encode(), None, 0)
+            return
+        self._taps[name] = tensor
+        lib.bv2_set_tap(self._handle, name.encode(), C.c_void_p(tensor.data_ptr()), tensor.numel())
+
+    # ------------------------------------------------------------------ the two phases
+    @torch.no_grad()
+    def encode_durations(self, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_w, noise_scale_w=0.8,
+                         sdp_ratio=0.0, length_scale=1.0) -> Dict[str, torch.Tensor]:
+        """Phase A = reference models.py:1045-1057.  ``noise_w`` [B,2,T] is the draw of models.py:248-251."""
+        if self._blob is None:
+            self.repack()
+        dev = self.device
+        B, T = x.shape
+        i64 = lambda t: t.to(dev, torch.int64).contiguous()
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        x, x_lengths, sid, tone, language = i64(x), i64(x_lengths), i64(sid), i64(tone), i64(language)
+        bert, ja_bert, en_bert, noise_w = f32(bert), f32(ja_bert), f32(en_bert), f32(noise_w)
+        if bert.shape != (B, H.BERT_DIM, T) or ja_bert.shape != bert.shape or en_bert.shape != bert.shape:
+            raise ValueError(f"bert features must be [B,{H.BERT_DIM},T] (reference infer.py:124)")
+        if noise_w.shape != (B, 2, T):
+            raise ValueError("noise_w must be [B,2,T]")
+        hp = self.hp
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = dict(g=e(B, hp.gin_channels), x=e(B, hp.hidden_channels, T), m_p=e(B, hp.inter_channels, T),
+                   logs_p=e(B, hp.inter_channels, T), x_mask=e(B, T), logw_sdp=e(B, T), logw_dp=e(B, T), logw=e(B, T),
+                   w_ceil=e(B, T), y_lengths=torch.empty(B, dtype=torch.int64, device=dev))
+        ein = L.EncodeIn(B, T, _ptr(x), _ptr(x_lengths), _ptr(sid), _ptr(tone), _ptr(language), _ptr(bert), _ptr(ja_bert),
+                         _ptr(en_bert), _ptr(noise_w), float(noise_scale_w), float(sdp_ratio), float(length_scale))
+        eout = L.EncodeOut(*[_ptr(out[k]) for k in ("g", "x", "m_p", "logs_p", "x_mask", "logw_sdp", "logw_dp", "logw",
+                                                    "w_ceil", "y_lengths")])
+        ws = self._workspace(B, T, 1)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self._lib.bv2_encode_durations(self._handle, stream, C.byref(ein), C.byref(eout),
+                                                       C.c_void_p(ws.data_ptr()), ws.numel()), "bv2_encode_durations")
+        return out
+
+    @torch.no_grad()
+    def decode(self, enc: Dict[str, torch.Tensor], noise_z: torch.Tensor, Ty: int, noise_scale=0.667, max_len=None,
+               want_attn: bool = True) -> Dict[str, torch.Tensor]:
+        """Phase B = reference models.py:1058-1073.  ``noise_z`` [B,inter,>=Ty] replaces randn_like at :1071."""
+        dev = self.device
+        hp = self.hp
+        B, _, T = enc["x"].shape
+        Ci = hp.inter_channels
+        assert noise_z.is_cuda and noise_z.dtype == torch.float32 and noise_z.stride(2) == 1 and noise_z.shape[2] >= Ty
+        L_dec = Ty if (max_len is None or max_len <= 0 or max_len >= Ty) else int(max_len)
+        S = L_dec * hp.total_upsample
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = dict(o=e(B, 1, S), attn=e(B, 1, Ty, T) if want_attn else None, y_mask=e(B, 1, Ty), z=e(B, Ci, Ty),
+                   z_p=e(B, Ci, Ty), m_p=e(B, Ci, Ty), logs_p=e(B, Ci, Ty))
+        din = L.DecodeIn(B, T, int(Ty), int(L_dec), _ptr(enc["m_p"]), _ptr(enc["logs_p"]), _ptr(enc["x_mask"]),
+                         _ptr(enc["w_ceil"]), _ptr(enc["y_lengths"]), _ptr(enc["g"]), _ptr(noise_z),
+                         noise_z.stride(0), noise_z.stride(1), float(noise_scale))
+        dout = L.DecodeOut(*[_ptr(out[k]) for k in ("o", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")])
+        ws = self._workspace(B, T, Ty)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self._lib.bv2_decode(self._handle, stream, C.byref(din), C.byref(dout), C.c_void_p(ws.data_ptr()),
+                                             ws.numel()), "bv2_decode")
+        return out
+
+    # ------------------------------------------------------------------ the reference entry point
+    @torch.no_grad()
+    def infer(self, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_scale=0.667, length_scale=1,
+              noise_scale_w=0.8, max_len=None, sdp_ratio=0, y=None, *, noise_w=None, noise_z=None, w_ceil=None,
+              want_attn=True):
+        """reference models.py:1026-1074.  Keyword-only extras (not in the reference): ``noise_w`` [B,2,T] and
+        ``noise_z`` [B,inter,>=T_y] inject the two N(0,1) draws (parity tests; the reference's ONNX export externalises
+        them the same way), ``w_ceil`` substitutes the durations, ``want_attn=False`` skips materialising the path."""
+        if self.device.type != "cuda":
+            raise RuntimeError("bert_vits2_amd.SynthesizerTrn.infer needs a GPU: no CPU fallback exists by design")
+        dev = self.device
+        B, T = x.shape
+        if noise_w is None:
+            noise_w = torch.randn(B, 2, T, device=dev, dtype=torch.float32)          # models.py:248-251
+        enc = self.encode_durations(x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_w,
+                                    noise_scale_w=noise_scale_w, sdp_ratio=sdp_ratio, length_scale=length_scale)
+        if w_ceil is not None:
+            wc = w_ceil.to(dev, torch.float32).reshape(B, T).contiguous()
+            enc["w_ceil"] = wc
+            enc["y_lengths"] = torch.clamp_min(wc.sum(1), 1).long()
+        Ty = int(enc["y_lengths"].max().item())        # the reference's one host sync (commons.py:120-122)
+        if noise_z is None:
+            noise_z = torch.randn(B, self.hp.inter_channels, Ty, device=dev, dtype=torch.float32)   # models.py:1071
+        else:
+            noise_z = noise_z.to(dev, torch.float32)
+            if noise_z.stride(2) != 1:
+                noise_z = noise_z.contiguous()
+        dec = self.decode(enc, noise_z, Ty, noise_scale=noise_scale, max_len=max_len, want_attn=want_attn)
+        self.last_encode = enc
+        return dec["o"], dec["attn"], dec["y_mask"], (dec["z"], dec["z_p"], dec["m_p"], dec["logs_p"])
+
+    # ------------------------------------------------------------------ single stages (reference ONNX seams)
+    @torch.no_grad()
+    def stage_flow(self, z_p: torch.Tensor, y_lengths: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        if self._blob is None:
+            self.repack()
+        B, Ci, Ty = z_p.shape
+        z_p = z_p.to(self.device, torch.float32).contiguous()
+        z = torch.empty_like(z_p)
+        yl = y_lengths.to(self.device, torch.int64).contiguous()
+        g = g.to(self.device, torch.float32).reshape(B, -1).contiguous()
+        ws = self._workspace(B, 1, Ty)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self._lib.bv2_stage_flow(self._handle, stream, B, Ty, _ptr(z_p), _ptr(yl), _ptr(g), _ptr(z),
+                                                 C.c_void_p(ws.data_ptr()), ws.numel()), "bv2_stage_flow")
+        return z
+
+    @torch.no_grad()
+    def stage_generator(self, z: torch.Tensor, y_lengths: torch.Tensor, g: torch.Tensor, L_frames: Optional[int] = None):
+        if self._blob is None:
+            self.repack()
+        B, Ci, Ty = z.shape
+        Lf = Ty if L_frames is None else int(L_frames)
+        z = z.to(self.device, torch.float32).contiguous()
+        yl = y_lengths.to(self.device, torch.int64).contiguous()
+        g = g.to(self.device, torch.float32).reshape(B, -1).contiguous()
+        o = torch.empty(B, 1, Lf * self.hp.total_upsample, dtype=torch.float32, device=self.device)
+        ws = self._workspace(B, 1, Ty)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self._lib.bv2_stage_generator(self._handle, stream, B, Ty, Lf, _ptr(z), _ptr(yl), _ptr(g), _ptr(o),
+                                                      C.c_void_p(ws.data_ptr()), ws.numel()), "bv2_stage_generator")
+        return o
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on=1):
+        """0 off, 1 time every MFMA kernel launch with HIP events, 2 only the Generator's launches."""
+        self._ensure_handle()
+        self._check(self._lib.bv2_profile_enable(self._handle, int(on)), "bv2_profile_enable")
+        self._lib.bv2_profile_reset(self._handle)
+
+    def profile_report(self):
+        rows = (L.ProfileRow * 32)()
+        n = self._lib.bv2_profile_report(self._handle, rows, 32)
+        out = []
+        for i in range(max(n, 0)):
+            r = rows[i]
+            out.append(dict(name=r.name.decode(), launches=r.launches, total_ms=r.total_ms, flops=r.flops, bytes=r.bytes))
+        self._lib.bv2_profile_reset(self._handle)
+        return out
+
+
+def from_hparams(hp: H.HParams) -> SynthesizerTrn:
+    return SynthesizerTrn(
+        hp.n_vocab, hp.spec_channels, hp.segment_size, inter_channels=hp.inter_channels, hidden_channels=hp.hidden_channels,
+        filter_channels=hp.filter_channels, n_heads=hp.n_heads, n_layers=hp.n_layers, kernel_size=hp.kernel_size,
+        p_dropout=hp.p_dropout, resblock=hp.resblock, resblock_kernel_sizes=hp.resblock_kernel_sizes,
+        resblock_dilation_sizes=hp.resblock_dilation_sizes, upsample_rates=hp.upsample_rates,
+        upsample_initial_channel=hp.upsample_initial_channel, upsample_kernel_sizes=hp.upsample_kernel_sizes,
+        n_speakers=hp.n_speakers, gin_channels=hp.gin_channels, use_sdp=hp.use_sdp, n_flow_layer=hp.n_flow_layer,
+        n_layers_trans_flow=hp.n_layers_trans_flow, flow_share_parameter=hp.flow_share_parameter,
+        use_transformer_flow=hp.use_transformer_flow)

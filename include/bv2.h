@@ -1,0 +1,184 @@
+/*
+ * bv2.h — C ABI of libbv2.so, the MI355X-native (gfx950) SynthesizerTrn.infer() hot path of Bert-VITS2 v2.3.
+ *
+ * The reference (fishaudio/Bert-VITS2) is 100 % Python and has NO FFI/operator interface; the only seam is the
+ * Python class models.SynthesizerTrn (reference models.py:811-1074).  This header is therefore the boundary a
+ * maintainer would bind from the reference's Python (ctypes stub shown in INTEGRATION.md); each entry point names
+ * the reference code it replaces.  The stage split mirrors the reference's own ONNX export, which cuts infer() into
+ * emb / enc_p / sdp / dp / flow / dec and makes both noise draws explicit inputs
+ * (reference onnx_modules/V230/models_onnx.py:896-1063, onnx_modules/V220_OnnxInference/__init__.py:88-117).
+ *
+ * Conventions
+ *  - plain C, no torch types: raw pointers + sizes.  All activations are fp32, layout [B, C, T], T contiguous
+ *    (the reference's layout).  Integer inputs are int64 like the reference's LongTensors.
+ *  - every DEVICE buffer (inputs, outputs, workspace, packed weights) is allocated and owned by the CALLER
+ *    (PyTorch in the shim).  The library never hipMalloc's; it only launches kernels / async copies on the
+ *    stream it is handed, so every entry point is hipGraph-capturable.
+ *  - status: 0 = ok, negative = error; bv2_last_error(h) holds the message (no exceptions cross the ABI).
+ *    The reference raises Python exceptions at the same places (shape asserts infer.py:124, ValueError
+ *    transforms.py:113-114); the Python shim turns a non-zero status into RuntimeError.
+ *  - one handle per GPU / per caller thread (thread-compatible, like the single-threaded reference).
+ */
+#ifndef BV2_H
+#define BV2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BV2_ABI_VERSION 1
+#define BV2_MAX_UPS 8
+#define BV2_MAX_RESBLOCK_KERNELS 4
+#define BV2_MAX_RESBLOCK_DILATIONS 4
+
+typedef struct bv2_handle bv2_handle;
+typedef void* bv2_stream; /* hipStream_t */
+
+/* Construction arguments of reference SynthesizerTrn.__init__ (models.py:816-842) that shape the hot path,
+ * as infer.get_net_g derives them from configs/config.json (infer.py:95-101). */
+typedef struct bv2_config {
+  int32_t struct_bytes;            /* = sizeof(bv2_config) */
+  int32_t n_vocab, n_tones, n_languages, bert_dim;      /* 112, 12, 3, 1024 (text/symbols.py:167-183) */
+  int32_t inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size;
+  int32_t gin_channels, n_speakers;
+  int32_t use_transformer_flow, n_flow_layer, n_layers_trans_flow;
+  int32_t n_upsamples;
+  int32_t upsample_rates[BV2_MAX_UPS];
+  int32_t upsample_kernel_sizes[BV2_MAX_UPS];
+  int32_t upsample_initial_channel;
+  int32_t n_resblock_kernels;
+  int32_t resblock_kernel_sizes[BV2_MAX_RESBLOCK_KERNELS];
+  int32_t n_resblock_dilations;
+  int32_t resblock_dilation_sizes[BV2_MAX_RESBLOCK_KERNELS][BV2_MAX_RESBLOCK_DILATIONS];
+} bv2_config;
+
+enum { BV2_F32 = 0, BV2_F16 = 1, BV2_BF16 = 2 };
+
+/* ---- lifetime ------------------------------------------------------------------------------------------- */
+int bv2_abi_version(void);
+/* replaces SynthesizerTrn.__init__ (models.py:816-935). */
+int bv2_create(const bv2_config* cfg, bv2_handle** out);
+void bv2_destroy(bv2_handle* h);
+/* h may be NULL: returns the message of the last failed bv2_create on this thread. */
+const char* bv2_last_error(const bv2_handle* h);
+
+/* ---- weights: replaces utils.load_checkpoint (utils.py:65-120) + per-forward weight_norm ---- */
+/* Hand over one tensor of the reference state_dict by its reference key.  host_ptr is HOST
+ * memory, copied.  Keys outside the inference schema (enc_q.*, sdp.post_*) are accepted and ignored (returns 1).
+ * Both weight-norm forms are accepted: <p>.weight_g + <p>.weight_v, or the folded <p>.weight that
+ * Generator.remove_weight_norm (models.py:559-564) leaves behind. */
+int bv2_load_tensor(bv2_handle* h, const char* ref_key, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
+/* Size in bytes of the packed weight blob for this config. */
+int64_t bv2_packed_bytes(const bv2_handle* h);
+/* Fold weight-norm (w = g*v/||v||, dim 0; C_in for ConvTranspose1d), fold the flows' channel Flips into weight
+ * permutations, fuse q/k/v, split ConvTranspose into polyphase taps, pad to MFMA tile multiples, and write the
+ * packed blob into host_blob (HOST memory, bv2_packed_bytes large).  Fails listing any missing tensor. */
+int bv2_pack_weights(bv2_handle* h, void* host_blob, int64_t bytes);
+/* Point the handle at a packed blob resident in DEVICE memory (caller-owned; e.g. uploaded by rank 0 and broadcast
+ * to the other GPUs with RCCL).  Verifies the blob header against this handle's config. */
+int bv2_attach_weights(bv2_handle* h, const void* dev_blob, int64_t bytes);
+
+/* ---- workspace ------------------------------------------------------------------------------------------- */
+/* Bytes of caller-provided DEVICE scratch needed by any stage call with batch B, T symbols, Ty_max frames. */
+int64_t bv2_workspace_bytes(const bv2_handle* h, int B, int T, int Ty_max);
+
+/* ---- phase A: models.py:1045-1057 (emb_g, enc_p, sdp, dp, exp/ceil/sum) ------------------------------------- */
+typedef struct bv2_encode_in {
+  int32_t B, T;
+  const int64_t* x;          /* [B,T] symbol ids */
+  const int64_t* x_lengths;  /* [B] */
+  const int64_t* sid;        /* [B] */
+  const int64_t* tone;       /* [B,T] */
+  const int64_t* language;   /* [B,T] */
+  const float* bert;         /* [B,bert_dim,T] */
+  const float* ja_bert;      /* [B,bert_dim,T] */
+  const float* en_bert;      /* [B,bert_dim,T] */
+  const float* noise_w;      /* [B,2,T]  N(0,1): the torch.randn of models.py:248-251, drawn by the caller */
+  float noise_scale_w, sdp_ratio, length_scale;
+} bv2_encode_in;
+
+typedef struct bv2_encode_out {   /* all DEVICE, caller-allocated */
+  float* g;          /* [B,gin]            emb_g(sid)                       models.py:1046 */
+  float* x;          /* [B,hidden,T]       encoder output                   models.py:1049 */
+  float* m_p;        /* [B,inter,T] */
+  float* logs_p;     /* [B,inter,T] */
+  float* x_mask;     /* [B,T] (1.0 / 0.0)                                  models.py:392-394 */
+  float* logw_sdp;   /* [B,T]  sdp(...) before mixing (may be NULL) */
+  float* logw_dp;    /* [B,T]  dp(...)  before mixing (may be NULL) */
+  float* logw;       /* [B,T]                                              models.py:1052-1054 */
+  float* w_ceil;     /* [B,T]  ceil(exp(logw)*mask*length_scale)           models.py:1055-1056 */
+  int64_t* y_lengths;/* [B]    clamp_min(sum(w_ceil),1)                    models.py:1057 */
+} bv2_encode_out;
+
+int bv2_encode_durations(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* out,
+                         void* workspace, int64_t workspace_bytes);
+
+/* ---- phase B: models.py:1058-1073 (sequence_mask, generate_path, expand, z_p, flow reverse, dec) ------------ */
+typedef struct bv2_decode_in {
+  int32_t B, T;
+  int32_t Ty;                /* max(y_lengths), read back by the caller (the reference's one host sync, commons.py:120-122) */
+  int32_t max_len;           /* frames fed to dec: (z*y_mask)[:, :, :max_len]; <=0 means all (models.py:1073) */
+  const float* m_p;          /* [B,inter,T]  from phase A */
+  const float* logs_p;       /* [B,inter,T] */
+  const float* x_mask;       /* [B,T] */
+  const float* w_ceil;       /* [B,T]  (the caller may substitute durations, as train_ms.evaluate-style tooling does) */
+  const int64_t* y_lengths;  /* [B] */
+  const float* g;            /* [B,gin] */
+  const float* noise_z;      /* N(0,1) for models.py:1071; element (b,c,j) at noise_z[b*nz_bstride + c*nz_cstride + j] */
+  int64_t nz_bstride, nz_cstride;
+  float noise_scale;
+} bv2_decode_in;
+
+typedef struct bv2_decode_out {   /* all DEVICE, caller-allocated; any pointer except o may be NULL */
+  float* o;          /* [B,1,S]  S = min(Ty,max_len) * prod(upsample_rates) */
+  float* attn;       /* [B,1,Ty,T] one-hot monotone path                   models.py:1061-1062 */
+  float* y_mask;     /* [B,1,Ty] */
+  float* z;          /* [B,inter,Ty] */
+  float* z_p;        /* [B,inter,Ty] */
+  float* m_p;        /* [B,inter,Ty] expanded */
+  float* logs_p;     /* [B,inter,Ty] expanded */
+} bv2_decode_out;
+
+int bv2_decode(bv2_handle* h, bv2_stream stream, const bv2_decode_in* in, const bv2_decode_out* out,
+               void* workspace, int64_t workspace_bytes);
+
+/* ---- single stages (the reference's ONNX seams; used by the parity tests and by stage-level consumers) ------- */
+/* flow(z_p, y_mask, g, reverse=True), models.py:1072.  z_p is not modified; z receives the result. */
+int bv2_stage_flow(bv2_handle* h, bv2_stream stream, int B, int Ty, const float* z_p, const int64_t* y_lengths,
+                   const float* g, float* z, void* workspace, int64_t workspace_bytes);
+/* dec((z*y_mask)[:, :, :L], g), models.py:1073 / Generator.forward models.py:538-557.  o is [B,1,L*prod(rates)];
+ * z has row stride Ty. */
+int bv2_stage_generator(bv2_handle* h, bv2_stream stream, int B, int Ty, int L, const float* z, const int64_t* y_lengths,
+                        const float* g, float* o, void* workspace, int64_t workspace_bytes);
+
+/* ---- one-shot convenience: whole infer() with an internal stream sync between the phases ---------------------- */
+/* Outputs must be sized for Ty_cap frames; returns -3 (and sets *Ty_out) if the realised Ty exceeds Ty_cap.
+ * Row strides of the [.,.,Ty] outputs are the realised Ty (*Ty_out), tensors are written densely. */
+int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* enc_out,
+              const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, float noise_scale, int32_t max_len,
+              int32_t Ty_cap, const bv2_decode_out* dec_out, int32_t* Ty_out, void* workspace, int64_t workspace_bytes);
+
+/* ---- debugging / measurement ------------------------------------------------------------------------------ */
+/* Ask the executor to copy a named intermediate (e.g. "dec.ups.0", "dec.stage.2", "flow.3.h", "enc.layer.1")
+ * into dev_dst (capacity in floats) the next time it is produced.  name==NULL clears all taps. */
+int bv2_set_tap(bv2_handle* h, const char* name, float* dev_dst, int64_t capacity_floats);
+
+/* Per-kernel-family timing with HIP events recorded on the caller's stream (bench.py's roofline leg). */
+typedef struct bv2_profile_row {
+  char name[64];          /* kernel family, e.g. "conv1d_mfma<128x128>" */
+  int64_t launches;
+  double total_ms;        /* sum of event-timed durations */
+  double flops;           /* algorithmic FLOPs (2*MAC) over those launches */
+  double bytes;           /* algorithmic bytes (inputs read once + outputs written once + weights) */
+} bv2_profile_row;
+int bv2_profile_enable(bv2_handle* h, int on);          /* 0 off, 1 every MFMA kernel launch, 2 Generator launches only */
+int bv2_profile_reset(bv2_handle* h);
+/* Synchronises the recorded events and aggregates them; returns the number of rows written (<= max_rows). */
+int bv2_profile_report(bv2_handle* h, bv2_profile_row* rows, int max_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BV2_H */

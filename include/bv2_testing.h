@@ -1,0 +1,40 @@
+/*
+ * bv2_testing.h — kernel-level entry points of libbv2.so used ONLY by tests/ (unit parity of single kernels against
+ * torch fp32 references).  Not part of the drop-in boundary; synchronous where noted.
+ */
+#ifndef BV2_TESTING_H
+#define BV2_TESTING_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* floats of device scratch bv2_test_conv1d needs for the packed weight + bias */
+int64_t bv2_test_conv_pack_floats(int cin, int cout, int k);
+
+/* One conv1d problem through the MFMA implicit-GEMM kernel with a forced tile variant (0 = auto, 1..5 see
+ * bv2_kernels.h TILE_*).  w_host [cout][cin][k] / bias_host [cout] are HOST pointers (packed + uploaded
+ * synchronously into wpack_dev); every other pointer is DEVICE.  x [B][cin][L], out/res [B][cout][L*out_tstride],
+ * masks [B][L].  pad_left < 0 means "same" padding ((k-1)/2*dil). */
+int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const float* bias_host, float* out, float* wpack_dev,
+                    int B, int cin, int cout, int k, int dil, int pad_left, int L, int tile, float lrelu_slope, int relu,
+                    const float* res, int res_mode, const float* in_mask, const float* out_mask, int mask_pre,
+                    int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale);
+
+/* windowed relative-position attention; qkv [B][3*H*D][T], mask [B][T], erk/erv [2W+1][D], out [B][H*D][T] (all DEVICE) */
+int bv2_test_attention(void* stream, const float* qkv, const float* mask, const float* erk, const float* erv, float* out,
+                       int B, int H, int D, int T, int W);
+
+/* channel LayerNorm family (see bv2_kernels.h LnArgs); all DEVICE pointers, nullable where optional */
+int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode, const float* dww, const float* dwb, int dil,
+                       const float* in_mask, const float* gamma, const float* beta, int post_gelu, const float* res,
+                       const float* vec, const float* mask, float* out, int B, int C, int T);
+
+/* inverse RQ spline on channel `dst` of z [B][2][T] with params [B][prow][T] (DEVICE) */
+int bv2_test_spline(void* stream, float* z, int src, int dst, const float* params, int prow, const float* mask,
+                    float sqrt_fc, float tail, int B, int T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

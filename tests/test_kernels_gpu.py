@@ -1,0 +1,188 @@
+"""GPU: single HIP kernels (through the test-only C entry points of include/bv2_testing.h) against plain PyTorch fp32
+references of the same op, computed on the CPU in fp64 where it matters.  Tolerances are fp32 round-off
+(sums of up to a few thousand products): 2e-5 relative to the output scale."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from bert_vits2_amd import lib as L
+    lib = L.load()
+    f32p = C.c_void_p
+    lib.bv2_test_conv_pack_floats.restype = C.c_int64
+    lib.bv2_test_conv_pack_floats.argtypes = [C.c_int] * 3
+    lib.bv2_test_conv1d.restype = C.c_int
+    lib.bv2_test_conv1d.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float])
+    lib.bv2_test_attention.restype = C.c_int
+    lib.bv2_test_attention.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5
+    lib.bv2_test_layernorm.restype = C.c_int
+    lib.bv2_test_layernorm.argtypes = ([C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3 +
+                                       [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3)
+    lib.bv2_test_spline.restype = C.c_int
+    lib.bv2_test_spline.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
+                                    C.c_float, C.c_int, C.c_int]
+    return lib
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def rel_err(a, b):
+    return ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+CONV_CASES = [
+    # B, cin, cout, k, dil, L, tile
+    (1, 32, 32, 3, 1, 200, 4), (1, 32, 32, 3, 1, 200, 5), (2, 64, 64, 7, 3, 300, 2), (2, 64, 64, 7, 3, 300, 3),
+    (1, 128, 128, 11, 5, 517, 1), (1, 128, 128, 11, 5, 517, 2), (1, 256, 256, 3, 1, 129, 1), (2, 16, 16, 11, 5, 700, 4),
+    (2, 16, 16, 3, 3, 700, 5), (1, 192, 768, 5, 1, 77, 0), (1, 768, 192, 5, 1, 77, 0), (3, 192, 576, 1, 1, 50, 0),
+    (2, 1024, 192, 1, 1, 24, 0), (2, 96, 192, 1, 1, 33, 0), (2, 192, 96, 1, 1, 33, 0), (2, 192, 29, 1, 1, 33, 0),
+    (2, 256, 1, 1, 1, 40, 0), (1, 192, 512, 7, 1, 64, 0), (1, 192, 384, 5, 1, 31, 0),
+]
+
+
+@pytest.mark.parametrize("B,cin,cout,k,dil,L,tile", CONV_CASES)
+def test_conv1d_mfma_plain(B, cin, cout, k, dil, L, tile):
+    lib = _lib()
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv1d(x.double(), w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil)
+    xd = x.cuda()
+    out = torch.full((B, cout, L), float("nan"), device="cuda")
+    wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
+    rc = lib.bv2_test_conv1d(None, P(xd), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, tile, 0.0, 0, None, 0,
+                             None, None, 0, 0, None, 1, None, None, 1.0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_conv1d_mfma_fused_epilogues(tile):
+    """lrelu pre-activation on a 3-source mean, per-batch bias, ReLU, pre-mask, residual add/rsub, post-mask."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(tile)
+    B, cin, cout, k, dil, L = 2, 64, 128, 5, 2, 333
+    xs = [torch.randn(B, cin, L, generator=g) for _ in range(3)]
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias, bias2 = torch.randn(cout, generator=g), torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, L, generator=g)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, L - 57])[:, None]).float()
+    xin = F.leaky_relu((xs[0] + xs[1] + xs[2]).double() * (1.0 / 3.0), 0.1) * mask[:, None].double()
+    y = F.conv1d(xin, w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil) + bias2[:, :, None].double()
+    y = torch.relu(y) * mask[:, None].double()
+    for res_mode, ref in ((1, (y + res.double()) * mask[:, None].double()), (2, (res.double() - y) * mask[:, None].double())):
+        out = torch.full((B, cout, L), float("nan"), device="cuda")
+        wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
+        xd = [t.cuda() for t in xs]
+        rd, md, b2 = res.cuda(), mask.cuda(), bias2.cuda()
+        rc = lib.bv2_test_conv1d(None, P(xd[0]), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, tile, 0.1, 1,
+                                 P(rd), res_mode, P(md), P(md), 1, 1, P(b2), 3, P(xd[1]), P(xd[2]), 1.0 / 3.0)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert rel_err(out, ref) < 2e-5
+
+
+def _ref_attention(qkv, mask, erk, erv, H, W):
+    B, C3, T = qkv.shape
+    HD = C3 // 3
+    D = HD // H
+    q, k, v = [t.view(B, H, D, T).transpose(2, 3).double() for t in qkv.split(HD, 1)]
+    qs = q / math.sqrt(D)
+    s = qs @ k.transpose(-1, -2)
+    idx = torch.arange(T)
+    rel = idx[None, :] - idx[:, None]
+    band = rel.abs() <= W
+    ql = qs @ erk.double().t()
+    s = s + torch.where(band, ql.gather(-1, (rel + W).clamp(0, 2 * W).expand(B, H, T, T)), torch.zeros((), dtype=torch.float64))
+    pair = (mask[:, None, :, None] * mask[:, None, None, :]) != 0
+    s = torch.where(pair, s, torch.full((), -1e4, dtype=torch.float64))
+    p = torch.softmax(s, -1)
+    o = p @ v
+    relw = torch.zeros(B, H, T, 2 * W + 1, dtype=torch.float64)
+    for r in range(-W, W + 1):
+        lo, hi = max(0, -r), min(T, T - r)
+        if hi > lo:
+            i = torch.arange(lo, hi)
+            relw[:, :, lo:hi, r + W] = p[:, :, i, i + r]
+    o = o + relw @ erv.double()
+    return o.transpose(2, 3).reshape(B, HD, T)
+
+
+@pytest.mark.parametrize("B,T,lens", [(1, 128, [128]), (2, 100, [100, 37]), (1, 3, [3]), (3, 33, [33, 1, 20]), (1, 400, [400])])
+def test_attention_relpos(B, T, lens):
+    lib = _lib()
+    H, D, W = 2, 96, 4
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B, 3 * H * D, T, generator=g)
+    qkv[:, : H * D] *= 3.0                      # sharpen the softmax a little
+    erk, erv = torch.randn(2 * W + 1, D, generator=g) * D ** -0.5, torch.randn(2 * W + 1, D, generator=g) * D ** -0.5
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float()
+    ref = _ref_attention(qkv, mask, erk, erv, H, W)
+    out = torch.full((B, H * D, T), float("nan"), device="cuda")
+    a = [t.cuda() for t in (qkv, mask, erk, erv)]
+    assert lib.bv2_test_attention(None, P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(out), B, H, D, T, W) == 0
+    torch.cuda.synchronize()
+    valid = mask[:, None, :].bool().expand_as(ref)          # padded query rows are masked downstream
+    assert ((out.cpu().double() - ref).abs()[valid].max() / ref.abs().max()).item() < 2e-5
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("C,T,B", [(192, 77, 2), (256, 40, 1), (192, 5, 3)])
+def test_layernorm_family(C, T, B):
+    lib = _lib()
+    g = torch.Generator().manual_seed(C + T)
+    a, add, res = (torch.randn(B, C, T, generator=g) for _ in range(3))
+    gamma, beta, vec = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(B, C, generator=g)
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, max(1, T - 3), 1][:B])[:, None]).float()
+
+    def ln(v):
+        return F.layer_norm(v.double().transpose(1, 2), (C,), gamma.double(), beta.double(), 1e-5).transpose(1, 2)
+
+    dev = lambda t: t.cuda()
+    # mode 0: LN(a+add) + vec, masked
+    ref = (ln(a + add) + vec[:, :, None].double()) * mask[:, None].double()
+    out = torch.empty(B, C, T, device="cuda")
+    t = [dev(x) for x in (a, add, gamma, beta, vec, mask)]
+    assert lib.bv2_test_layernorm(None, P(t[0]), P(t[1]), 0, None, None, 1, None, P(t[2]), P(t[3]), 0, None, P(t[4]), P(t[5]),
+                                  P(out), B, C, T) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 1e-5
+    # mode 1: gelu(LN(depthwise k3 dil conv(a*mask))) ; then res + .
+    for dil in (1, 3, 9):
+        dww, dwb = torch.randn(C, 1, 3, generator=g), torch.randn(C, generator=g)
+        y = F.conv1d((a * mask[:, None]).double(), dww.double(), dwb.double(), padding=dil, dilation=dil, groups=C)
+        ref = res.double() + F.gelu(ln(y))
+        t2 = [dev(x) for x in (dww, dwb, res)]
+        assert lib.bv2_test_layernorm(None, P(t[0]), None, 1, P(t2[0]), P(t2[1]), dil, P(t[5]), P(t[2]), P(t[3]), 1, P(t2[2]),
+                                      None, None, P(out), B, C, T) == 0
+        torch.cuda.synchronize()
+        assert rel_err(out, ref) < 1e-5
+
+
+def test_spline_inverse_kernel():
+    from oracle import bv2_oracle as O
+    lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    B, T, K = 2, 300, 10
+    params = torch.randn(B, 32, T, generator=g) * 3
+    z = torch.randn(B, 2, T, generator=g) * 4           # some beyond the +-5 tails
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, T - 40])[:, None]).float()
+    h = params[:, :29].transpose(1, 2)
+    ref1 = O.rq_spline_inverse(z[:, 1].double(), (h[..., :K] / math.sqrt(192)).double(), (h[..., K:2 * K] / math.sqrt(192)).double(),
+                               h[..., 2 * K:].double()) * mask.double()
+    zd, pd, md = z.cuda(), params.cuda(), mask.cuda()
+    assert lib.bv2_test_spline(None, P(zd), 0, 1, P(pd), 32, P(md), math.sqrt(192), 5.0, B, T) == 0
+    torch.cuda.synchronize()
+    assert (zd[:, 1].cpu().double() - ref1).abs().max().item() < 2e-5
+    assert torch.equal(zd[:, 0].cpu(), z[:, 0] * mask)
