@@ -44,29 +44,56 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(hp, sd, batch, kw, iters):
+def log(msg):
+    sys.stderr.write(f"[bench {time.strftime('%H:%M:%S')}] {msg}\n")
+    sys.stderr.flush()
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (os.cpu_count() reports the
+    host's cores even inside a quota-limited container, and oversubscribed OpenMP teams are catastrophically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(hp, sd, batch, kw, iters, budget_s=45.0):
     """The oracle restatement (same aten CPU kernels and per-call weight_norm fold as the reference's infer) timed on
-    this box's host cores — a reported baseline, kind "port" (the Python reference cannot travel to the GPU box)."""
+    this box's host cores — a reported baseline, kind "port" (the Python reference cannot travel to the GPU box).
+    Bounded: stops after ``iters`` timed runs or ``budget_s`` seconds, whichever comes first."""
     from oracle import bv2_oracle as O
-    nthreads = os.cpu_count() or 1
+    nthreads = min(usable_cores(), 64)
     torch.set_num_threads(nthreads)
     B, T = batch["x"].shape
     nw, nz = synth.synthetic_noise(B, T, 3 * T + 8, hp.inter_channels)
     run = lambda: O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"],
                           batch["bert"], batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, **kw)
-    out = run()
-    run()
+    t_start = time.perf_counter()
+    out = run()                                     # warm-up
+    log(f"cpu baseline warm-up {time.perf_counter() - t_start:.2f}s on {nthreads} threads")
     ts = []
-    for _ in range(iters):
+    while len(ts) < iters and (time.perf_counter() - t_start) < budget_s:
         t0 = time.perf_counter()
         out = run()
         ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
     audio_s = float(out["y_lengths"].sum()) * hp.total_upsample / hp.sampling_rate
-    return dict(value=audio_s / med, unit="audio-seconds/sec", cores=nthreads, kind="port",
-                sample=f"{iters} timed runs (median) of the same workload (B={B}, T={T}, T_y={int(out['y_lengths'].max())}, "
-                       f"{audio_s:.3f} s audio) after 2 warm-ups, torch CPU fp32", ms_per_step=med * 1e3)
+    return dict(value=round(audio_s / med, 3), unit="audio-seconds/sec", cores=nthreads, kind="port",
+                sample=f"{len(ts)} timed runs (median) of the same workload (B={B}, T={T}, T_y={int(out['y_lengths'].max())}, "
+                       f"{audio_s:.3f} s audio) after 1 warm-up, torch CPU fp32", ms_per_step=round(med * 1e3, 2))
 
 
 def main():
@@ -94,7 +121,9 @@ def main():
     if rank == 0:
         sd = synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5)
         model.load_state_dict(sd, strict=False)
+    log(f"rank {rank}/{world}: packing / distributing weights")
     t_bcast = sharding.distribute_weights(model, dev, src=0)
+    log("weights attached")
 
     # ---- this rank's utterances (weak scaling: same per-GPU work, different utterances)
     batch = synth.synthetic_batch([T] * B, first_index=rank * B)
@@ -107,8 +136,11 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         out = call()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first infer() done")
     model.profile(2)                   # HIP events around the Generator's kernel launches only (dominant family)
     torch.cuda.synchronize()
     barrier()
@@ -122,6 +154,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     prof = model.profile_report()
     model.profile(0)
     Ty = y_mask.shape[2]
@@ -166,6 +199,7 @@ def main():
             model.profile(0)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU baseline (oracle port)")
             cpu = cpu_baseline(hp, sd, batch, kw, args.cpu_iters)
         line = dict(
             metric="audio-seconds/sec (44.1 kHz), SynthesizerTrn.infer(), 128-phoneme utterance", value=round(value, 2),

@@ -105,6 +105,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own libamdhip64.so (soname libamdhip64.so.7).  It must be in the process BEFORE libbv2.so is
+    # dlopen'ed so that libbv2's NEEDED libamdhip64.so.7 binds to the SAME HIP runtime that owns torch's device
+    # pointers and streams; loaded the other way round the process ends up with two runtimes and the library cannot
+    # touch torch's memory (hipMemcpy -> invalid value).
+    import torch  # noqa: F401
     if build_if_missing and _build.needs_build():
         _build.build(verbose=False)
     if not os.path.exists(_build.LIB):
