@@ -190,13 +190,17 @@ def main():
                                        alg_GBps=round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)) for r in prof])
         full = None
         if args.full_profile:
-            model.profile(1)
+            model.profile(3)               # one row per launch site and shape (untimed pass; events perturb the run)
             for _ in range(3):
                 call()
             torch.cuda.synchronize()
             full = [dict(name=r["name"], launches=r["launches"] / 3, ms_per_step=round(r["total_ms"] / 3, 4),
+                         us_per_launch=round(r["total_ms"] * 1e3 / r["launches"], 2),
                          tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 3)) for r in model.profile_report()]
             model.profile(0)
+            for r in sorted(full, key=lambda r: -r["ms_per_step"]):
+                log(f"  {r['ms_per_step']:8.4f} ms/step  {r['launches']:5.0f} x {r['us_per_launch']:8.2f} us  "
+                    f"{r['tflops']:7.2f} TF  {r['name']}")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle port)")

@@ -227,7 +227,7 @@ int bv2_profile_enable(bv2_handle* h, int on) {
     }
   }
   h->prof_on = on != 0;
-  h->prof_mode = on == 2 ? 2 : 1;
+  h->prof_mode = (on == 2 || on == 3) ? on : 1;
   return 0;
   BV2_CATCH(h)
 }
@@ -279,17 +279,19 @@ int64_t bv2_test_conv_pack_floats(int cin, int cout, int k) {
 int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const float* bias_host, float* out, float* wpack_dev,
                     int B, int cin, int cout, int k, int dil, int pad_left, int L, int tile, float lrelu_slope, int relu,
                     const float* res, int res_mode, const float* in_mask, const float* out_mask, int mask_pre,
-                    int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale) {
+                    int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale, int ksplit,
+                    int64_t slab_stride) {
   try {
     const int cin_pad = t_round_up(cin, 16), ld = t_round_up(cout, 128), cout_pad = t_round_up(cout, 32);
     std::vector<float> pk((size_t)bv2_test_conv_pack_floats(cin, cout, k), 0.f);
+    if (w_host)                                   // w_host == NULL: wpack_dev already holds the packed weight (timing loops)
     for (int j = 0; j < k; ++j)
       for (int ci = 0; ci < cin; ++ci)
         for (int co = 0; co < cout; ++co)
-          pk[((size_t)j * cin_pad + ci) * ld + co] = w_host[((size_t)co * cin + ci) * k + j];
+          pk[(size_t)conv_w_index(j, ci, co, cin_pad, ld)] = w_host[((size_t)co * cin + ci) * k + j];
     const size_t boff = (size_t)k * cin_pad * ld;
     if (bias_host) for (int co = 0; co < cout; ++co) pk[boff + co] = bias_host[co];
-    if (hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
+    if (w_host && hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
     ConvLaunch cl;
     std::memset(&cl, 0, sizeof(cl));
     ConvProb& p = cl.p[0];
@@ -304,25 +306,25 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
     p.pad_left = pad_left < 0 ? ((k - 1) / 2) * dil : pad_left;
     p.pre_act = lrelu_slope != 0.f ? PRE_LRELU : PRE_NONE; p.slope = lrelu_slope;
     p.act = relu ? ACT_RELU : ACT_NONE; p.mask_pre = mask_pre; p.mask_post = mask_post;
-    cl.nprob = 1; cl.B = B; cl.L = L;
+    cl.nprob = 1; cl.B = B; cl.L = L; cl.ksplit = ksplit < 1 ? 1 : ksplit; cl.slab_stride = slab_stride;
     const char* vn = nullptr;
     return launch_conv1d(static_cast<hipStream_t>(stream), cl, tile, &vn);
   } catch (...) { return -100; }
 }
 
-int bv2_test_attention(void* stream, const float* qkv, const float* mask, const float* erk, const float* erv, float* out,
+int bv2_test_attention(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,
                        int B, int H, int D, int T, int W) {
   AttnArgs a;
-  a.qkv = qkv; a.mask = mask; a.erk = erk; a.erv = erv; a.out = out; a.B = B; a.H = H; a.D = D; a.T = T; a.W = W;
+  a.qkv = qkv; a.ld = ld; a.mask = mask; a.erv = erv; a.out = out; a.B = B; a.H = H; a.D = D; a.T = T; a.W = W;
   return launch_attention(static_cast<hipStream_t>(stream), a);
 }
 
 int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode, const float* dww, const float* dwb, int dil,
                        const float* in_mask, const float* gamma, const float* beta, int post_gelu, const float* res,
-                       const float* vec, const float* mask, float* out, int B, int C, int T) {
+                       const float* vec, const float* mask, float* out, int B, int C, int T, int nslab, int64_t slab_stride) {
   LnArgs l;
   std::memset(&l, 0, sizeof(l));
-  l.a = a; l.add = add; l.mode = mode; l.dww = dww; l.dwb = dwb; l.dil = dil; l.in_mask = in_mask;
+  l.a = a; l.add = add; l.nslab = nslab; l.slab_stride = slab_stride; l.mode = mode; l.dww = dww; l.dwb = dwb; l.dil = dil; l.in_mask = in_mask;
   l.gamma = gamma; l.beta = beta; l.eps = 1e-5f; l.post_gelu = post_gelu; l.res = res; l.vec = vec; l.vec_bstride = C;
   l.mask = mask; l.out = out; l.B = B; l.C = C; l.T = T;
   return launch_layernorm(static_cast<hipStream_t>(stream), l);

@@ -37,7 +37,10 @@ struct Ctx {
   }
 
   // ---- profiling: HIP events on the caller's stream around one kernel family launch
+  const char* cur_tag = "";
+  std::string cur_shape;
   int prof_begin(const char* tag) {
+    cur_tag = tag;
     if (!h->prof_on || h->prof_used >= h->prof_pool.size()) return -1;
     if (h->prof_mode == 2 && std::strncmp(tag, "dec.", 4) != 0) return -1;   // Generator kernels only
     const int i = (int)h->prof_used++;
@@ -47,10 +50,12 @@ struct Ctx {
   void prof_end(int i, const char* name, double flops, double bytes) {
     if (i < 0) return;
     (void)hipEventRecord(h->prof_pool[i].e1, s);
+    std::string key = name;
+    if (h->prof_mode == 3) key = std::string(cur_tag) + "|" + name + cur_shape;   // one row per launch site and shape
     int fam = -1;
     for (size_t k = 0; k < h->prof_names.size(); ++k)
-      if (h->prof_names[k] == name) fam = (int)k;
-    if (fam < 0) { fam = (int)h->prof_names.size(); h->prof_names.push_back(name); }
+      if (h->prof_names[k] == key) fam = (int)k;
+    if (fam < 0) { fam = (int)h->prof_names.size(); h->prof_names.push_back(key); }
     h->prof_pool[i].fam = fam; h->prof_pool[i].flops = flops; h->prof_pool[i].bytes = bytes;
   }
 
@@ -77,18 +82,28 @@ struct Ctx {
     p.slope = 0.1f;
     return p;
   }
-  void conv(ConvLaunch& L, const char* tag) {
-    if (rc) return;
+  // Launch; returns the number of partial slabs written per output (1 unless the split-K kernel was allowed to split K
+  // across workgroups: max_split > 1 means the CONSUMER sums `slab_stride`-spaced slabs).
+  int conv(ConvLaunch& L, const char* tag, int max_split = 1, int64_t slab_stride = 0) {
+    if (rc) return 1;
+    L.ksplit = 1; L.slab_stride = slab_stride;
+    if (max_split > 1 && conv_use_splitk(L)) L.ksplit = conv_pick_ksplit(L, max_split);
     const char* vn = "conv1d_mfma";
     const int pi = prof_begin(tag);
+    if (pi >= 0 && h->prof_mode == 3) {
+      const ConvProb& q = L.p[0];
+      cur_shape = " n" + std::to_string(L.nprob) + " " + std::to_string(q.cin) + ">" + std::to_string(q.cout) + " k" +
+                  std::to_string(q.k) + " L" + std::to_string(L.L) + " B" + std::to_string(L.B) + " s" + std::to_string(L.ksplit);
+    }
     const int r = launch_conv1d(s, L, TILE_AUTO, &vn);
     prof_end(pi, vn, conv_flops(L), conv_bytes(L));
     if (r) fail(tag, r);
+    return L.ksplit;
   }
-  void conv1(const ConvProb& p, int B, int L, const char* tag) {
+  int conv1(const ConvProb& p, int B, int L, const char* tag, int max_split = 1, int64_t slab_stride = 0) {
     ConvLaunch cl;
     cl.p[0] = p; cl.nprob = 1; cl.B = B; cl.L = L;
-    conv(cl, tag);
+    return conv(cl, tag, max_split, slab_stride);
   }
   void ln(const LnArgs& a, const char* tag) {
     if (rc) return;
@@ -106,18 +121,23 @@ struct Ctx {
 //   f   = relu(conv_k(x*mask))            (MFMA, input mask + ReLU fused)
 //   s   = conv_k(f*mask)*mask + x         (MFMA, masks + residual fused)
 //   x   = LN2(s) [ + spk, *mask when the NEXT layer is the conditioning layer; *mask after the last layer ]
-struct EncBufs { float *x, *s, *att, *qkv, *f1; };
+struct EncBufs { float *x, *s, *att, *qkv, *f1; int64_t slab; };   // s holds kSlabs slabs of `slab` floats
+
+constexpr int kSlabs = BV2_MAX_KSPLIT;
+inline int attn_ld(int T) { return (T + 31) / 32 * 32; }
+inline int qkv_rows(const EncoderW& e) { return 3 * e.hidden + e.heads * (2 * kAttnWindow + 1); }
 
 void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask, const float* spk, int spk_bstride,
                  int B, int T, const char* tapname) {
-  const int H = e.hidden;
+  const int H = e.hidden, ld = attn_ld(T), R = qkv_rows(e);
   // cond_layer_idx == 2 > 0: the speaker add always rides on the previous layer's LN2 epilogue
   for (int i = 0; i < e.n_layers; ++i) {
     const EncLayerW& L = e.layer[i];
     ConvProb p = c.prob(L.qkv, b.x, b.qkv, T);
+    p.out_rstride = ld; p.out_bstride = (int64_t)R * ld;      // rows padded to 32 columns: aligned tile loads
     c.conv1(p, B, T, "enc.qkv");
     AttnArgs a;
-    a.qkv = b.qkv; a.mask = mask; a.erk = c.W(L.erk.off); a.erv = c.W(L.erv.off); a.out = b.att;
+    a.qkv = b.qkv; a.ld = ld; a.mask = mask; a.erv = c.W(L.erv.off); a.out = b.att;
     a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow;
     if (!c.rc) {
       const int pi = c.prof_begin("attention");
@@ -127,18 +147,19 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     }
     p = c.prob(L.o, b.att, b.s, T);
     p.res = b.x; p.res_mode = RES_ADD;
-    c.conv1(p, B, T, "enc.o");
+    int ns = c.conv1(p, B, T, "enc.o", kSlabs, b.slab);
     LnArgs l;
     std::memset(&l, 0, sizeof(l));
-    l.a = b.s; l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T;
+    l.a = b.s; l.nslab = ns; l.slab_stride = b.slab;
+    l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T;
     c.ln(l, "enc.ln1");
     p = c.prob(L.ffn1, b.x, b.f1, T);
     p.in_mask = mask; p.act = ACT_RELU;
     c.conv1(p, B, T, "enc.ffn1");
     p = c.prob(L.ffn2, b.f1, b.s, T);
     p.in_mask = mask; p.out_mask = mask; p.mask_pre = 1; p.res = b.x; p.res_mode = RES_ADD;
-    c.conv1(p, B, T, "enc.ffn2");
-    l.a = b.s; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off);
+    ns = c.conv1(p, B, T, "enc.ffn2", kSlabs, b.slab);
+    l.a = b.s; l.nslab = ns; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off);
     if (i + 1 == kCondLayer && i + 1 < e.n_layers) { l.vec = spk; l.vec_bstride = spk_bstride; l.mask = mask; }
     if (i + 1 == e.n_layers) l.mask = mask;
     c.ln(l, "enc.ln2");
@@ -151,7 +172,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
 
 // modules.DDSConv.forward (reference modules.py:118-130), 3 launches per layer:
 //   y1 = gelu(LN1(dwconv_k3,dil(x*mask)))   y2 = W_1x1 y1 (MFMA)   x = x + gelu(LN2(y2))   [*mask after the last]
-void run_dds(Ctx& c, const DDSW& d, float* x, float* y1, float* y2, const float* mask, int B, int C, int T) {
+void run_dds(Ctx& c, const DDSW& d, float* x, float* y1, float* y2, int64_t slab, const float* mask, int B, int C, int T) {
   for (int i = 0; i < kSdpLayers; ++i) {
     const DDSLayerW& L = d.l[i];
     LnArgs l;
@@ -160,9 +181,9 @@ void run_dds(Ctx& c, const DDSW& d, float* x, float* y1, float* y2, const float*
     l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.post_gelu = 1; l.out = y1; l.B = B; l.C = C; l.T = T;
     c.ln(l, "dds.ln1");
     ConvProb p = c.prob(L.c1x1, y1, y2, T);
-    c.conv1(p, B, T, "dds.1x1");
+    const int ns = c.conv1(p, B, T, "dds.1x1", kSlabs, slab);
     std::memset(&l, 0, sizeof(l));
-    l.a = y2; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off); l.eps = 1e-5f; l.post_gelu = 1; l.res = x; l.out = x;
+    l.a = y2; l.nslab = ns; l.slab_stride = slab; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off); l.eps = 1e-5f; l.post_gelu = 1; l.res = x; l.out = x;
     l.B = B; l.C = C; l.T = T;
     if (i + 1 == kSdpLayers) l.mask = mask;
     c.ln(l, "dds.ln2");
@@ -170,7 +191,11 @@ void run_dds(Ctx& c, const DDSW& d, float* x, float* y1, float* y2, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// slabs a split-K consumer may have to sum: only the small-N regime (conv_use_splitk) ever splits K across workgroups
+inline int n_slabs(int B, int T) { return (int64_t)B * T <= 4096 ? kSlabs : 1; }
+
 struct PlanA {
+  int64_t slab;
   float *gv, *bsum, *dp0, *dp1, *dp2, *logw_dp, *sdp_h, *sdp_x, *y1, *y2, *z, *params, *logw_sdp;
   EncBufs enc;
 };
@@ -179,11 +204,14 @@ PlanA plan_a(Arena& A, const Model& m, int B, int T) {
   const int64_t H = c.hidden_channels, BT = (int64_t)B * T;
   PlanA p;
   p.gv = A.get<float>((int64_t)B * 3 * H);
-  p.bsum = A.get<float>(BT * H);
+  const int ns = n_slabs(B, T);
+  p.slab = BT * H;
+  p.bsum = A.get<float>(3 * ns * BT * H);
   p.enc.x = nullptr;   // encoder state lives in out.x
-  p.enc.s = A.get<float>(BT * H);
+  p.enc.slab = BT * H;
+  p.enc.s = A.get<float>(ns * BT * H);
   p.enc.att = A.get<float>(BT * H);
-  p.enc.qkv = A.get<float>(BT * 3 * H);
+  p.enc.qkv = A.get<float>((int64_t)B * qkv_rows(m.enc) * attn_ld(T));
   p.enc.f1 = A.get<float>(BT * c.filter_channels);
   p.dp0 = A.get<float>(BT * H);
   p.dp1 = A.get<float>(BT * kDpFilter);
@@ -193,7 +221,7 @@ PlanA plan_a(Arena& A, const Model& m, int B, int T) {
   p.sdp_h = A.get<float>(BT * H);
   p.sdp_x = A.get<float>(BT * H);
   p.y1 = A.get<float>(BT * H);
-  p.y2 = A.get<float>(BT * H);
+  p.y2 = A.get<float>(ns * BT * H);
   p.z = A.get<float>(BT * 2);
   p.params = A.get<float>(BT * 32);
   return p;
@@ -230,9 +258,10 @@ PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
   p.h = A.get<float>(BT * H);
   if (c.use_transformer_flow) {
     p.enc.x = p.h;
-    p.enc.s = A.get<float>(BT * H);
+    p.enc.slab = BT * H;
+    p.enc.s = A.get<float>(n_slabs(B, Ty) * BT * H);
     p.enc.att = A.get<float>(BT * H);
-    p.enc.qkv = A.get<float>(BT * 3 * H);
+    p.enc.qkv = A.get<float>((int64_t)B * qkv_rows(m.coupling[0].enc) * attn_ld(Ty));
     p.enc.f1 = A.get<float>(BT * c.filter_channels);
   } else {
     p.xin = A.get<float>(BT * 2 * H);
@@ -288,17 +317,26 @@ int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_
 
   // ---- TextEncoder (reference models.py:377-400)
   const float* berts[3] = {in.bert, in.ja_bert, in.en_bert};
-  for (int i = 0; i < 3; ++i) {
-    ConvProb p = c.prob(m.bert[i], berts[i], P.bsum, T);
-    if (i > 0) { p.res = P.bsum; p.res_mode = RES_ADD; }
-    c.conv1(p, B, T, "enc_p.bert_proj");
+  int bert_slabs;
+  {
+    // the three 1024 -> hidden projections in ONE launch; each writes its own partial slab(s), the embed kernel sums them
+    ConvLaunch cl;
+    cl.nprob = 3; cl.B = B; cl.L = T;
+    cl.ksplit = 1; cl.slab_stride = P.slab;
+    for (int i = 0; i < 3; ++i) cl.p[i] = c.prob(m.bert[i], berts[i], P.bsum, T);
+    const int ks = conv_use_splitk(cl) ? conv_pick_ksplit(cl, kSlabs / 2) : 1;
+    for (int i = 0; i < 3; ++i) cl.p[i].out = P.bsum + (int64_t)i * ks * P.slab;
+    c.conv(cl, "enc_p.bert_proj", ks > 1 ? ks : 1, P.slab);
+    if (cl.ksplit != ks) c.fail("enc_p.bert_proj (split mismatch)", -1);
+    bert_slabs = 3 * ks;
   }
   {
     EmbedArgs e;
     e.x = in.x; e.tone = in.tone; e.lang = in.language;
     e.emb = c.W(m.emb.off); e.tone_emb = c.W(m.tone_emb.off); e.lang_emb = c.W(m.lang_emb.off);
     e.n_vocab = cf.n_vocab; e.n_tones = cf.n_tones; e.n_langs = cf.n_languages;
-    e.bsum = P.bsum; e.mask = mask; e.out = out.x; e.scale = (float)std::sqrt((double)H); e.B = B; e.C = H; e.T = T;
+    e.bsum = P.bsum; e.nslab = bert_slabs; e.slab_stride = P.slab;
+    e.mask = mask; e.out = out.x; e.scale = (float)std::sqrt((double)H); e.B = B; e.C = H; e.T = T;
     c.chk(launch_embed(s, e), "embed");
   }
   c.tap("enc.x0", out.x, (int64_t)B * H * T);
@@ -338,7 +376,7 @@ int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_
     ConvProb p = c.prob(m.sdp_pre, out.x, P.sdp_h, T);
     p.bias2 = sdp_c; p.bias2_bstride = 3 * H;                 // x = pre(x) + cond(g)
     c.conv1(p, B, T, "sdp.pre");
-    run_dds(c, m.sdp_convs, P.sdp_h, P.y1, P.y2, mask, B, H, T);
+    run_dds(c, m.sdp_convs, P.sdp_h, P.y1, P.y2, P.slab, mask, B, H, T);
     p = c.prob(m.sdp_proj, P.sdp_h, P.sdp_x, T);
     p.out_mask = mask; p.mask_post = 1;
     c.conv1(p, B, T, "sdp.proj");
@@ -349,7 +387,7 @@ int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_
       const int src = (i % 2 == 0) ? 1 : 0, dst = 1 - src;
       const ConvFlowW& F = m.cf[i];
       c.chk(launch_convflow_pre(s, P.z, src, c.W(F.pre_w.off), c.W(F.pre_b.off), P.sdp_x, P.sdp_h, B, H, T), "cf.pre");
-      run_dds(c, F.convs, P.sdp_h, P.y1, P.y2, mask, B, H, T);
+      run_dds(c, F.convs, P.sdp_h, P.y1, P.y2, P.slab, mask, B, H, T);
       p = c.prob(F.proj, P.sdp_h, P.params, T);
       p.out_bstride = (int64_t)32 * T;
       p.out_mask = mask; p.mask_post = 1;

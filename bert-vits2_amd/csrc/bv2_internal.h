@@ -36,7 +36,7 @@ struct GemvW { int cout = 0, cin = 0; int64_t w_off = -1, b_off = -1; };
 
 struct EncLayerW {
   ConvW qkv, o, ffn1, ffn2;
-  VecW erk, erv, g1, b1, g2, b2;
+  VecW erv, g1, b1, g2, b2;
 };
 struct EncoderW {
   int n_layers = 0, ksize = 1, hidden = 0, filter = 0, heads = 0;

@@ -12,9 +12,10 @@ namespace bv2 {
 //   out[b][co][t*out_tstride + out_toff] = epilogue( bias[co] + bias2[b][co]
 //        + sum_{ci<cin, j<k} Wp[j][ci][co] * pre( in_scale * sum_s x_s[b][ci][t - pad_left + j*dil] * in_mask[b][.] ) )
 //
-// Wp is the PACKED weight: [k][cin_pad][w_ld] fp32, co fastest (cin_pad % 16 == 0; w_ld % 128 == 0 is the row stride, so
-// any tile height may read a full row; rows >= cout are zero; cout_pad = cout rounded up to 32 bounds the tiling),
-// which makes both MFMA operands natural, conflict-free LDS row reads.  One launch can carry several problems
+// Wp is the PACKED weight in MFMA "fragment order": [k][cin_pad/8][2][w_ld][4] fp32 — element (tap j, ci, co) lives at
+// ((((j*(cin_pad/8) + ci/8)*2 + (ci&1))*w_ld + co)*4 + (ci%8)/2, so the A operands of four consecutive K steps are one
+// aligned float4 per lane (cin_pad % 16 == 0; w_ld % 128 == 0, so any tile height may read a full row; rows >= cout are
+// zero; cout_pad = cout rounded up to 32 bounds the tiling).  One launch can carry several problems
 // (blockIdx.z) that share B and L: the three ResBlock branches of a Generator stage, the u polyphase branches of a
 // ConvTranspose1d, or the m_p / logs_p halves of enc_p.proj.
 enum { PRE_NONE = 0, PRE_LRELU = 1 };
@@ -50,16 +51,27 @@ struct ConvProb {
 };
 
 #define BV2_MAX_PROBS 8
+#define BV2_MAX_KSPLIT 8
 struct ConvLaunch {
   ConvProb p[BV2_MAX_PROBS];
   int nprob;
   int B;
   int L;                    // output positions per problem (index t)
+  int ksplit;               // split-K kernel only: K split across workgroups into `ksplit` partial slabs (1 = none)
+  int64_t slab_stride;      // floats between the partial slabs of one output (slab z is written at out + z*slab_stride)
 };
 
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
-enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5 };
+enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6 };
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
+// true when TILE_AUTO will pick the split-K kernel for this launch (small-N regime); only then may ksplit exceed 1
+bool conv_use_splitk(const ConvLaunch& L);
+// K-split factor (power of two <= max_split) that fills the chip for a split-K launch whose consumer sums the slabs
+int conv_pick_ksplit(const ConvLaunch& L, int max_split);
+// float index of weight element (tap j, input channel ci, output channel co) in the packed layout
+inline int64_t conv_w_index(int j, int ci, int co, int cin_pad, int w_ld) {
+  return ((((int64_t)j * (cin_pad / 8) + ci / 8) * 2 + (ci & 1)) * w_ld + co) * 4 + (ci % 8) / 2;
+}
 double conv_flops(const ConvLaunch& L);
 double conv_bytes(const ConvLaunch& L);
 
@@ -75,12 +87,13 @@ int launch_conv_post(hipStream_t stream, const ConvPostArgs& a);
 
 // --------------------------------------------------------------------------------------------------------------
 // channel LayerNorm family (kernels/layernorm.hip)
-//   v[c][t]   = a[b][c][t] (+ add[b][c][t])                         mode 0
+//   v[c][t]   = sum_{s<nslab} a[s*slab_stride + b][c][t] (+ add[b][c][t])   mode 0 (nslab partial slabs of a split-K conv)
 //             = dwb[c] + sum_j dww[c][j] * a[b][c][t+(j-1)*dil]*in_mask[b][.]   mode 1 (depthwise k=3, DDSConv)
 //   y         = (v - mean_c) * rsqrt(var_c + eps) * gamma[c] + beta[c];  y = gelu(y) if post_gelu
 //   out       = ((res ? res : 0) + y + (vec ? vec[b][c] : 0)) * (mask ? mask[b][t] : 1)
 struct LnArgs {
   const float* a; const float* add;
+  int nslab; int64_t slab_stride;     // nslab <= 1: a is a plain tensor
   int mode; const float* dww; const float* dwb; int dil; const float* in_mask;
   const float* gamma; const float* beta; float eps;
   int post_gelu;
@@ -93,9 +106,12 @@ int launch_layernorm(hipStream_t stream, const LnArgs& a);
 // --------------------------------------------------------------------------------------------------------------
 // windowed relative-position multi-head attention (kernels/attention.hip), reference attentions.py:273-322
 struct AttnArgs {
-  const float* qkv;         // [B][3*H*D][T]: q rows [0,HD), k rows [HD,2HD), v rows [2HD,3HD); head h = rows h*D..h*D+D-1
+  // [B][3*H*D + H*(2W+1)][ld]: q rows [0,HD) ALREADY divided by sqrt(D), k rows [HD,2HD), v rows [2HD,3HD) (head h = rows
+  // h*D..h*D+D-1), then per head the 2W+1 relative-key logit rows qe[h][r][i] = (q_i/sqrt(D))·Ek[r] — all produced by
+  // ONE fused 1x1 projection (the scale and Ek are folded into its weights at pack time).  ld % 32 == 0, ld >= T.
+  const float* qkv;
+  int ld;
   const float* mask;        // [B][T]
-  const float* erk;         // [2W+1][D]
   const float* erv;         // [2W+1][D]
   float* out;               // [B][H*D][T]
   int B, H, D, T, W;
@@ -117,7 +133,8 @@ struct EmbedArgs {
   const int64_t* x; const int64_t* tone; const int64_t* lang;
   const float* emb; const float* tone_emb; const float* lang_emb;
   int n_vocab, n_tones, n_langs;
-  const float* bsum; const float* mask; float* out; float scale; int B, C, T;
+  const float* bsum; int nslab; int64_t slab_stride;   // bsum = sum of nslab partial slabs of the BERT projections
+  const float* mask; float* out; float scale; int B, C, T;
 };
 int launch_embed(hipStream_t stream, const EmbedArgs& a);
 

@@ -5,8 +5,10 @@
 //     reference models.py:513, modules.py:160-182, 226-292) — also accepts already folded `.weight` checkpoints
 //     (Generator.remove_weight_norm, models.py:559-564);
 // and what only a from-scratch layout can do:
-//   * conv weights re-laid as [tap][C_in pad16][C_out ld128] (C_out fastest) = the MFMA A-operand order;
-//   * conv_q/k/v fused into one 3*hidden-row projection;
+//   * conv weights re-laid as [tap][C_in/8][C_in&1][C_out ld128][(C_in%8)/2] = the MFMA A-operand fragment order: the
+//     operands of four consecutive K steps are one aligned float4 per lane (bv2_kernels.h conv_w_index);
+//   * conv_q/k/v fused into one projection that also emits, per head, the 2W+1 relative-key logits
+//     q_i·Ek[r]/sqrt(d) (they are linear in the layer input: rows Ek·Wq/sqrt(d)); 1/sqrt(d) folded into the q rows;
 //   * ConvTranspose1d split into its u polyphase stride-1 convolutions (k/u taps each);
 //   * the flows' channel Flip (modules.py:374-381) folded into input/output channel permutations of pre/post,
 //     so no flip ever touches HBM;
@@ -100,10 +102,9 @@ struct Packer {
     c.b_off = bias ? alloc(c.cout_pad) : -1;
     if (fill() && ok) {
       for (int j = 0; j < k; ++j)
-        for (int ci = 0; ci < cin; ++ci) {
-          float* row = blob + c.w_off + ((int64_t)j * c.cin_pad + ci) * c.w_ld;
-          for (int co = 0; co < cout; ++co) row[co] = src(co, ci, j);
-        }
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co)
+            blob[c.w_off + conv_w_index(j, ci, co, c.cin_pad, c.w_ld)] = src(co, ci, j);
       if (bias)
         for (int co = 0; co < cout; ++co) blob[c.b_off + co] = bsrc(co);
     }
@@ -158,19 +159,34 @@ EncoderW pack_encoder(Packer& P, const std::string& p, int hidden, int filter, i
   for (int i = 0; i < layers; ++i) {
     EncLayerW& L = e.layer[i];
     const std::string a = p + ".attn_layers." + std::to_string(i);
-    // fused q/k/v projection (reference attentions.py:264-266 runs three 1x1 convs)
+    // fused q/k/v projection (reference attentions.py:264-266 runs three 1x1 convs) + relative-key logit rows
     const HostTensor *wq = P.get(a + ".conv_q.weight", {hidden, hidden, 1}), *wk = P.get(a + ".conv_k.weight", {hidden, hidden, 1}),
                      *wv = P.get(a + ".conv_v.weight", {hidden, hidden, 1});
     const HostTensor *bq = P.get(a + ".conv_q.bias", {hidden}), *bk = P.get(a + ".conv_k.bias", {hidden}),
                      *bv = P.get(a + ".conv_v.bias", {hidden});
-    const bool ok = wq && wk && wv && bq && bk && bv;
-    const HostTensor* ws[3] = {wq, wk, wv};
-    const HostTensor* bs[3] = {bq, bk, bv};
-    L.qkv = P.conv(3 * hidden, hidden, 1, true,
-                   [&](int co, int ci, int) { return ws[co / hidden]->data[(int64_t)(co % hidden) * hidden + ci]; },
-                   [&](int co) { return bs[co / hidden]->data[co % hidden]; }, ok);
+    const HostTensor* ek = P.get(a + ".emb_rel_k", {1, nr, dk});
+    const bool ok = wq && wk && wv && bq && bk && bv && ek;
+    const double isq = 1.0 / std::sqrt((double)dk);        // query / sqrt(k_channels), attentions.py:280
+    auto wsrc = [&](int co, int ci, int) -> float {
+      if (co < hidden) return (float)(wq->data[(int64_t)co * hidden + ci] * isq);
+      if (co < 2 * hidden) return wk->data[(int64_t)(co - hidden) * hidden + ci];
+      if (co < 3 * hidden) return wv->data[(int64_t)(co - 2 * hidden) * hidden + ci];
+      const int hh = (co - 3 * hidden) / nr, r = (co - 3 * hidden) % nr;
+      double acc = 0;
+      for (int c = 0; c < dk; ++c) acc += (double)ek->data[r * dk + c] * wq->data[(int64_t)(hh * dk + c) * hidden + ci];
+      return (float)(acc * isq);
+    };
+    auto bsrc = [&](int co) -> float {
+      if (co < hidden) return (float)(bq->data[co] * isq);
+      if (co < 2 * hidden) return bk->data[co - hidden];
+      if (co < 3 * hidden) return bv->data[co - 2 * hidden];
+      const int hh = (co - 3 * hidden) / nr, r = (co - 3 * hidden) % nr;
+      double acc = 0;
+      for (int c = 0; c < dk; ++c) acc += (double)ek->data[r * dk + c] * bq->data[hh * dk + c];
+      return (float)(acc * isq);
+    };
+    L.qkv = P.conv(3 * hidden + heads * nr, hidden, 1, true, wsrc, bsrc, ok);
     L.o = P.conv1d(a + ".conv_o", hidden, hidden, 1);
-    L.erk = P.vec(a + ".emb_rel_k", {1, nr, dk});
     L.erv = P.vec(a + ".emb_rel_v", {1, nr, dk});
     L.g1 = P.vec(p + ".norm_layers_1." + std::to_string(i) + ".gamma", {hidden});
     L.b1 = P.vec(p + ".norm_layers_1." + std::to_string(i) + ".beta", {hidden});

@@ -2,11 +2,22 @@
 // implicit GEMM on the gfx950 fp32 matrix core (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains at the 157 TF vector rate).
 //
 //   GEMM view:  M = C_out (rows, from the packed weight),  N = time (columns, contiguous in HBM),  K = (tap j, C_in).
-//   A[m][kk] = Wp[j][ci][co]  -> LDS tile Ws[CK][BM]  (co fastest: lane l reads Ws[kk = l>>5][m = l&31], conflict free)
-//   B[kk][n] = act(x)[ci][t0 + n - pad_left + j*dil] -> LDS tile Xs[CK][BN + (k-1)*dil] staged ONCE per C_in chunk and
-//              re-used by all k taps (the pre-activation / input mask / 3-way mean is applied while staging, once per
-//              element instead of once per use).  Lane l reads Xs[kk = l>>5][n = l&31 (+ tap shift)], conflict free.
-//   D: lane holds column n = l&31, rows (r&3)+8(r>>2)+4(l>>5): each register stores as two 128-byte row segments.
+//
+// Packed weight ("fragment order", written once by bv2_model.cpp):  Wp[tap j][group g = ci/8][lh = ci&1][co (ld w_ld)][q = (ci%8)/2]
+//   -> the four floats a lane needs as MFMA A operand (A[m = l&31][kk = l>>5]) for four consecutive K steps of one
+//      8-channel group are ONE aligned float4, both in HBM and in LDS (conflict-free ds_read_b128, 1 read per 4 MFMAs).
+//
+// Two kernels:
+//  * conv1d_mfma_kernel  — LDS-tiled, for problems with enough columns to fill the chip (the Generator, and every conv at
+//    large batch).  Per (C_in chunk, tap) step: weights global -> registers -> LDS (double buffered, loads in flight under
+//    the MFMAs); the activation tile Xs[CK][BN + (k-1)*dil] is prefetched into registers one chunk ahead, the
+//    pre-activation / 3-way branch mean / input mask are applied once per element while it is written to the other LDS
+//    buffer, and it is re-used by all k taps.  ONE barrier per step.
+//  * conv1d_splitk_kernel — for the small-N problems of the text encoder / flow / duration predictors at small batch
+//    (N = T or T_y columns, a few hundred): 32x32 output tile per workgroup, the 4 waves split K (channel groups) and
+//    reduce through LDS; optionally K is also split ACROSS workgroups into `ksplit` partial slabs that the consumer
+//    (LayerNorm / embed kernel) sums.  Operands go global -> registers directly (4-deep prefetch ring), no barriers in
+//    the main loop.  Workgroups that share a weight slice are placed on the same XCD (block b runs on XCD b % 8).
 //
 // Replaces (reference): every Conv1d of modules.ResBlock1 (modules.py:296-309), Generator.conv_pre / ups
 // (models.py:539-545), attentions.FFN (attentions.py:438-446), q/k/v/o and all 1x1 projections, DurationPredictor
@@ -17,13 +28,28 @@
 namespace bv2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct defeats SROA here
 
-template <int WM, int WN, int MI, int NI, int CK>
+// load base[byte_off]: wave-uniform base (SGPR pair) + 32-bit per-lane BYTE offset -> the `global_load v, v_off, s[base]`
+// addressing form (one VGPR per address instead of a 64-bit pair)
+__device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// float4 index of the A-operand quad of (tap j, channel group g, half lh, row co)
+__device__ __forceinline__ int64_t wq_index(int j, int g, int lh, int co, int groups, int w_ld) {
+  return ((int64_t)((j * groups + g) * 2 + lh)) * w_ld + co;
+}
+
+template <int WM, int WN, int MI, int NI, int CK, int XS>
 __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles) {
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
+  constexpr int XP = XS * 64;                     // X tile row pitch (floats)
+  constexpr int RPW = CK / 4;                     // X rows staged per wave
+  constexpr int GR = CK / 8;                      // channel groups per chunk
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  constexpr int W4 = CK * BM / 4;                 // float4 per weight tile
+  constexpr int W4 = GR * 2 * BM;                 // float4 per weight tile
   constexpr int NW4 = (W4 + 255) / 256;           // float4 per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -37,13 +63,23 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   const int t0 = blockIdx.x * BN;
   if (m0 >= P.cout_pad) return;                   // problems in one launch may have different C_out
 
-  const int k = P.k, dil = P.dil;
+  // problem fields used in the main loop, hoisted into registers (P lives in the kernarg segment; re-reading it costs
+  // an s_load + lgkmcnt wait at every use)
+  const int k = P.k, dil = P.dil, cin = P.cin, Lin = P.Lin, w_ld = P.w_ld, nsrc = P.nsrc;
+  const float in_scale = P.in_scale, slope = P.slope;
+  const bool lrelu = P.pre_act == PRE_LRELU;
+  // per-batch base pointers (wave-uniform -> SGPR pairs); element offsets inside one batch item fit 32 bits
+  const float* const x0p = P.x[0] + (int64_t)b * P.x_bstride;
+  const float* const x1p = P.x[1] ? P.x[1] + (int64_t)b * P.x_bstride : nullptr;
+  const float* const x2p = P.x[2] ? P.x[2] + (int64_t)b * P.x_bstride : nullptr;
+  const float* const maskp = P.in_mask ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
+  const int x_rstride = P.x_rstride;
   const int XW = BN + (k - 1) * dil;
-  float* Ws = smem;                               // [2][CK][BM]
-  float* Xs = smem + 2 * CK * BM;                 // [CK][XW]
-
   const int nchunks = P.cin_pad / CK;
+  const int groups = P.cin_pad / 8;
   const int nsteps = nchunks * k;
+  f32x4* Ws = reinterpret_cast<f32x4*>(smem);     // [2][GR][2][BM] float4
+  float* Xs = smem + 2 * W4 * 4;                  // [nchunks > 1 ? 2 : 1][CK][XP]
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -53,86 +89,159 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  float4 wreg[NW4];
+  f32x4 wreg[NW4];
+  float xr[RPW][XS];
+  float xm[XS];
+  const f32x4* wg = reinterpret_cast<const f32x4*>(P.w) + m0;
 
-  auto load_w = [&](int step) {
-    const int c = step / k, j = step - c * k;
-    const float* src = P.w + ((int64_t)(j * P.cin_pad + c * CK)) * P.w_ld + m0;
+  auto issue_w = [&](int c, int j) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NW4; ++q) {
       const int idx = tid + q * 256;
-      if (idx < W4) {
-        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-        wreg[q] = *reinterpret_cast<const float4*>(src + (int64_t)row * P.w_ld + c4 * 4);
+      if (W4 % 256 == 0 || idx < W4) {
+        const int run = idx / BM, m = idx - run * BM;             // run = gl*2 + lh
+        wreg[q] = wg[((int64_t)((j * groups + c * GR) * 2 + run)) * w_ld + m];
       }
     }
   };
-  auto store_w = [&](int buf) {
-    float* dst = Ws + buf * CK * BM;
+  auto store_w = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NW4; ++q) {
       const int idx = tid + q * 256;
-      if (idx < W4) *reinterpret_cast<float4*>(dst + idx * 4) = wreg[q];
+      if (W4 % 256 == 0 || idx < W4) Ws[buf * W4 + idx] = wreg[q];
     }
   };
-  auto stage_x = [&](int c) {
-    const int tbase = t0 - P.pad_left;
-    for (int ci = wid; ci < CK; ci += 4) {
-      const int cg = c * CK + ci;
-      const bool cok = cg < P.cin;
-      const int64_t roff = (int64_t)b * P.x_bstride + (int64_t)cg * P.x_rstride;
-      for (int i = lane; i < XW; i += 64) {
-        const int t = tbase + i;
-        float v = 0.f;
-        if (cok && t >= 0 && t < P.Lin) {
-          v = P.x[0][roff + t];
-          if (P.nsrc > 1) v += P.x[1][roff + t];
-          if (P.nsrc > 2) v += P.x[2][roff + t];
-          v *= P.in_scale;
-          if (P.pre_act == PRE_LRELU) v = v > 0.f ? v : v * P.slope;
-          if (P.in_mask) v *= P.in_mask[(int64_t)b * P.in_mask_bstride + t];
-        }
-        Xs[ci * XW + i] = v;
+  // X prefetch: branch-free, unconditional loads from CLAMPED addresses (so nothing waits on a load before the MFMAs);
+  // zero padding / the channel tail / the input mask are applied when the registers are written to LDS.
+  const int tbase = t0 - P.pad_left;
+  unsigned tc[XS];
+  float colsc[XS];                                // in_scale for real columns, 0 for padding / beyond the tile
+#pragma unroll
+  for (int s = 0; s < XS; ++s) {
+    const int t = tbase + lane + 64 * s;
+    const bool tok = (lane + 64 * s < XW) && t >= 0 && t < Lin;
+    colsc[s] = tok ? in_scale : 0.f;
+    tc[s] = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));   // byte offset
+  }
+  auto issue_x = [&](int c) __attribute__((always_inline)) {
+    unsigned roff[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      int cg = c * CK + wid * RPW + r;
+      cg = cg < cin ? cg : cin - 1;
+      roff[r] = 4u * (unsigned)cg * (unsigned)x_rstride;
+    }
+    if (maskp) {
+#pragma unroll
+      for (int s = 0; s < XS; ++s) xm[s] = ld_off(maskp, tc[s]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < XS; ++s) xm[s] = 1.f;
+    }
+    if (nsrc == 1) {
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) xr[r][s] = ld_off(x0p, roff[r] + tc[s]);
+    } else {
+      // mean of the ResBlock branches (Generator ups inputs): one source per pass, passes fenced so that the register
+      // footprint stays one tile + one pass of temporaries instead of nsrc tiles
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) xr[r][s] = ld_off(x0p, roff[r] + tc[s]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) xr[r][s] += ld_off(x1p, roff[r] + tc[s]);
+      if (nsrc > 2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < XS; ++s)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) xr[r][s] += ld_off(x2p, roff[r] + tc[s]);
+      }
+    }
+  };
+  auto store_x = [&](int c, int buf) __attribute__((always_inline)) {
+    float* dst = Xs + buf * (CK * XP) + (wid * RPW) * XP + lane;
+    const int rows_ok = cin - (c * CK + wid * RPW);                // rows r < rows_ok are real channels
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      const float sc = colsc[s] * xm[s];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        float v = xr[r][s];
+        const float vn = v * slope;
+        v = (lrelu && v < 0.f) ? vn : v;
+        v *= sc;
+        dst[r * XP + 64 * s] = r < rows_ok ? v : 0.f;
       }
     }
   };
 
   // prologue
-  load_w(0);
-  stage_x(0);
+  issue_w(0, 0);
+  issue_x(0);
   store_w(0);
+  store_x(0, 0);
   __syncthreads();
 
+  int c = 0, j = 0;
   for (int step = 0; step < nsteps; ++step) {
     const int buf = step & 1;
-    const int c = step / k, j = step - c * k;
     const bool more = (step + 1) < nsteps;
-    if (more) load_w(step + 1);                   // global loads stay in flight under the MFMAs below
+    const bool last_tap = (j == k - 1);
+    const bool next_chunk = (c + 1) < nchunks;
+    if (more) issue_w(last_tap ? c + 1 : c, last_tap ? 0 : j + 1);   // global loads stay in flight under the MFMAs
+    if (j == 0 && next_chunk) issue_x(c + 1);
 
-    const float* wsb = Ws + buf * CK * BM + lh * BM + wm * (MI * 32) + l31;
-    const float* xsb = Xs + lh * XW + wn * (NI * 32) + l31 + j * dil;
+    const f32x4* wsb = Ws + buf * W4 + lh * BM + wm * (MI * 32) + l31;
+    const float* xsb = Xs + (c & 1) * (CK * XP) + lh * XP + wn * (NI * 32) + l31 + j * dil;
+    // software-pipelined operand reads: the LDS reads of K-step u+1 are issued before the MFMAs of step u
+    f32x4 a4[MI], a4n[MI];
+    float bb[NI], bbn[NI];
 #pragma unroll
-    for (int s = 0; s < CK / 2; ++s) {
-      float a[MI], bb[NI];
+    for (int mi = 0; mi < MI; ++mi) a4[mi] = wsb[mi * 32];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = wsb[(2 * s) * BM + mi * 32];
+    for (int ni = 0; ni < NI; ++ni) bb[ni] = xsb[ni * 32];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bb[ni] = xsb[(2 * s) * XW + ni * 32];
+    for (int g = 0; g < GR; ++g) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
-    }
-
-    if (more) {
-      if (j == k - 1) {                           // next step starts a new C_in chunk: everyone is done reading Xs
-        __syncthreads();
-        stage_x(c + 1);
+          for (int ni = 0; ni < NI; ++ni) bbn[ni] = xsb[(8 * g + 2 * (q + 1)) * XP + ni * 32];
+        } else if (g + 1 < GR) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bbn[ni] = xsb[(8 * (g + 1)) * XP + ni * 32];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a4n[mi] = wsb[(g + 1) * 2 * BM + mi * 32];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const float a = q == 0 ? a4[mi].x : (q == 1 ? a4[mi].y : (q == 2 ? a4[mi].z : a4[mi].w));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[ni], acc[mi][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bb[ni] = bbn[ni];
+        if (q == 3) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a4[mi] = a4n[mi];
+        }
+        // pin the emitted order: next step's LDS reads first, then this step's MFMAs (reads land under the MFMAs)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
       }
-      store_w(buf ^ 1);
     }
+
+    if (more) store_w(buf ^ 1);
+    if (last_tap && next_chunk) store_x(c + 1, (c + 1) & 1);
     __syncthreads();
+    if (last_tap) { j = 0; ++c; } else ++j;
   }
 
   // epilogue
@@ -162,36 +271,229 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   }
 }
 
-struct TileCfg { int id, bm, bn; const char* name; };
+// ---------------------------------------------------------------------------------------------------------------
+// split-K kernel for small-N problems
+constexpr int SK_PD = 4;          // prefetch ring depth (units of 4 MFMAs)
+
+__device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+template <bool MASK>
+__global__ void __launch_bounds__(256) conv1d_splitk_kernel(const ConvLaunch L, const int mtiles, const int ntiles,
+                                                            const int per_xcd, const int total) {
+  __shared__ __attribute__((aligned(16))) float red[4][32][33];
+  // XCD-aware placement: consecutive virtual ids (which share a weight slice) land on the same XCD
+  const int bid = blockIdx.x;
+  const int v = (bid & 7) * per_xcd + (bid >> 3);
+  if (v >= total) return;
+  int rem = v;
+  const int nt = rem % ntiles; rem /= ntiles;
+  const int z = rem % L.ksplit; rem /= L.ksplit;
+  const int mt = rem % mtiles; rem /= mtiles;
+  const int b = rem % L.B; rem /= L.B;
+  const ConvProb& P = L.p[rem];
+  const int m0 = mt * 32, t0 = nt * 32;
+  if (m0 >= P.cout_pad) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // problem fields hoisted into registers (P lives in the kernarg segment)
+  const int k = P.k, dil = P.dil, cin = P.cin, Lin = P.Lin;
+  const int groups = P.cin_pad / 8;
+  const float in_scale = P.in_scale, slope = P.slope;
+  const bool lrelu = P.pre_act == PRE_LRELU;
+  const float* const xp = P.x[0] + (int64_t)b * P.x_bstride;       // wave-uniform bases, 32-bit byte offsets per lane
+  const float* const mp = MASK ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
+  const float* const wp = P.w;
+  const unsigned x_rs4 = 4u * (unsigned)P.x_rstride;
+  const unsigned w_unit = 32u * (unsigned)P.w_ld;                   // bytes between consecutive channel groups
+  const unsigned w_tap = w_unit * (unsigned)groups;                 // bytes between consecutive taps
+  const unsigned w_lane = 16u * (unsigned)(lh * P.w_ld + m0 + l31);
+  // channel groups of this (slice z, wave wid): contiguous range, balanced
+  const int nsl = L.ksplit * 4, sl = z * 4 + wid;
+  const int g0 = (int)(((int64_t)groups * sl) / nsl), g1 = (int)(((int64_t)groups * (sl + 1)) / nsl);
+  const int U = (g1 - g0) * k;                   // units of (group, tap) = 4 MFMAs each
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int tcol = t0 + l31 - P.pad_left;
+  f32x4 ar[SK_PD];
+  float br[SK_PD][4];
+  float mr[SK_PD], vmr[SK_PD];                    // raw mask value / validity*in_scale of the unit's column
+
+  // Loads are UNCONDITIONAL (also past the last unit: clamped to a valid address, result unused) and nothing here reads a
+  // loaded value, so the compiler's vmcnt bookkeeping is exact and the ring really keeps SK_PD units in flight; padding
+  // columns are zeroed by vmr, padded channels meet zero weights.
+  int lg = g0, lj = 0;                            // next unit to LOAD
+  const unsigned row_max = (unsigned)(cin - 1) * x_rs4;            // byte offset of the last real channel row
+  const unsigned x_rs8 = 2u * x_rs4;
+  auto group_off = [&](int g) __attribute__((always_inline)) {
+    const int gc = g < groups ? g : groups - 1;
+    return (unsigned)(8 * gc + lh) * x_rs4;
+  };
+  auto weight_off = [&](int g) __attribute__((always_inline)) {
+    const int gc = g < groups ? g : groups - 1;
+    return w_lane + (unsigned)gc * w_unit;
+  };
+  unsigned goff = group_off(lg), woff = weight_off(lg), joff = 0;   // joff = lj * w_tap
+  auto load_unit = [&](int slot) __attribute__((always_inline)) {
+    ar[slot] = ld_off4(wp, woff + joff);
+    const int t = tcol + lj * dil;
+    const bool tok = t >= 0 && t < Lin;
+    const unsigned tcl = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
+    vmr[slot] = tok ? in_scale : 0.f;
+    mr[slot] = MASK ? ld_off(mp, tcl) : 1.f;
+    unsigned ro = goff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned rc = ro < row_max ? ro : row_max;             // padded channels re-read the last real row (x 0 weight)
+      br[slot][q] = ld_off(xp, rc + tcl);
+      ro += x_rs8;
+    }
+    joff += w_tap;
+    if (++lj == k) { lj = 0; joff = 0; ++lg; goff = group_off(lg); woff = weight_off(lg); }
+  };
+
+#pragma unroll
+  for (int i = 0; i < SK_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  for (int u0 = 0; u0 < U; u0 += SK_PD) {
+#pragma unroll
+    for (int i = 0; i < SK_PD; ++i) {
+      if (u0 + i < U) {
+        float bq[4];
+        const float cs = MASK ? vmr[i] * mr[i] : vmr[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = br[i][q];
+          const float xn = x * slope;
+          x = (lrelu && x < 0.f) ? xn : x;
+          bq[q] = x * cs;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].x, bq[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].y, bq[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].z, bq[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].w, bq[3], acc, 0, 0, 0);
+      }
+      load_unit(i);
+      __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay SK_PD - 1 units
+    }
+  }
+
+  // reduce the 4 waves' partial tiles through LDS
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r];
+  __syncthreads();
+  const int col = t0 + (tid & 31);
+  if (col >= L.L) return;
+  const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
+  float* outp = P.out + (int64_t)z * L.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = (tid >> 5) + 8 * i;
+    const int row = m0 + rl;
+    if (row >= P.cout) continue;
+    float vv = (red[0][rl][tid & 31] + red[1][rl][tid & 31]) + (red[2][rl][tid & 31] + red[3][rl][tid & 31]);
+    if (z == 0) {
+      if (P.bias) vv += P.bias[row];
+      if (P.bias2) vv += P.bias2[(int64_t)b * P.bias2_bstride + row];
+    }
+    if (P.act == ACT_RELU) vv = fmaxf(vv, 0.f);           // host guarantees act == NONE when ksplit > 1
+    if (P.mask_pre) vv *= om;
+    const int64_t oidx = (int64_t)row * P.out_rstride + (int64_t)col * P.out_tstride + P.out_toff;
+    if (z == 0) {
+      if (P.res_mode == RES_ADD) vv += P.res[(int64_t)b * P.res_bstride + oidx];
+      else if (P.res_mode == RES_RSUB) vv = P.res[(int64_t)b * P.res_bstride + oidx] - vv;
+    } else if (P.res_mode == RES_RSUB) {
+      vv = -vv;
+    }
+    if (P.mask_post) vv *= om;
+    outp[(int64_t)b * P.out_bstride + oidx] = vv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct TileCfg { int id, bm, bn, xs; const char* name; };
 static const TileCfg kTiles[] = {
     // order = preference of the auto picker (largest first)
-    {TILE_128x128, 128, 128, "conv1d_mfma<128x128>"}, {TILE_64x128, 64, 128, "conv1d_mfma<64x128>"},
-    {TILE_32x256, 32, 256, "conv1d_mfma<32x256>"},    {TILE_64x64, 64, 64, "conv1d_mfma<64x64>"},
-    {TILE_32x128, 32, 128, "conv1d_mfma<32x128>"},
+    {TILE_128x128, 128, 128, 3, "conv1d_mfma<128x128>"}, {TILE_64x128, 64, 128, 3, "conv1d_mfma<64x128>"},
+    {TILE_32x256, 32, 256, 5, "conv1d_mfma<32x256>"},    {TILE_64x64, 64, 64, 2, "conv1d_mfma<64x64>"},
+    {TILE_32x128, 32, 128, 3, "conv1d_mfma<32x128>"},
 };
 
-template <int WM, int WN, int MI, int NI>
-static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int max_cout_pad, int max_xw_extra) {
+template <int WM, int WN, int MI, int NI, int XS>
+static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int max_cout_pad, int max_extra, int max_chunks) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  if (BN + max_extra > XS * 64) return -2;        // halo does not fit the staged tile
   const int mtiles = (max_cout_pad + BM - 1) / BM;
   dim3 grid((L.L + BN - 1) / BN, mtiles * L.B, L.nprob);
-  const size_t lds = sizeof(float) * (size_t)(2 * ck * BM + ck * (BN + max_xw_extra));
-  if (lds > 160 * 1024) return -2;
+  const int nxbuf = max_chunks > 1 ? 2 : 1;     // a single-chunk problem never re-stages its X tile
   if (ck == 32) {
-    auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 32>;
+    const size_t lds = sizeof(float) * (size_t)(2 * 8 * BM * 4 + 2 * 32 * XS * 64);
+    const size_t lds1 = sizeof(float) * (size_t)(2 * 8 * BM * 4 + nxbuf * 32 * XS * 64);
+    auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 32, XS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles);
   } else {
-    auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 16>;
+    const size_t lds = sizeof(float) * (size_t)(2 * 4 * BM * 4 + 2 * 16 * XS * 64);
+    const size_t lds1 = sizeof(float) * (size_t)(2 * 4 * BM * 4 + nxbuf * 16 * XS * 64);
+    auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 16, XS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+static int launch_splitk(hipStream_t stream, const ConvLaunch& L, int max_cout_pad) {
+  const int mtiles = max_cout_pad / 32, ntiles = (L.L + 31) / 32;
+  const int total = L.nprob * L.B * mtiles * L.ksplit * ntiles;
+  const int per_xcd = (total + 7) / 8;
+  bool any_mask = false, all_mask = true;
+  for (int i = 0; i < L.nprob; ++i) {
+    if (L.p[i].nsrc != 1) return -2;              // multi-source inputs only exist on the LDS-tiled path
+    if (L.p[i].in_mask) any_mask = true; else all_mask = false;
+  }
+  if (any_mask != all_mask) return -2;            // one launch = one mask mode
+  if (any_mask)
+    hipLaunchKernelGGL(conv1d_splitk_kernel<true>, dim3(per_xcd * 8), dim3(256), 0, stream, L, mtiles, ntiles, per_xcd, total);
+  else
+    hipLaunchKernelGGL(conv1d_splitk_kernel<false>, dim3(per_xcd * 8), dim3(256), 0, stream, L, mtiles, ntiles, per_xcd, total);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// K-split factor for the split-K kernel: enough workgroups to cover the chip, at most ~6 channel groups per wave.
+int conv_pick_ksplit(const ConvLaunch& L, int max_split) {
+  if (max_split <= 1) return 1;
+  int groups = 0, mt = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    if (L.p[i].cin_pad / 8 > groups) groups = L.p[i].cin_pad / 8;
+    if (L.p[i].cout_pad / 32 > mt) mt = L.p[i].cout_pad / 32;
+    if (L.p[i].act != ACT_NONE) return 1;
+  }
+  const long base = (long)L.nprob * L.B * mt * ((L.L + 31) / 32);
+  int ks = 1;
+  while (ks < max_split && (groups / (4 * ks) > 6 || base * ks < 192) && groups / (4 * ks * 2) >= 2) ks *= 2;
+  return ks;
+}
+
+bool conv_use_splitk(const ConvLaunch& L) {
+  // small-N regime: even 32x128 tiles would leave most CUs idle
+  int mt = 0;
+  for (int i = 0; i < L.nprob; ++i)
+    if (L.p[i].cout_pad / 32 > mt) mt = L.p[i].cout_pad / 32;
+  for (int i = 0; i < L.nprob; ++i)
+    if (L.p[i].nsrc != 1 || (L.p[i].in_mask != nullptr) != (L.p[0].in_mask != nullptr)) return false;
+  const long cols = (long)L.B * L.L;
+  const long tiles128 = (long)L.nprob * mt * ((L.L + 127) / 128) * L.B;
+  return cols <= 4096 && tiles128 < 512;
+}
+
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name) {
   if (L.nprob < 1 || L.nprob > BV2_MAX_PROBS || L.B < 1 || L.L < 1) return -1;
-  int max_cout_pad = 0, max_extra = 0, ck = 32;
+  int max_cout_pad = 0, max_extra = 0, ck = 32, max_chunks = 1;
   for (int i = 0; i < L.nprob; ++i) {
     const ConvProb& p = L.p[i];
     if (p.cout_pad % 32 || p.cin_pad % 16 || p.k < 1 || p.dil < 1 || p.w_ld % 128 || p.w_ld < p.cout_pad) return -1;
@@ -199,6 +501,15 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     if ((p.k - 1) * p.dil > max_extra) max_extra = (p.k - 1) * p.dil;
     if (p.cin_pad % 32) ck = 16;
   }
+  for (int i = 0; i < L.nprob; ++i)
+    if (L.p[i].cin_pad / ck > max_chunks) max_chunks = L.p[i].cin_pad / ck;
+  if (tile == TILE_AUTO && conv_use_splitk(L)) tile = TILE_SPLITK;
+  if (tile == TILE_SPLITK) {
+    if (L.ksplit < 1 || L.ksplit > BV2_MAX_KSPLIT) return -1;
+    if (variant_name) *variant_name = "conv1d_splitk<32x32>";
+    return launch_splitk(stream, L, max_cout_pad);
+  }
+  if (L.ksplit != 1) return -1;                   // the LDS-tiled kernel never splits K across workgroups
   if (tile == TILE_AUTO) {
     // largest tile that still yields >= ~1 workgroup per CU (256 CUs); small problems fall to the smallest tiles
     const long target = 256;
@@ -206,6 +517,7 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     for (const TileCfg& t : kTiles) {
       if (t.bm > max_cout_pad && t.bm != 32) continue;
       if (max_cout_pad % t.bm && t.bm != 32) continue;
+      if (t.bn + max_extra > t.xs * 64) continue;
       const long blocks = (long)((L.L + t.bn - 1) / t.bn) * ((max_cout_pad + t.bm - 1) / t.bm) * L.B * L.nprob;
       if (blocks >= target) { tile = t.id; break; }
     }
@@ -214,11 +526,11 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
   for (const TileCfg& t : kTiles)
     if (t.id == tile && variant_name) *variant_name = t.name;
   switch (tile) {
-    case TILE_128x128: return launch_variant<2, 2, 2, 2>(stream, L, ck, max_cout_pad, max_extra);
-    case TILE_64x128:  return launch_variant<2, 2, 1, 2>(stream, L, ck, max_cout_pad, max_extra);
-    case TILE_64x64:   return launch_variant<2, 2, 1, 1>(stream, L, ck, max_cout_pad, max_extra);
-    case TILE_32x128:  return launch_variant<1, 4, 1, 1>(stream, L, ck, max_cout_pad, max_extra);
-    case TILE_32x256:  return launch_variant<1, 4, 1, 2>(stream, L, ck, max_cout_pad, max_extra);
+    case TILE_128x128: return launch_variant<2, 2, 2, 2, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    case TILE_64x128:  return launch_variant<2, 2, 1, 2, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    case TILE_64x64:   return launch_variant<2, 2, 1, 1, 2>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    case TILE_32x128:  return launch_variant<1, 4, 1, 1, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    case TILE_32x256:  return launch_variant<1, 4, 1, 2, 5>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
   }
   return -1;
 }

@@ -1,30 +1,32 @@
 // layernorm.hip — LayerNorm over the CHANNEL dim of a [B,C,T] tensor (reference modules.py:26-29 / attentions.py:21-24:
 // transpose -> F.layer_norm(eps=1e-5, biased variance) -> transpose), with the surrounding elementwise work fused:
-//   * residual sum in front (Encoder: norm(x + y), attentions.py:114,118)
+//   * the partial slabs of a split-K convolution summed in front (conv_mfma.hip), plus the residual sum
+//     (Encoder: norm(x + y), attentions.py:114,118)
 //   * depthwise k=3 dilated conv in front (DDSConv.convs_sep, modules.py:122)
 //   * exact-erf GELU, residual add, per-batch speaker vector add, and sequence mask behind
 //     (modules.py:124-129, attentions.py:107-111,119).
-// Layout: a workgroup owns 32 consecutive time steps x all C channels; thread (tx = t, ty = channel group of 8) keeps
-// its C/8 values in registers, so the input is read once (coalesced 128-byte row segments) and the statistics are a
-// two-pass (mean, then centred sum of squares) reduction over registers + one LDS exchange between the 8 groups.
+// Layout: a workgroup owns 16 consecutive time steps x all C channels (small tiles: at batch 1 the tensor is ~300 KB and
+// the kernel is pure latency, so it is cut into as many workgroups as keeps 64-byte row segments); thread (tx = t,
+// ty = channel group of 16) keeps its C/16 values in registers, so the input is read once and the statistics are a
+// two-pass (mean, then centred sum of squares) reduction over registers + one LDS exchange between the 16 groups.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
 
 namespace bv2 {
 
-constexpr int LN_TT = 32;      // time steps per workgroup
-constexpr int LN_G = 8;        // channel groups (threads along C)
-constexpr int LN_MAXCPT = 32;  // channels per thread (C <= 256)
+constexpr int LN_TT = 16;      // time steps per workgroup
+constexpr int LN_G = 16;       // channel groups (threads along C)
+constexpr int LN_MAXCPT = 16;  // channels per thread (C <= 256)
 
 __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
-  __shared__ float red[LN_G][LN_TT];
+  __shared__ float red[LN_G][LN_TT + 1];
   __shared__ float stat[LN_TT];
-  const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 5;
+  const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 4;
   const int b = blockIdx.y;
   const int t = blockIdx.x * LN_TT + tx;
   const bool tok = t < A.T;
-  const int cpt = (A.C + LN_G - 1) / LN_G;
   const int64_t base = (int64_t)b * A.C * A.T;
+  const int nslab = A.nslab < 1 ? 1 : A.nslab;
 
   float v[LN_MAXCPT];
   float s = 0.f;
@@ -32,11 +34,12 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
   for (int i = 0; i < LN_MAXCPT; ++i) {
     v[i] = 0.f;
     const int c = ty + i * LN_G;
-    if (i < cpt && c < A.C && tok) {
+    if (c < A.C && tok) {
       const int64_t off = base + (int64_t)c * A.T + t;
       float x;
       if (A.mode == 0) {
         x = A.a[off];
+        for (int sl = 1; sl < nslab; ++sl) x += A.a[(int64_t)sl * A.slab_stride + off];
         if (A.add) x += A.add[off];
       } else {
         x = A.dwb[c];
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
 #pragma unroll
   for (int i = 0; i < LN_MAXCPT; ++i) {
     const int c = ty + i * LN_G;
-    if (i < cpt && c < A.C) {
+    if (c < A.C) {
       const float d = v[i] - mean;
       q += d * d;
     }
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
 #pragma unroll
   for (int i = 0; i < LN_MAXCPT; ++i) {
     const int c = ty + i * LN_G;
-    if (i < cpt && c < A.C) {
+    if (c < A.C) {
       const int64_t off = base + (int64_t)c * A.T + t;
       float y = (v[i] - mean) * rstd * A.gamma[c] + A.beta[c];
       if (A.post_gelu) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
 }
 
 int launch_layernorm(hipStream_t stream, const LnArgs& a) {
-  if (a.C > LN_G * LN_MAXCPT || a.C < 1 || a.T < 1 || a.B < 1) return -1;
+  if (a.C > LN_G * LN_MAXCPT || a.C < 1 || a.T < 1 || a.B < 1 || a.nslab > BV2_MAX_KSPLIT) return -1;
   dim3 grid((a.T + LN_TT - 1) / LN_TT, a.B);
   hipLaunchKernelGGL(layernorm_kernel, grid, dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -111,7 +111,9 @@ __global__ void embed_kernel(const EmbedArgs A) {
   const int64_t off = ((int64_t)b * A.C + c) * A.T + t;
   float v = A.emb[xi * A.C + c] + A.tone_emb[ti * A.C + c];
   v += A.lang_emb[li * A.C + c];
-  v += A.bsum[off];
+  float bs = A.bsum[off];
+  for (int sl = 1; sl < A.nslab; ++sl) bs += A.bsum[(int64_t)sl * A.slab_stride + off];
+  v += bs;
   A.out[off] = v * A.scale * A.mask[bt];
 }
 int launch_embed(hipStream_t stream, const EmbedArgs& a) {

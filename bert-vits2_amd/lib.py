@@ -65,7 +65,7 @@ class DecodeOut(C.Structure):
 
 
 class ProfileRow(C.Structure):
-    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
 
 

@@ -310,8 +310,8 @@ class SynthesizerTrn(nn.Module):
         self._lib.bv2_profile_reset(self._handle)
 
     def profile_report(self):
-        rows = (L.ProfileRow * 32)()
-        n = self._lib.bv2_profile_report(self._handle, rows, 32)
+        rows = (L.ProfileRow * 256)()
+        n = self._lib.bv2_profile_report(self._handle, rows, 256)
         out = []
         for i in range(max(n, 0)):
             r = rows[i]

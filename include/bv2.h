@@ -167,13 +167,14 @@ int bv2_set_tap(bv2_handle* h, const char* name, float* dev_dst, int64_t capacit
 
 /* Per-kernel-family timing with HIP events recorded on the caller's stream (bench.py's roofline leg). */
 typedef struct bv2_profile_row {
-  char name[64];          /* kernel family, e.g. "conv1d_mfma<128x128>" */
+  char name[96];          /* kernel family, e.g. "conv1d_mfma<128x128>" (mode 3: "site|family shape") */
   int64_t launches;
   double total_ms;        /* sum of event-timed durations */
   double flops;           /* algorithmic FLOPs (2*MAC) over those launches */
   double bytes;           /* algorithmic bytes (inputs read once + outputs written once + weights) */
 } bv2_profile_row;
-int bv2_profile_enable(bv2_handle* h, int on);          /* 0 off, 1 every MFMA kernel launch, 2 Generator launches only */
+int bv2_profile_enable(bv2_handle* h, int on);          /* 0 off, 1 every MFMA kernel launch, 2 Generator launches only,
+                                                            3 every MFMA launch with one row per launch site and shape */
 int bv2_profile_reset(bv2_handle* h);
 /* Synchronises the recorded events and aggregates them; returns the number of rows written (<= max_rows). */
 int bv2_profile_report(bv2_handle* h, bv2_profile_row* rows, int max_rows);

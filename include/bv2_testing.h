@@ -12,23 +12,26 @@ extern "C" {
 /* floats of device scratch bv2_test_conv1d needs for the packed weight + bias */
 int64_t bv2_test_conv_pack_floats(int cin, int cout, int k);
 
-/* One conv1d problem through the MFMA implicit-GEMM kernel with a forced tile variant (0 = auto, 1..5 see
- * bv2_kernels.h TILE_*).  w_host [cout][cin][k] / bias_host [cout] are HOST pointers (packed + uploaded
+/* One conv1d problem through the MFMA implicit-GEMM kernels with a forced variant (0 = auto, 1..5 LDS-tiled kernel tile
+ * shapes, 6 = split-K kernel; see bv2_kernels.h TILE_*).  With tile 6 and ksplit > 1 the output is `ksplit` partial
+ * slabs, `slab_stride` floats apart, whose SUM is the result (bias / residual ride on slab 0).  w_host [cout][cin][k] / bias_host [cout] are HOST pointers (packed + uploaded
  * synchronously into wpack_dev); every other pointer is DEVICE.  x [B][cin][L], out/res [B][cout][L*out_tstride],
  * masks [B][L].  pad_left < 0 means "same" padding ((k-1)/2*dil). */
 int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const float* bias_host, float* out, float* wpack_dev,
                     int B, int cin, int cout, int k, int dil, int pad_left, int L, int tile, float lrelu_slope, int relu,
                     const float* res, int res_mode, const float* in_mask, const float* out_mask, int mask_pre,
-                    int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale);
+                    int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale, int ksplit,
+                    int64_t slab_stride);
 
-/* windowed relative-position attention; qkv [B][3*H*D][T], mask [B][T], erk/erv [2W+1][D], out [B][H*D][T] (all DEVICE) */
-int bv2_test_attention(void* stream, const float* qkv, const float* mask, const float* erk, const float* erv, float* out,
+/* windowed relative-position attention; qkv [B][3*H*D + H*(2W+1)][ld] (q rows pre-divided by sqrt(D); the last H*(2W+1)
+ * rows are the relative-key logits q_i·Ek[r]/sqrt(D)), ld % 32 == 0, mask [B][T], erv [2W+1][D], out [B][H*D][T] (all DEVICE) */
+int bv2_test_attention(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,
                        int B, int H, int D, int T, int W);
 
 /* channel LayerNorm family (see bv2_kernels.h LnArgs); all DEVICE pointers, nullable where optional */
 int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode, const float* dww, const float* dwb, int dil,
                        const float* in_mask, const float* gamma, const float* beta, int post_gelu, const float* res,
-                       const float* vec, const float* mask, float* out, int B, int C, int T);
+                       const float* vec, const float* mask, float* out, int B, int C, int T, int nslab, int64_t slab_stride);
 
 /* inverse RQ spline on channel `dst` of z [B][2][T] with params [B][prow][T] (DEVICE) */
 int bv2_test_spline(void* stream, float* z, int src, int dst, const float* params, int prow, const float* mask,

@@ -19,12 +19,13 @@ def _lib():
     lib.bv2_test_conv_pack_floats.argtypes = [C.c_int] * 3
     lib.bv2_test_conv1d.restype = C.c_int
     lib.bv2_test_conv1d.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
-                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float])
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                    C.c_int, C.c_int64])
     lib.bv2_test_attention.restype = C.c_int
-    lib.bv2_test_attention.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5
+    lib.bv2_test_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5
     lib.bv2_test_layernorm.restype = C.c_int
     lib.bv2_test_layernorm.argtypes = ([C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3 +
-                                       [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3)
+                                       [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_int64])
     lib.bv2_test_spline.restype = C.c_int
     lib.bv2_test_spline.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                                     C.c_float, C.c_int, C.c_int]
@@ -46,6 +47,10 @@ CONV_CASES = [
     (2, 16, 16, 3, 3, 700, 5), (1, 192, 768, 5, 1, 77, 0), (1, 768, 192, 5, 1, 77, 0), (3, 192, 576, 1, 1, 50, 0),
     (2, 1024, 192, 1, 1, 24, 0), (2, 96, 192, 1, 1, 33, 0), (2, 192, 96, 1, 1, 33, 0), (2, 192, 29, 1, 1, 33, 0),
     (2, 256, 1, 1, 1, 40, 0), (1, 192, 512, 7, 1, 64, 0), (1, 192, 384, 5, 1, 31, 0),
+    # forced split-K kernel (tile 6) incl. dilation, ragged channel counts, and the LDS-tiled kernel on the same small shapes
+    (1, 192, 768, 5, 1, 77, 6), (1, 768, 192, 5, 1, 384, 6), (2, 1024, 192, 1, 1, 24, 6), (2, 96, 192, 1, 1, 33, 6),
+    (2, 192, 29, 1, 1, 33, 6), (1, 64, 64, 7, 3, 300, 6), (1, 512, 256, 2, 1, 100, 6), (1, 192, 768, 5, 1, 77, 4),
+    (1, 768, 192, 5, 1, 77, 2), (2, 48, 40, 3, 2, 50, 6),
 ]
 
 
@@ -61,7 +66,56 @@ def test_conv1d_mfma_plain(B, cin, cout, k, dil, L, tile):
     out = torch.full((B, cout, L), float("nan"), device="cuda")
     wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
     rc = lib.bv2_test_conv1d(None, P(xd), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, tile, 0.0, 0, None, 0,
-                             None, None, 0, 0, None, 1, None, None, 1.0)
+                             None, None, 0, 0, None, 1, None, None, 1.0, 1, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("ksplit", [2, 4, 8])
+@pytest.mark.parametrize("res_mode", [0, 1, 2])
+def test_conv1d_splitk_partial_slabs(ksplit, res_mode):
+    """K split across workgroups: the result is the SUM of `ksplit` slabs (bias / residual / reverse-subtract ride on
+    slab 0, masks are applied to every slab) — what the LayerNorm / embed consumers add up."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(ksplit * 10 + res_mode)
+    B, cin, cout, k, dil, L = 2, 768, 192, 5, 1, 70
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias, res = torch.randn(cout, generator=g), torch.randn(B, cout, L, generator=g)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, L - 19])[:, None]).float()
+    y = F.conv1d((x * mask[:, None]).double(), w.double(), bias.double(), padding=(k - 1) // 2) * mask[:, None].double()
+    ref = y if res_mode == 0 else (y + res.double() if res_mode == 1 else res.double() - y)
+    slab = B * cout * L
+    out = torch.full((ksplit, B, cout, L), float("nan"), device="cuda")
+    wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
+    xd, rd, md = x.cuda(), res.cuda(), mask.cuda()
+    rc = lib.bv2_test_conv1d(None, P(xd), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, 6, 0.0, 0,
+                             P(rd) if res_mode else None, res_mode, P(md), P(md), 1, 0, None, 1, None, None, 1.0, ksplit, slab)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_err(out.sum(0), ref) < 2e-5
+
+
+def test_conv1d_splitk_fused_epilogues():
+    """split-K kernel, single slab: lrelu pre-activation with in_scale, per-batch bias, ReLU, masks, residual."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(77)
+    B, cin, cout, k, dil, L = 2, 64, 128, 5, 2, 133
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias, bias2 = torch.randn(cout, generator=g), torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, L, generator=g)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, L - 57])[:, None]).float()
+    xin = F.leaky_relu(x.double() * 0.5, 0.1) * mask[:, None].double()
+    y = F.conv1d(xin, w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil) + bias2[:, :, None].double()
+    y = torch.relu(y) * mask[:, None].double()
+    ref = (y + res.double()) * mask[:, None].double()
+    out = torch.full((B, cout, L), float("nan"), device="cuda")
+    wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
+    xd, rd, md, b2 = x.cuda(), res.cuda(), mask.cuda(), bias2.cuda()
+    rc = lib.bv2_test_conv1d(None, P(xd), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, 6, 0.1, 1,
+                             P(rd), 1, P(md), P(md), 1, 1, P(b2), 1, None, None, 0.5, 1, 0)
     assert rc == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 2e-5
@@ -87,7 +141,7 @@ def test_conv1d_mfma_fused_epilogues(tile):
         xd = [t.cuda() for t in xs]
         rd, md, b2 = res.cuda(), mask.cuda(), bias2.cuda()
         rc = lib.bv2_test_conv1d(None, P(xd[0]), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, tile, 0.1, 1,
-                                 P(rd), res_mode, P(md), P(md), 1, 1, P(b2), 3, P(xd[1]), P(xd[2]), 1.0 / 3.0)
+                                 P(rd), res_mode, P(md), P(md), 1, 1, P(b2), 3, P(xd[1]), P(xd[2]), 1.0 / 3.0, 1, 0)
         assert rc == 0
         torch.cuda.synchronize()
         assert rel_err(out, ref) < 2e-5
@@ -119,7 +173,8 @@ def _ref_attention(qkv, mask, erk, erv, H, W):
     return o.transpose(2, 3).reshape(B, HD, T)
 
 
-@pytest.mark.parametrize("B,T,lens", [(1, 128, [128]), (2, 100, [100, 37]), (1, 3, [3]), (3, 33, [33, 1, 20]), (1, 400, [400])])
+@pytest.mark.parametrize("B,T,lens", [(1, 128, [128]), (2, 100, [100, 37]), (1, 3, [3]), (3, 33, [33, 1, 20]), (1, 400, [400]),
+                                      (1, 384, [384]), (2, 250, [250, 129]), (1, 600, [600])])
 def test_attention_relpos(B, T, lens):
     lib = _lib()
     H, D, W = 2, 96, 4
@@ -130,8 +185,16 @@ def test_attention_relpos(B, T, lens):
     mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float()
     ref = _ref_attention(qkv, mask, erk, erv, H, W)
     out = torch.full((B, H * D, T), float("nan"), device="cuda")
-    a = [t.cuda() for t in (qkv, mask, erk, erv)]
-    assert lib.bv2_test_attention(None, P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(out), B, H, D, T, W) == 0
+    # kernel input layout: rows [q/sqrt(D) | k | v | per head the 2W+1 relative-key logits], row stride ld (32-aligned),
+    # padding columns filled with NaN to prove they are never consumed
+    ld = (T + 31) // 32 * 32
+    NR = 2 * W + 1
+    qs = qkv[:, : H * D] / math.sqrt(D)
+    qe = torch.einsum("bhdt,rd->bhrt", qs.view(B, H, D, T), erk).reshape(B, H * NR, T)
+    packed = torch.full((B, 3 * H * D + H * NR, ld), float("nan"))
+    packed[:, :, :T] = torch.cat([qs, qkv[:, H * D:], qe], 1)
+    a = [t.cuda() for t in (packed, mask, erv)]
+    assert lib.bv2_test_attention(None, P(a[0]), ld, P(a[1]), P(a[2]), P(out), B, H, D, T, W) == 0
     torch.cuda.synchronize()
     valid = mask[:, None, :].bool().expand_as(ref)          # padded query rows are masked downstream
     assert ((out.cpu().double() - ref).abs()[valid].max() / ref.abs().max()).item() < 2e-5
@@ -155,7 +218,15 @@ def test_layernorm_family(C, T, B):
     out = torch.empty(B, C, T, device="cuda")
     t = [dev(x) for x in (a, add, gamma, beta, vec, mask)]
     assert lib.bv2_test_layernorm(None, P(t[0]), P(t[1]), 0, None, None, 1, None, P(t[2]), P(t[3]), 0, None, P(t[4]), P(t[5]),
-                                  P(out), B, C, T) == 0
+                                  P(out), B, C, T, 1, 0) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 1e-5
+    # mode 0 fed by 3 partial slabs whose sum is `a`
+    parts = torch.randn(3, B, C, T, generator=g)
+    parts[0] = a - parts[1] - parts[2]
+    pd_ = parts.cuda()
+    assert lib.bv2_test_layernorm(None, P(pd_), P(t[1]), 0, None, None, 1, None, P(t[2]), P(t[3]), 0, None, P(t[4]), P(t[5]),
+                                  P(out), B, C, T, 3, B * C * T) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 1e-5
     # mode 1: gelu(LN(depthwise k3 dil conv(a*mask))) ; then res + .
@@ -165,7 +236,7 @@ def test_layernorm_family(C, T, B):
         ref = res.double() + F.gelu(ln(y))
         t2 = [dev(x) for x in (dww, dwb, res)]
         assert lib.bv2_test_layernorm(None, P(t[0]), None, 1, P(t2[0]), P(t2[1]), dil, P(t[5]), P(t[2]), P(t[3]), 1, P(t2[2]),
-                                      None, None, P(out), B, C, T) == 0
+                                      None, None, P(out), B, C, T, 1, 0) == 0
         torch.cuda.synchronize()
         assert rel_err(out, ref) < 1e-5
 
