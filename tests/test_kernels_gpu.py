@@ -49,7 +49,7 @@ CONV_CASES = [
     (2, 256, 1, 1, 1, 40, 0), (1, 192, 512, 7, 1, 64, 0), (1, 192, 384, 5, 1, 31, 0),
     # forced split-K kernel (tile 6) incl. dilation, ragged channel counts, and the LDS-tiled kernel on the same small shapes
     (1, 192, 768, 5, 1, 77, 6), (1, 768, 192, 5, 1, 384, 6), (2, 1024, 192, 1, 1, 24, 6), (2, 96, 192, 1, 1, 33, 6),
-    (2, 192, 29, 1, 1, 33, 6), (1, 64, 64, 7, 3, 300, 6), (1, 512, 256, 2, 1, 100, 6), (1, 192, 768, 5, 1, 77, 4),
+    (2, 192, 29, 1, 1, 33, 6), (1, 64, 64, 7, 3, 300, 6), (1, 512, 256, 3, 1, 100, 6), (1, 192, 768, 5, 1, 77, 4),
     (1, 768, 192, 5, 1, 77, 2), (2, 48, 40, 3, 2, 50, 6),
 ]
 
