@@ -10,7 +10,7 @@
 // them as 2W+1 extra output rows per head (weights Ek·Wq/sqrt(d), folded at pack time).
 //
 // Mapping (latency-first: at batch 1 the whole op is ~0.1 GFLOP): one workgroup = 32 queries of one (batch, head); it
-// has one wave per 32-key tile (up to 16 waves, round-robin beyond), flash-decoding style, merged through LDS.
+// has one wave per 32-key tile (up to 8 waves, round-robin beyond), flash-decoding style, merged through LDS.
 //   S^T tile  [32 keys x 32 queries] = K^T·Q : A[m=key][kk=c] = k[c][j] and B[kk=c][n=query] = q[c][i] are both natural
 //             row reads of the [C][T] layout (time contiguous) — no transposes anywhere.
 //   D layout: lane holds ONE query column (l&31) and 16 key rows -> row max / row sum are in-lane + one shfl_xor(32).
@@ -24,6 +24,15 @@
 namespace bv2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// wave-uniform base (SGPR pair) + 32-bit per-lane BYTE offset: one VGPR per address instead of a 64-bit pair
+__device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 constexpr int AQ = 32;          // queries per workgroup
 constexpr int AK = 32;          // keys per tile
@@ -33,8 +42,10 @@ constexpr int ANS = 4;          // merge slots
 template <int DT, int NW>       // D = 32*DT head channels, NW waves
 __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   constexpr int D = 32 * DT;
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
   const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AQ;
   const int T = A.T, W = A.W, NR = 2 * W + 1, ld = A.ld;
@@ -42,7 +53,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   const int R = 3 * HD + A.H * NR;
 
   float* Os = smem;                                 // [ANS][D][AQ] partial outputs
-  float* Sb = Os + ANS * D * AQ;                    // [NR][AQ] raw band logits
+  float* Qs = Os + ANS * D * AQ;                    // [D][AQ] query tile (pre-scaled by the projection)
+  float* Ev = Qs + D * AQ;                          // [2*AMAXW+1][D] relative-value embedding
+  float* Sb = Ev + (2 * AMAXW + 1) * D;             // [NR][AQ] raw band logits -> band probabilities
   float* Mw = Sb + (2 * AMAXW + 1) * AQ;            // [NW][AQ]
   float* Lw = Mw + NW * AQ;                         // [NW][AQ]
 
@@ -55,7 +68,39 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 
   const int iq = i0 + l31;                          // this lane's query
   const bool iok = iq < T;
+  const int ntiles = (T + AK - 1) / AK;
+
+  // ---- everything this wave's first key tile needs goes in flight at once (one memory round trip):
+  //      K tile -> D/2 registers + key mask now; the V tile (D/8 float4) is issued as soon as the K registers are consumed
+  float kreg[D / 2];
+  f32x4 vreg[DT][4];
+  float mkey = 0.f;
+  const unsigned koff = 4u * (unsigned)(lh * ld + l31);         // per-lane byte offsets, shared by every load of a tile
+  const unsigned voff = 4u * (unsigned)(l31 * ld + 4 * lh);
+  auto issue_k = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) kreg[s] = ld_off(kp, koff + 4u * (unsigned)(j0 + 2 * s * ld));
+    const int jm = j0 + l31;
+    mkey = mp[jm < T ? jm : T - 1];
+  };
+  auto issue_v = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < DT; ++m)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) vreg[m][g4] = ld_off4(vp, voff + 4u * (unsigned)((m * 32) * ld + j0 + 8 * g4));
+  };
+  const bool have_tile = wid < ntiles;
+  if (have_tile) {
+    issue_k(wid * AK);
+  }
   const float mi = iok ? mp[iq] : 0.f;
+  // query tile and Ev -> LDS (all threads)
+  for (int e = tid; e < D * AQ; e += NT) {
+    const int c = e >> 5, i = e & 31;
+    Qs[e] = qp[c * ld + i0 + i];                    // columns beyond T: finite-or-not garbage, dead columns below
+  }
+  for (int e = tid; e < NR * D; e += NT) Ev[e] = A.erv[e];
+  __syncthreads();
 
   f32x16 O[DT];
 #pragma unroll
@@ -64,46 +109,59 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     for (int r = 0; r < 16; ++r) O[m][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (T + AK - 1) / AK;
+#pragma unroll 1
   for (int kt = wid; kt < ntiles; kt += NW) {
     const int j0 = kt * AK;
-    // ---- S^T = K^T Q   (rows beyond T hold finite-or-not garbage: replaced below, never accumulated)
+    if (kt >= NW) issue_k(j0);
+    // ---- S^T = K^T Q   (rows beyond T hold garbage: replaced below, never accumulated)
     f32x16 S;
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    // the Q operand streams from LDS a few K-steps ahead of the MFMAs (pinned: hoisting all D/2 reads costs registers)
+    float qb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qb[s] = Qs[(2 * s + lh) * AQ + l31];
 #pragma unroll
     for (int s = 0; s < D / 2; ++s) {
-      const float a = kp[(int64_t)(2 * s + lh) * ld + j0 + l31];
-      const float q = qp[(int64_t)(2 * s + lh) * ld + iq];
-      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q, S, 0, 0, 0);
+      const float qcur = qb[s & 3];
+      if (s + 4 < D / 2) qb[s & 3] = Qs[(2 * (s + 4) + lh) * AQ + l31];
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qcur, S, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);             // keep the V loads BEHIND the S MFMAs (K registers are free again)
+    issue_v(j0);                                   // in flight under the softmax
+    __builtin_amdgcn_sched_barrier(0);
     // ---- relative logits, mask, band capture, online softmax (lane = query column, regs = key rows)
     const bool near_band = (j0 - i0 <= AQ - 1 + W) && (i0 - j0 <= AK - 1 + W);     // wave-uniform
     float tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int jr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int j = j0 + jr;
       float sv = S[r];
-      const int rel = j - iq;
-      const bool inband = near_band && (rel >= -W) && (rel <= W) && iok;
-      if (inband) sv += qe[(int64_t)(rel + W) * ld + iq];
-      if (j < T) {
-        if (!(mi != 0.f && mp[j] != 0.f)) sv = -1e4f;        // masked_fill(mask == 0, -1e4), attentions.py:297
+      const float mj = __shfl(mkey, jr);                       // key mask of row jr (lane jr loaded key j0+jr)
+      if (near_band) {
+        const int rel = j - iq;
+        const bool inband = (rel >= -W) && (rel <= W) && iok && j < T;
+        if (inband) sv += qe[(rel + W) * ld + iq];
+        if (!(mi != 0.f && mj != 0.f)) sv = -1e4f;              // masked_fill(mask == 0, -1e4), attentions.py:297
         if (inband) Sb[(rel + W) * AQ + l31] = sv;
       } else {
-        sv = -INFINITY;                                       // key does not exist
+        if (!(mi != 0.f && mj != 0.f)) sv = -1e4f;
       }
-      if (!iok) sv = (j < T) ? 0.f : -INFINITY;               // dead query column: keep it finite
+      if (j >= T) sv = -INFINITY;                               // key does not exist
+      if (!iok) sv = (j < T) ? 0.f : -INFINITY;                 // dead query column: keep it finite
       S[r] = sv;
       tmax = fmaxf(tmax, sv);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);                  // first tile: exp(-inf) = 0
+    const float alpha = __expf(m_run - m_new);                  // first tile: exp(-inf) = 0
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = expf(S[r] - m_new);
+      const float p = __expf(S[r] - m_new);
       psum += p;
       S[r] = p;
     }
@@ -119,10 +177,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     // ---- O^T += V P^T, K-steps in D-layout row order
 #pragma unroll
     for (int m = 0; m < DT; ++m) {
-      const float* vrow = vp + (int64_t)(m * 32 + l31) * ld + j0 + 4 * lh;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        float4 v4 = *reinterpret_cast<const float4*>(vrow + 8 * g4);
+        f32x4 v4 = vreg[m][g4];
         const int jb = j0 + 8 * g4 + 4 * lh;
         if (jb + 3 >= T) {                                    // tile tail: keys that do not exist contribute exactly 0
           v4.x = jb + 0 < T ? v4.x : 0.f; v4.y = jb + 1 < T ? v4.y : 0.f;
@@ -146,9 +203,24 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     const float mw = Mw[w * AQ + l31];
-    l_tot += (mw == -INFINITY) ? 0.f : Lw[w * AQ + l31] * expf(mw - m_tot);
+    l_tot += (mw == -INFINITY) ? 0.f : Lw[w * AQ + l31] * __expf(mw - m_tot);
   }
-  const float fac = (m_run == -INFINITY) ? 0.f : expf(m_run - m_tot);
+  const float il = 1.0f / l_tot;                    // per lane: query l31 (== tid & 31 below since AQ == 32)
+  const float fac = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_tot);
+  // band logits -> band probabilities p[i][i+r] (each (r, i) once)
+  for (int e = tid; e < NR * AQ; e += NT) {
+    const int r = e >> 5, i = e & 31;
+    const int j = i0 + i + r - W;
+    float mt = -INFINITY, lt = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mt = fmaxf(mt, Mw[w * AQ + i]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float mw = Mw[w * AQ + i];
+      lt += (mw == -INFINITY) ? 0.f : Lw[w * AQ + i] * __expf(mw - mt);
+    }
+    Sb[e] = (j >= 0 && j < T && i0 + i < T) ? __expf(Sb[e] - mt) / lt : 0.f;
+  }
   constexpr int ROUNDS = (NW + ANS - 1) / ANS;
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -169,7 +241,6 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 
   // ---- normalise, add relative-value term, store (coalesced over queries)
   float* op = A.out + (int64_t)b * HD * T + (int64_t)(h * D) * T;
-  const float il = 1.0f / l_tot;                    // per lane: query l31 (same for tid&31 below since AQ == 32)
   const int i = tid & 31, ig = i0 + i;
   if (ig < T) {
     for (int c = tid >> 5; c < D; c += 2 * NW) {
@@ -177,17 +248,14 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 #pragma unroll
       for (int sl = 0; sl < NSLOT; ++sl) o += Os[sl * (D * AQ) + c * AQ + i];
       o *= il;
-      for (int r = 0; r < NR; ++r) {
-        const int j = ig + r - W;
-        if (j >= 0 && j < T) o += (expf(Sb[r * AQ + i] - m_tot) * il) * A.erv[r * D + c];
-      }
+      for (int r = 0; r < NR; ++r) o += Sb[r * AQ + i] * Ev[r * D + c];
       op[(int64_t)c * T + ig] = o;
     }
   }
 }
 
 static size_t attn_lds_bytes(int D, int NW) {
-  return sizeof(float) * (size_t)(ANS * D * AQ + (2 * AMAXW + 1) * AQ + 2 * NW * AQ);
+  return sizeof(float) * (size_t)(ANS * D * AQ + D * AQ + (2 * AMAXW + 1) * D + (2 * AMAXW + 1) * AQ + 2 * NW * AQ);
 }
 
 template <int DT, int NW>
@@ -201,10 +269,9 @@ static int launch_attn_variant(hipStream_t stream, const AttnArgs& a, dim3 grid)
 
 template <int DT>
 static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int ntiles) {
+  // 8 waves is the most the register file holds without spilling (K tile + O + S per wave, 2 waves per SIMD)
   if (ntiles <= 4) return launch_attn_variant<DT, 4>(stream, a, grid);
-  if (ntiles <= 8) return launch_attn_variant<DT, 8>(stream, a, grid);
-  if (ntiles <= 12) return launch_attn_variant<DT, 12>(stream, a, grid);
-  return launch_attn_variant<DT, 16>(stream, a, grid);
+  return launch_attn_variant<DT, 8>(stream, a, grid);
 }
 
 int launch_attention(hipStream_t stream, const AttnArgs& a) {

@@ -23,6 +23,7 @@
 // (models.py:539-545), attentions.FFN (attentions.py:438-446), q/k/v/o and all 1x1 projections, DurationPredictor
 // convs (models.py:285-299), WN in/res_skip layers (modules.py:192-210).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "../bv2_kernels.h"
 
 namespace bv2 {
@@ -55,7 +56,8 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 
   const ConvProb& P = L.p[blockIdx.z];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
   const int l31 = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
   const int b = blockIdx.y / mtiles;
@@ -273,16 +275,17 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 
 // ---------------------------------------------------------------------------------------------------------------
 // split-K kernel for small-N problems
-constexpr int SK_PD = 4;          // prefetch ring depth (units of 4 MFMAs)
+constexpr int SK_PD = 8;          // prefetch ring depth (units of 4 MFMAs)
 
 __device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-template <bool MASK>
-__global__ void __launch_bounds__(256) conv1d_splitk_kernel(const ConvLaunch L, const int mtiles, const int ntiles,
-                                                            const int per_xcd, const int total) {
-  __shared__ __attribute__((aligned(16))) float red[4][32][33];
+template <bool MASK, int NWV>    // NWV waves per workgroup split K inside the workgroup
+__global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunch L, const int mtiles, const int ntiles,
+                                                                 const int per_xcd, const int total) {
+  extern __shared__ __attribute__((aligned(16))) float red_raw[];
+  float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(red_raw);   // [NWV][32][33]
   // XCD-aware placement: consecutive virtual ids (which share a weight slice) land on the same XCD
   const int bid = blockIdx.x;
   const int v = (bid & 7) * per_xcd + (bid >> 3);
@@ -297,7 +300,8 @@ __global__ void __launch_bounds__(256) conv1d_splitk_kernel(const ConvLaunch L, 
   if (m0 >= P.cout_pad) return;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
   const int l31 = lane & 31, lh = lane >> 5;
   // problem fields hoisted into registers (P lives in the kernarg segment)
   const int k = P.k, dil = P.dil, cin = P.cin, Lin = P.Lin;
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(256) conv1d_splitk_kernel(const ConvLaunch L, 
   const unsigned w_tap = w_unit * (unsigned)groups;                 // bytes between consecutive taps
   const unsigned w_lane = 16u * (unsigned)(lh * P.w_ld + m0 + l31);
   // channel groups of this (slice z, wave wid): contiguous range, balanced
-  const int nsl = L.ksplit * 4, sl = z * 4 + wid;
+  const int nsl = L.ksplit * NWV, sl = z * NWV + wid;
   const int g0 = (int)(((int64_t)groups * sl) / nsl), g1 = (int)(((int64_t)groups * (sl + 1)) / nsl);
   const int U = (g1 - g0) * k;                   // units of (group, tap) = 4 MFMAs each
 
@@ -383,7 +387,7 @@ __global__ void __launch_bounds__(256) conv1d_splitk_kernel(const ConvLaunch L, 
     }
   }
 
-  // reduce the 4 waves' partial tiles through LDS
+  // reduce the waves' partial tiles through LDS
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r];
   __syncthreads();
@@ -391,12 +395,16 @@ __global__ void __launch_bounds__(256) conv1d_splitk_kernel(const ConvLaunch L, 
   if (col >= L.L) return;
   const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
   float* outp = P.out + (int64_t)z * L.slab_stride;
+  constexpr int RPP = 2 * NWV;                    // rows per pass (one element per thread per pass)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rl = (tid >> 5) + 8 * i;
+  for (int i = 0; i < 32 / RPP; ++i) {
+    const int rl = (tid >> 5) + RPP * i;
     const int row = m0 + rl;
     if (row >= P.cout) continue;
-    float vv = (red[0][rl][tid & 31] + red[1][rl][tid & 31]) + (red[2][rl][tid & 31] + red[3][rl][tid & 31]);
+    float vv = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; w += 4)
+      vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
     if (z == 0) {
       if (P.bias) vv += P.bias[row];
       if (P.bias2) vv += P.bias2[(int64_t)b * P.bias2_bstride + row];
@@ -447,7 +455,35 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int m
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-static int launch_splitk(hipStream_t stream, const ConvLaunch& L, int max_cout_pad) {
+// waves per workgroup of the split-K kernel: enough K slices that a wave owns ~SK_PD (group, tap) units, i.e. its
+// whole operand stream is in flight after one or two round trips
+static int splitk_waves(const ConvLaunch& L) {
+  int units = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    const int u = (L.p[i].cin_pad / 8) * L.p[i].k;
+    if (u > units) units = u;
+  }
+  const int want = (units + SK_PD - 1) / SK_PD;                   // K slices wanted in total (workgroup x cross-workgroup)
+  const int per_wg = (want + L.ksplit - 1) / L.ksplit;
+  return per_wg > 8 ? 16 : (per_wg > 4 ? 8 : 4);
+}
+
+template <bool MASK>
+static void launch_splitk_nw(hipStream_t stream, const ConvLaunch& L, int nw, dim3 grid, int mtiles, int ntiles, int per_xcd,
+                             int total) {
+  const size_t lds = sizeof(float) * (size_t)nw * 32 * 33;
+  if (nw == 16) {
+    auto kern = conv1d_splitk_kernel<MASK, 16>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, stream, L, mtiles, ntiles, per_xcd, total);
+  } else if (nw == 8) {
+    hipLaunchKernelGGL((conv1d_splitk_kernel<MASK, 8>), grid, dim3(512), lds, stream, L, mtiles, ntiles, per_xcd, total);
+  } else {
+    hipLaunchKernelGGL((conv1d_splitk_kernel<MASK, 4>), grid, dim3(256), lds, stream, L, mtiles, ntiles, per_xcd, total);
+  }
+}
+
+static int launch_splitk(hipStream_t stream, const ConvLaunch& L, int max_cout_pad, const char** variant_name) {
   const int mtiles = max_cout_pad / 32, ntiles = (L.L + 31) / 32;
   const int total = L.nprob * L.B * mtiles * L.ksplit * ntiles;
   const int per_xcd = (total + 7) / 8;
@@ -457,25 +493,28 @@ static int launch_splitk(hipStream_t stream, const ConvLaunch& L, int max_cout_p
     if (L.p[i].in_mask) any_mask = true; else all_mask = false;
   }
   if (any_mask != all_mask) return -2;            // one launch = one mask mode
-  if (any_mask)
-    hipLaunchKernelGGL(conv1d_splitk_kernel<true>, dim3(per_xcd * 8), dim3(256), 0, stream, L, mtiles, ntiles, per_xcd, total);
-  else
-    hipLaunchKernelGGL(conv1d_splitk_kernel<false>, dim3(per_xcd * 8), dim3(256), 0, stream, L, mtiles, ntiles, per_xcd, total);
+  const int nw = splitk_waves(L);
+  if (variant_name) *variant_name = nw == 16 ? "conv1d_splitk<32x32,16w>" : (nw == 8 ? "conv1d_splitk<32x32,8w>" : "conv1d_splitk<32x32,4w>");
+  const dim3 grid(per_xcd * 8);
+  if (any_mask) launch_splitk_nw<true>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total);
+  else launch_splitk_nw<false>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// K-split factor for the split-K kernel: enough workgroups to cover the chip, at most ~6 channel groups per wave.
+// K-split factor ACROSS workgroups for the split-K kernel (only when the consumer sums the slabs): as many slices as it
+// takes for a wave of a 16-wave workgroup to own ~SK_PD units, and at least ~192 workgroups on the chip.
 int conv_pick_ksplit(const ConvLaunch& L, int max_split) {
   if (max_split <= 1) return 1;
-  int groups = 0, mt = 0;
+  int groups = 0, mt = 0, units = 0;
   for (int i = 0; i < L.nprob; ++i) {
     if (L.p[i].cin_pad / 8 > groups) groups = L.p[i].cin_pad / 8;
+    if ((L.p[i].cin_pad / 8) * L.p[i].k > units) units = (L.p[i].cin_pad / 8) * L.p[i].k;
     if (L.p[i].cout_pad / 32 > mt) mt = L.p[i].cout_pad / 32;
     if (L.p[i].act != ACT_NONE) return 1;
   }
   const long base = (long)L.nprob * L.B * mt * ((L.L + 31) / 32);
   int ks = 1;
-  while (ks < max_split && (groups / (4 * ks) > 6 || base * ks < 192) && groups / (4 * ks * 2) >= 2) ks *= 2;
+  while (ks < max_split && groups / (ks * 2) >= 4 && (units > 16 * SK_PD * ks || base * ks < 192)) ks *= 2;
   return ks;
 }
 
@@ -501,18 +540,21 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     if ((p.k - 1) * p.dil > max_extra) max_extra = (p.k - 1) * p.dil;
     if (p.cin_pad % 32) ck = 16;
   }
+  static const int force_ck = [] { const char* e = getenv("BV2_FORCE_CK"); return e ? atoi(e) : 0; }();
+  if (force_ck == 16) ck = 16;
   for (int i = 0; i < L.nprob; ++i)
     if (L.p[i].cin_pad / ck > max_chunks) max_chunks = L.p[i].cin_pad / ck;
   if (tile == TILE_AUTO && conv_use_splitk(L)) tile = TILE_SPLITK;
   if (tile == TILE_SPLITK) {
     if (L.ksplit < 1 || L.ksplit > BV2_MAX_KSPLIT) return -1;
-    if (variant_name) *variant_name = "conv1d_splitk<32x32>";
-    return launch_splitk(stream, L, max_cout_pad);
+    return launch_splitk(stream, L, max_cout_pad, variant_name);
   }
   if (L.ksplit != 1) return -1;                   // the LDS-tiled kernel never splits K across workgroups
   if (tile == TILE_AUTO) {
-    // largest tile that still yields >= ~1 workgroup per CU (256 CUs); small problems fall to the smallest tiles
-    const long target = 256;
+    // largest tile that still yields >= ~2 workgroups per CU (256 CUs): the problems of one launch differ in cost
+    // (k = 3 / 7 / 11 branches), and with two resident workgroups per CU the dispatcher only balances them if there are
+    // more workgroups than slots.  BV2_TILE_TARGET overrides (tuning experiments).
+    static const long target = [] { const char* e = getenv("BV2_TILE_TARGET"); return e ? atol(e) : 512L; }();
     tile = TILE_32x128;
     for (const TileCfg& t : kTiles) {
       if (t.bm > max_cout_pad && t.bm != 32) continue;

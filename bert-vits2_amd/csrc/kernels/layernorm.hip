@@ -5,77 +5,94 @@
 //   * depthwise k=3 dilated conv in front (DDSConv.convs_sep, modules.py:122)
 //   * exact-erf GELU, residual add, per-batch speaker vector add, and sequence mask behind
 //     (modules.py:124-129, attentions.py:107-111,119).
-// Layout: a workgroup owns 16 consecutive time steps x all C channels (small tiles: at batch 1 the tensor is ~300 KB and
-// the kernel is pure latency, so it is cut into as many workgroups as keeps 64-byte row segments); thread (tx = t,
-// ty = channel group of 16) keeps its C/16 values in registers, so the input is read once and the statistics are a
-// two-pass (mean, then centred sum of squares) reduction over registers + one LDS exchange between the 16 groups.
+// Latency-first layout (at batch 1 the tensor is ~300 KB): a workgroup owns only 8 consecutive time steps x all C
+// channels; thread (tx = t, ty = channel group of 32) keeps its C/32 values in registers.  All loads are unconditional
+// (clamped addresses) and the slab / channel counts are template parameters, so every load of a thread is in flight
+// at once: ONE memory round trip, then a two-pass (mean, centred sum of squares) reduction through LDS.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
 
 namespace bv2 {
 
-constexpr int LN_TT = 16;      // time steps per workgroup
-constexpr int LN_G = 16;       // channel groups (threads along C)
-constexpr int LN_MAXCPT = 16;  // channels per thread (C <= 256)
+constexpr int LN_TT = 8;       // time steps per workgroup
+constexpr int LN_G = 32;       // channel groups (threads along C)
 
+template <int CPT, int NSLAB, int MODE, bool GUARD>   // CPT channels per thread; GUARD: C < CPT*LN_G allowed
 __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
   __shared__ float red[LN_G][LN_TT + 1];
   __shared__ float stat[LN_TT];
-  const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 4;
+  const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 3;
   const int b = blockIdx.y;
   const int t = blockIdx.x * LN_TT + tx;
   const bool tok = t < A.T;
-  const int64_t base = (int64_t)b * A.C * A.T;
-  const int nslab = A.nslab < 1 ? 1 : A.nslab;
+  const int tcl = tok ? t : A.T - 1;
+  const int C = A.C, T = A.T;
+  const int64_t base = (int64_t)b * C * T;
+  const float* ap = A.a + base;
 
-  float v[LN_MAXCPT];
-  float s = 0.f;
+  float v[CPT];
+  if (MODE == 0) {
 #pragma unroll
-  for (int i = 0; i < LN_MAXCPT; ++i) {
-    v[i] = 0.f;
-    const int c = ty + i * LN_G;
-    if (c < A.C && tok) {
-      const int64_t off = base + (int64_t)c * A.T + t;
-      float x;
-      if (A.mode == 0) {
-        x = A.a[off];
-        for (int sl = 1; sl < nslab; ++sl) x += A.a[(int64_t)sl * A.slab_stride + off];
-        if (A.add) x += A.add[off];
-      } else {
-        x = A.dwb[c];
+    for (int i = 0; i < CPT; ++i) {
+      int c = ty + i * LN_G;
+      if (GUARD) c = c < C ? c : C - 1;
+      const int off = c * T + tcl;
+      float x = ap[off];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int tt = t + (j - 1) * A.dil;
-          if (tt >= 0 && tt < A.T) {
-            float xv = A.a[base + (int64_t)c * A.T + tt];
-            if (A.in_mask) xv *= A.in_mask[(int64_t)b * A.T + tt];
-            x += A.dww[c * 3 + j] * xv;
-          }
-        }
-      }
+      for (int sl = 1; sl < NSLAB; ++sl) x += ap[(int64_t)sl * A.slab_stride + off];
       v[i] = x;
-      s += x;
+    }
+    if (A.add) {
+      const float* dp = A.add + base;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        int c = ty + i * LN_G;
+        if (GUARD) c = c < C ? c : C - 1;
+        v[i] += dp[c * T + tcl];
+      }
+    }
+  } else {
+    // depthwise k=3 conv with dilation: taps at t-dil, t, t+dil; zero padding; input pre-multiplied by in_mask
+    float mk3[3];
+    int tt3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tt = t + (j - 1) * A.dil;
+      const bool ok = tok && tt >= 0 && tt < T;
+      tt3[j] = ok ? tt : tcl;
+      mk3[j] = ok ? (A.in_mask ? A.in_mask[(int64_t)b * T + tt3[j]] : 1.f) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      int c = ty + i * LN_G;
+      if (GUARD) c = c < C ? c : C - 1;
+      float x = A.dwb[c];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) x += A.dww[c * 3 + j] * (ap[c * T + tt3[j]] * mk3[j]);
+      v[i] = x;
     }
   }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i)
+    if (!GUARD || ty + i * LN_G < C) s += v[i];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0) {
     float m = 0.f;
 #pragma unroll
     for (int g = 0; g < LN_G; ++g) m += red[g][tx];
-    stat[tx] = m / (float)A.C;
+    stat[tx] = m / (float)C;
   }
   __syncthreads();
   const float mean = stat[tx];
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCPT; ++i) {
-    const int c = ty + i * LN_G;
-    if (c < A.C) {
+  for (int i = 0; i < CPT; ++i)
+    if (!GUARD || ty + i * LN_G < C) {
       const float d = v[i] - mean;
       q += d * d;
     }
-  }
   __syncthreads();
   red[ty][tx] = q;
   __syncthreads();
@@ -83,30 +100,52 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
     float m = 0.f;
 #pragma unroll
     for (int g = 0; g < LN_G; ++g) m += red[g][tx];
-    stat[tx] = 1.0f / sqrtf(m / (float)A.C + A.eps);
+    stat[tx] = 1.0f / sqrtf(m / (float)C + A.eps);
   }
   __syncthreads();
   const float rstd = stat[tx];
   if (!tok) return;
-  const float mk = A.mask ? A.mask[(int64_t)b * A.T + t] : 1.f;
+  const float mk = A.mask ? A.mask[(int64_t)b * T + t] : 1.f;
+  float rr[CPT];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCPT; ++i) {
+  for (int i = 0; i < CPT; ++i) {
+    int c = ty + i * LN_G;
+    if (GUARD) c = c < C ? c : C - 1;
+    rr[i] = A.res ? A.res[base + c * T + t] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
     const int c = ty + i * LN_G;
-    if (c < A.C) {
-      const int64_t off = base + (int64_t)c * A.T + t;
+    if (!GUARD || c < C) {
       float y = (v[i] - mean) * rstd * A.gamma[c] + A.beta[c];
       if (A.post_gelu) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
-      if (A.res) y += A.res[off];
+      y += rr[i];
       if (A.vec) y += A.vec[(int64_t)b * A.vec_bstride + c];
-      A.out[off] = y * mk;
+      A.out[base + c * T + t] = y * mk;
     }
   }
 }
 
+template <int CPT, bool GUARD>
+static void launch_ln_cfg(hipStream_t stream, const LnArgs& a, dim3 grid) {
+  if (a.mode != 0) { hipLaunchKernelGGL((layernorm_kernel<CPT, 1, 1, GUARD>), grid, dim3(256), 0, stream, a); return; }
+  switch (a.nslab) {
+    case 2: hipLaunchKernelGGL((layernorm_kernel<CPT, 2, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((layernorm_kernel<CPT, 4, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
+    case 8: hipLaunchKernelGGL((layernorm_kernel<CPT, 8, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((layernorm_kernel<CPT, 1, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
+  }
+}
+
 int launch_layernorm(hipStream_t stream, const LnArgs& a) {
-  if (a.C > LN_G * LN_MAXCPT || a.C < 1 || a.T < 1 || a.B < 1 || a.nslab > BV2_MAX_KSPLIT) return -1;
+  if (a.C > LN_G * 8 || a.C < 1 || a.T < 1 || a.B < 1) return -1;
+  if ((int64_t)a.C * a.T >= (1ll << 31)) return -1;             // 32-bit in-batch offsets
+  const int ns = a.nslab < 1 ? 1 : a.nslab;
+  if (a.mode == 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8) return -1;
   dim3 grid((a.T + LN_TT - 1) / LN_TT, a.B);
-  hipLaunchKernelGGL(layernorm_kernel, grid, dim3(256), 0, stream, a);
+  if (a.C == 6 * LN_G) launch_ln_cfg<6, false>(stream, a, grid);          // hidden_channels 192
+  else if (a.C == 8 * LN_G) launch_ln_cfg<8, false>(stream, a, grid);     // DurationPredictor filter 256
+  else launch_ln_cfg<8, true>(stream, a, grid);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
