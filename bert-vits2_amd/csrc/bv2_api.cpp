@@ -283,14 +283,15 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
                     int64_t slab_stride) {
   try {
     const int cin_pad = t_round_up(cin, 16), ld = t_round_up(cout, 128), cout_pad = t_round_up(cout, 32);
-    std::vector<float> pk((size_t)bv2_test_conv_pack_floats(cin, cout, k), 0.f);
+    std::vector<float> pk;
+    if (w_host) pk.assign((size_t)bv2_test_conv_pack_floats(cin, cout, k), 0.f);
     if (w_host)                                   // w_host == NULL: wpack_dev already holds the packed weight (timing loops)
     for (int j = 0; j < k; ++j)
       for (int ci = 0; ci < cin; ++ci)
         for (int co = 0; co < cout; ++co)
-          pk[(size_t)conv_w_index(j, ci, co, cin_pad, ld)] = w_host[((size_t)co * cin + ci) * k + j];
+          pk[(size_t)conv_w_index(j, ci, co, cin_pad, k)] = w_host[((size_t)co * cin + ci) * k + j];
     const size_t boff = (size_t)k * cin_pad * ld;
-    if (bias_host) for (int co = 0; co < cout; ++co) pk[boff + co] = bias_host[co];
+    if (w_host && bias_host) for (int co = 0; co < cout; ++co) pk[boff + co] = bias_host[co];
     if (w_host && hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
     ConvLaunch cl;
     std::memset(&cl, 0, sizeof(cl));

@@ -12,10 +12,14 @@ namespace bv2 {
 //   out[b][co][t*out_tstride + out_toff] = epilogue( bias[co] + bias2[b][co]
 //        + sum_{ci<cin, j<k} Wp[j][ci][co] * pre( in_scale * sum_s x_s[b][ci][t - pad_left + j*dil] * in_mask[b][.] ) )
 //
-// Wp is the PACKED weight in MFMA "fragment order": [k][cin_pad/8][2][w_ld][4] fp32 — element (tap j, ci, co) lives at
-// ((((j*(cin_pad/8) + ci/8)*2 + (ci&1))*w_ld + co)*4 + (ci%8)/2, so the A operands of four consecutive K steps are one
-// aligned float4 per lane (cin_pad % 16 == 0; w_ld % 128 == 0, so any tile height may read a full row; rows >= cout are
-// zero; cout_pad = cout rounded up to 32 bounds the tiling).  One launch can carry several problems
+// Wp is the PACKED weight in MFMA "fragment order", one CONTIGUOUS stream per 32-row output tile:
+//   [m-tile = co/32][group = ci/8][tap j][lh = ci&1][co%32][q = (ci%8)/2]   (fp32; see conv_w_index)
+// so the A operands of four consecutive K steps are one aligned float4 per lane, a (group, tap) unit of one m-tile is
+// 1 KB contiguous, and a workgroup's weight stream is sequential in memory (the previous [tap][group][lh][C_out][4]
+// layout made every workgroup read 512-byte pieces at a multi-KB power-of-two-ish stride, which camped on 2 of the 16
+// L2 channels of an XCD: measured 125 GB/s of weight streaming).  cin_pad % 16 == 0; w_ld % 128 == 0 is the number of
+// rows ALLOCATED (so any tile height may read whole m-tiles; rows >= cout are zero); cout_pad = cout rounded up to 32
+// bounds the tiling.  One launch can carry several problems
 // (blockIdx.z) that share B and L: the three ResBlock branches of a Generator stage, the u polyphase branches of a
 // ConvTranspose1d, or the m_p / logs_p halves of enc_p.proj.
 enum { PRE_NONE = 0, PRE_LRELU = 1 };
@@ -69,8 +73,8 @@ bool conv_use_splitk(const ConvLaunch& L);
 // K-split factor (power of two <= max_split) that fills the chip for a split-K launch whose consumer sums the slabs
 int conv_pick_ksplit(const ConvLaunch& L, int max_split);
 // float index of weight element (tap j, input channel ci, output channel co) in the packed layout
-inline int64_t conv_w_index(int j, int ci, int co, int cin_pad, int w_ld) {
-  return ((((int64_t)j * (cin_pad / 8) + ci / 8) * 2 + (ci & 1)) * w_ld + co) * 4 + (ci % 8) / 2;
+inline int64_t conv_w_index(int j, int ci, int co, int cin_pad, int k) {
+  return ((((((int64_t)(co >> 5) * (cin_pad / 8) + ci / 8) * k + j) * 2 + (ci & 1)) * 32) + (co & 31)) * 4 + (ci % 8) / 2;
 }
 double conv_flops(const ConvLaunch& L);
 double conv_bytes(const ConvLaunch& L);

@@ -5,8 +5,8 @@
 //     reference models.py:513, modules.py:160-182, 226-292) — also accepts already folded `.weight` checkpoints
 //     (Generator.remove_weight_norm, models.py:559-564);
 // and what only a from-scratch layout can do:
-//   * conv weights re-laid as [tap][C_in/8][C_in&1][C_out ld128][(C_in%8)/2] = the MFMA A-operand fragment order: the
-//     operands of four consecutive K steps are one aligned float4 per lane (bv2_kernels.h conv_w_index);
+//   * conv weights re-laid as [C_out/32][C_in/8][tap][C_in&1][C_out%32][(C_in%8)/2] = the MFMA A-operand fragment order,
+//     one contiguous stream per 32-row output tile (bv2_kernels.h conv_w_index);
 //   * conv_q/k/v fused into one projection that also emits, per head, the 2W+1 relative-key logits
 //     q_i·Ek[r]/sqrt(d) (they are linear in the layer input: rows Ek·Wq/sqrt(d)); 1/sqrt(d) folded into the q rows;
 //   * ConvTranspose1d split into its u polyphase stride-1 convolutions (k/u taps each);
@@ -104,7 +104,7 @@ struct Packer {
       for (int j = 0; j < k; ++j)
         for (int ci = 0; ci < cin; ++ci)
           for (int co = 0; co < cout; ++co)
-            blob[c.w_off + conv_w_index(j, ci, co, c.cin_pad, c.w_ld)] = src(co, ci, j);
+            blob[c.w_off + conv_w_index(j, ci, co, c.cin_pad, k)] = src(co, ci, j);
       if (bias)
         for (int co = 0; co < cout; ++co) blob[c.b_off + co] = bsrc(co);
     }

@@ -3,9 +3,11 @@
 //
 //   GEMM view:  M = C_out (rows, from the packed weight),  N = time (columns, contiguous in HBM),  K = (tap j, C_in).
 //
-// Packed weight ("fragment order", written once by bv2_model.cpp):  Wp[tap j][group g = ci/8][lh = ci&1][co (ld w_ld)][q = (ci%8)/2]
+// Packed weight ("fragment order", written once by bv2_model.cpp):
+//      Wp[m-tile = co/32][group g = ci/8][tap j][lh = ci&1][co%32][q = (ci%8)/2]
 //   -> the four floats a lane needs as MFMA A operand (A[m = l&31][kk = l>>5]) for four consecutive K steps of one
-//      8-channel group are ONE aligned float4, both in HBM and in LDS (conflict-free ds_read_b128, 1 read per 4 MFMAs).
+//      8-channel group are ONE aligned float4, both in HBM and in LDS (conflict-free ds_read_b128, 1 read per 4 MFMAs),
+//      and the weight stream of one 32-row output tile is contiguous (sequential reads: no L2-channel camping).
 //
 // Two kernels:
 //  * conv1d_mfma_kernel  — LDS-tiled, for problems with enough columns to fill the chip (the Generator, and every conv at
@@ -37,10 +39,6 @@ __device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// float4 index of the A-operand quad of (tap j, channel group g, half lh, row co)
-__device__ __forceinline__ int64_t wq_index(int j, int g, int lh, int co, int groups, int w_ld) {
-  return ((int64_t)((j * groups + g) * 2 + lh)) * w_ld + co;
-}
 
 template <int WM, int WN, int MI, int NI, int CK, int XS>
 __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles) {
@@ -67,7 +65,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 
   // problem fields used in the main loop, hoisted into registers (P lives in the kernarg segment; re-reading it costs
   // an s_load + lgkmcnt wait at every use)
-  const int k = P.k, dil = P.dil, cin = P.cin, Lin = P.Lin, w_ld = P.w_ld, nsrc = P.nsrc;
+  const int k = P.k, dil = P.dil, cin = P.cin, Lin = P.Lin, nsrc = P.nsrc;
   const float in_scale = P.in_scale, slope = P.slope;
   const bool lrelu = P.pre_act == PRE_LRELU;
   // per-batch base pointers (wave-uniform -> SGPR pairs); element offsets inside one batch item fit 32 bits
@@ -94,15 +92,17 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   f32x4 wreg[NW4];
   float xr[RPW][XS];
   float xm[XS];
-  const f32x4* wg = reinterpret_cast<const f32x4*>(P.w) + m0;
+  const f32x4* wg = reinterpret_cast<const f32x4*>(P.w);
+  const int mt0 = m0 >> 5;
 
+  // weight tile of step (chunk c, tap j): for each of the BM/32 m-tiles, GR pieces of [lh][32 rows] float4 (1 KB each)
   auto issue_w = [&](int c, int j) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NW4; ++q) {
       const int idx = tid + q * 256;
       if (W4 % 256 == 0 || idx < W4) {
-        const int run = idx / BM, m = idx - run * BM;             // run = gl*2 + lh
-        wreg[q] = wg[((int64_t)((j * groups + c * GR) * 2 + run)) * w_ld + m];
+        const int r = idx & 63, gl = (idx >> 6) % GR, mtl = idx / (64 * GR);           // r = lh*32 + row
+        wreg[q] = wg[((int64_t)((mt0 + mtl) * groups + c * GR + gl) * k + j) * 64 + r];
       }
     }
   };
@@ -110,7 +110,10 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 #pragma unroll
     for (int q = 0; q < NW4; ++q) {
       const int idx = tid + q * 256;
-      if (W4 % 256 == 0 || idx < W4) Ws[buf * W4 + idx] = wreg[q];
+      if (W4 % 256 == 0 || idx < W4) {
+        const int r = idx & 63, gl = (idx >> 6) % GR, mtl = idx / (64 * GR);
+        Ws[buf * W4 + (gl * 2 + (r >> 5)) * BM + mtl * 32 + (r & 31)] = wreg[q];     // LDS: [gl][lh][BM]
+      }
     }
   };
   // X prefetch: branch-free, unconditional loads from CLAMPED addresses (so nothing waits on a load before the MFMAs);
@@ -312,9 +315,9 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const float* const mp = MASK ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
   const float* const wp = P.w;
   const unsigned x_rs4 = 4u * (unsigned)P.x_rstride;
-  const unsigned w_unit = 32u * (unsigned)P.w_ld;                   // bytes between consecutive channel groups
-  const unsigned w_tap = w_unit * (unsigned)groups;                 // bytes between consecutive taps
-  const unsigned w_lane = 16u * (unsigned)(lh * P.w_ld + m0 + l31);
+  const unsigned w_tap = 1024u;                                      // bytes between consecutive taps of one group
+  const unsigned w_unit = w_tap * (unsigned)k;                      // bytes between consecutive channel groups
+  const unsigned w_lane = 16u * (unsigned)(lh * 32 + l31) + (unsigned)mt * (unsigned)groups * w_unit;   // this m-tile's stream
   // channel groups of this (slice z, wave wid): contiguous range, balanced
   const int nsl = L.ksplit * NWV, sl = z * NWV + wid;
   const int g0 = (int)(((int64_t)groups * sl) / nsl), g1 = (int)(((int64_t)groups * (sl + 1)) / nsl);
@@ -455,17 +458,28 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int m
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// waves per workgroup of the split-K kernel: enough K slices that a wave owns ~SK_PD (group, tap) units, i.e. its
-// whole operand stream is in flight after one or two round trips
-static int splitk_waves(const ConvLaunch& L) {
+// Work split of the split-K kernel.  Measured on MI355X (tools/kbench.py, profiles/r01_kbench_*.txt): a wave is fastest
+// with ~16 (group, tap) units of 4 MFMAs; more waves per workgroup than 8 never helps, and when the consumer can sum
+// partial slabs, splitting K ACROSS workgroups (ksplit) beats adding waves.
+constexpr int SK_UNITS_PER_WAVE = 16;
+
+static int splitk_units(const ConvLaunch& L) {
   int units = 0;
   for (int i = 0; i < L.nprob; ++i) {
     const int u = (L.p[i].cin_pad / 8) * L.p[i].k;
     if (u > units) units = u;
   }
-  const int want = (units + SK_PD - 1) / SK_PD;                   // K slices wanted in total (workgroup x cross-workgroup)
-  const int per_wg = (want + L.ksplit - 1) / L.ksplit;
-  return per_wg > 8 ? 16 : (per_wg > 4 ? 8 : 4);
+  return units;
+}
+
+static int splitk_waves(const ConvLaunch& L) {
+  if (const char* e = getenv("BV2_SPLITK_WAVES")) {               // tuning experiments (tools/kbench.py)
+    const int w = atoi(e);
+    if (w == 4 || w == 8 || w == 16) return w;
+  }
+  const int slices = (splitk_units(L) + SK_UNITS_PER_WAVE - 1) / SK_UNITS_PER_WAVE;   // K slices wanted in total
+  const int per_wg = (slices + L.ksplit - 1) / L.ksplit;
+  return per_wg > 4 ? 8 : 4;
 }
 
 template <bool MASK>
@@ -501,20 +515,17 @@ static int launch_splitk(hipStream_t stream, const ConvLaunch& L, int max_cout_p
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// K-split factor ACROSS workgroups for the split-K kernel (only when the consumer sums the slabs): as many slices as it
-// takes for a wave of a 16-wave workgroup to own ~SK_PD units, and at least ~192 workgroups on the chip.
+// K-split factor ACROSS workgroups for the split-K kernel (only when the consumer sums the slabs).
 int conv_pick_ksplit(const ConvLaunch& L, int max_split) {
   if (max_split <= 1) return 1;
-  int groups = 0, mt = 0, units = 0;
+  int groups = 1 << 30;
   for (int i = 0; i < L.nprob; ++i) {
-    if (L.p[i].cin_pad / 8 > groups) groups = L.p[i].cin_pad / 8;
-    if ((L.p[i].cin_pad / 8) * L.p[i].k > units) units = (L.p[i].cin_pad / 8) * L.p[i].k;
-    if (L.p[i].cout_pad / 32 > mt) mt = L.p[i].cout_pad / 32;
+    if (L.p[i].cin_pad / 8 < groups) groups = L.p[i].cin_pad / 8;
     if (L.p[i].act != ACT_NONE) return 1;
   }
-  const long base = (long)L.nprob * L.B * mt * ((L.L + 31) / 32);
+  const int slices = (splitk_units(L) + SK_UNITS_PER_WAVE - 1) / SK_UNITS_PER_WAVE;
   int ks = 1;
-  while (ks < max_split && groups / (ks * 2) >= 4 && (units > 16 * SK_PD * ks || base * ks < 192)) ks *= 2;
+  while (ks < max_split && ks * 4 < slices && groups / (ks * 2 * 4) >= 1) ks *= 2;
   return ks;
 }
 
@@ -551,10 +562,10 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
   }
   if (L.ksplit != 1) return -1;                   // the LDS-tiled kernel never splits K across workgroups
   if (tile == TILE_AUTO) {
-    // largest tile that still yields >= ~2 workgroups per CU (256 CUs): the problems of one launch differ in cost
+    // largest tile that still yields >= ~6 workgroups per CU (256 CUs; measured optimum, profiles/r01_c_*): the problems of one launch differ in cost
     // (k = 3 / 7 / 11 branches), and with two resident workgroups per CU the dispatcher only balances them if there are
     // more workgroups than slots.  BV2_TILE_TARGET overrides (tuning experiments).
-    static const long target = [] { const char* e = getenv("BV2_TILE_TARGET"); return e ? atol(e) : 512L; }();
+    static const long target = [] { const char* e = getenv("BV2_TILE_TARGET"); return e ? atol(e) : 1536L; }();
     tile = TILE_32x128;
     for (const TileCfg& t : kTiles) {
       if (t.bm > max_cout_pad && t.bm != 32) continue;

@@ -221,12 +221,12 @@ def test_layernorm_family(C, T, B):
                                   P(out), B, C, T, 1, 0) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 1e-5
-    # mode 0 fed by 3 partial slabs whose sum is `a`
-    parts = torch.randn(3, B, C, T, generator=g)
-    parts[0] = a - parts[1] - parts[2]
+    # mode 0 fed by 4 partial slabs whose sum is `a`
+    parts = torch.randn(4, B, C, T, generator=g)
+    parts[0] = a - parts[1] - parts[2] - parts[3]
     pd_ = parts.cuda()
     assert lib.bv2_test_layernorm(None, P(pd_), P(t[1]), 0, None, None, 1, None, P(t[2]), P(t[3]), 0, None, P(t[4]), P(t[5]),
-                                  P(out), B, C, T, 3, B * C * T) == 0
+                                  P(out), B, C, T, 4, B * C * T) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 1e-5
     # mode 1: gelu(LN(depthwise k3 dil conv(a*mask))) ; then res + .
