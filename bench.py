@@ -96,6 +96,22 @@ def cpu_baseline(hp, sd, batch, kw, iters, budget_s=45.0):
                        f"{audio_s:.3f} s audio) after 1 warm-up, torch CPU fp32", ms_per_step=round(med * 1e3, 2))
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes of tools/collect_traffic.py (rocprofv3 cannot wrap the timed run
+    itself without perturbing it, so the counters come from separate passes of this same command, committed under
+    profiles/): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE.  None when no such profile exists."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            k = json.load(open(path))["kernels"].get(kernel)
+            if k:
+                return dict(bytes_per_launch=round(k["traffic_bytes"]), fetch_bytes=round(k["fetch_bytes"]),
+                            write_bytes=round(k["write_bytes"]), source=os.path.relpath(path, ROOT))
+        except Exception:
+            continue
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,7 +194,10 @@ def main():
             ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             gen_ms = sum(r["total_ms"] for r in prof) / args.steps
             roof = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                        traffic=(pmc_traffic(dom["name"]) or {}).get("bytes_per_launch"),
+                        traffic_detail=pmc_traffic(dom["name"]),
+                        alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
                         launches_per_step=dom["launches"] / args.steps,
                         avg_launch_us=round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                         flops_per_launch=dom["flops"] / dom["launches"],

@@ -562,19 +562,23 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
   }
   if (L.ksplit != 1) return -1;                   // the LDS-tiled kernel never splits K across workgroups
   if (tile == TILE_AUTO) {
-    // largest tile that still yields >= ~6 workgroups per CU (256 CUs; measured optimum, profiles/r01_c_*): the problems of one launch differ in cost
-    // (k = 3 / 7 / 11 branches), and with two resident workgroups per CU the dispatcher only balances them if there are
-    // more workgroups than slots.  BV2_TILE_TARGET overrides (tuning experiments).
+    // largest tile that still yields >= ~6 workgroups per CU (256 CUs; measured optimum, profiles/r01_c_*): the problems
+    // of one launch differ in cost (k = 3 / 7 / 11 branches) and only 2-3 workgroups are resident per CU, so the
+    // dispatcher balances them only if there are several times more workgroups than slots; per-tile prologue/epilogue
+    // latency is also hidden by the co-resident workgroups.  BV2_TILE_TARGET overrides (tuning experiments).
     static const long target = [] { const char* e = getenv("BV2_TILE_TARGET"); return e ? atol(e) : 1536L; }();
     tile = TILE_32x128;
+    long best_blocks = -1;
+    bool reached = false;
     for (const TileCfg& t : kTiles) {
       if (t.bm > max_cout_pad && t.bm != 32) continue;
       if (max_cout_pad % t.bm && t.bm != 32) continue;
       if (t.bn + max_extra > t.xs * 64) continue;
       const long blocks = (long)((L.L + t.bn - 1) / t.bn) * ((max_cout_pad + t.bm - 1) / t.bm) * L.B * L.nprob;
-      if (blocks >= target) { tile = t.id; break; }
+      if (blocks >= target) { tile = t.id; reached = true; break; }
+      if (blocks > best_blocks) { best_blocks = blocks; tile = t.id; }   // nothing reaches the target: most workgroups, largest first
     }
-    if (tile == TILE_32x128 && max_cout_pad % 64 == 0 && L.L <= 64) tile = TILE_64x64;
+    (void)reached;
   }
   for (const TileCfg& t : kTiles)
     if (t.id == tile && variant_name) *variant_name = t.name;

@@ -182,3 +182,61 @@ def test_full_size_properties_c2():
     nz2 = torch.cat([nz, nz], 0)
     o2, *_ = m.infer(*a(b2), noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, noise_w=nw2, noise_z=nz2.cuda())
     assert rms((o2[0] - o[0]).cpu()) < 2e-5
+
+
+def _dev_args(b):
+    return (b["x"].cuda(), b["x_lengths"].cuda(), b["sid"].cuda(), b["tone"].cuda(), b["language"].cuda(),
+            b["bert"].cuda(), b["ja_bert"].cuda(), b["en_bert"].cuda())
+
+
+def test_large_batch_takes_the_tiled_path_and_matches_batch_1():
+    """BASELINE config 3/4 shape (B=34 x T=128 ragged, pinned durations): B*T and B*T_y exceed the split-K regime, so every
+    encoder / flow convolution runs on the LDS-tiled kernel and the attention / LayerNorm kernels see B > 1.  Utterances are
+    independent (reference commons.py:119-123 masks per utterance), so each must reproduce its own batch-1 synthesis."""
+    from bert_vits2_amd import hparams as H, synth
+    hp = H.default_v23()
+    m = gpu_model(hp, 0, pin_durations=2.5)
+    lens = [128] + [96 + (7 * i) % 33 for i in range(33)]
+    big = synth.synthetic_batch(lens, languages=[i % 3 for i in range(34)], sids=[(11 * i) % hp.n_speakers for i in range(34)])
+    nw, nz = synth.synthetic_noise(34, 128, 400)
+    kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0)
+    o, attn, y_mask, (z, z_p, m_p, logs_p) = m.infer(*_dev_args(big), noise_w=nw, noise_z=nz.cuda(), **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all() and y_mask.shape[2] == 384
+    assert torch.equal(y_mask.sum((1, 2)).cpu(), torch.tensor([3.0 * n for n in lens]))
+    for i in (0, 5, 33):
+        n = lens[i]
+        one = {k: (v[i:i + 1, ..., :n] if v.dim() > 1 else v[i:i + 1]) for k, v in big.items()}
+        one["x_lengths"] = big["x_lengths"][i:i + 1]
+        o1, _, ym1, _ = m.infer(*_dev_args(one), noise_w=nw[i:i + 1, :, :n], noise_z=nz[i:i + 1].cuda(), **kw)
+        # dec is NOT masked (reference models.py:1073 masks z only): inside a longer batch the frames after y_length are
+        # z = 0 rather than zero padding, so the last receptive field (~13 frames) of a ragged utterance legitimately
+        # differs from its stand-alone synthesis — in the reference too (SURVEY.md 7.4-9).  Compare up to a 32-frame margin.
+        S = (3 * n - (0 if n == 128 else 32)) * hp.total_upsample
+        assert ym1.shape[2] == 3 * n
+        assert rms((o[i, 0, :S] - o1[0, 0, :S]).cpu()) < 2e-5, i
+
+
+def test_long_form_c5_properties():
+    """BASELINE config 5 shape: 512 symbols -> T_y = 1536 frames (786 432 samples): 48 key tiles per attention query
+    tile, multi-chunk prefix scan in the length regulator, the largest Generator launch.  Size-independent properties."""
+    from bert_vits2_amd import hparams as H, synth
+    hp = H.default_v23()
+    m = gpu_model(hp, 0, pin_durations=2.5)
+    b = synth.synthetic_batch([512, 300])
+    nw, nz = synth.synthetic_noise(2, 512, 1536 + 8)
+    kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0)
+    o, attn, y_mask, (z, z_p, m_p, logs_p) = m.infer(*_dev_args(b), noise_w=nw, noise_z=nz.cuda(), **kw)
+    torch.cuda.synchronize()
+    assert y_mask.shape[2] == 1536 and o.shape == (2, 1, 1536 * 512)
+    assert torch.equal(attn[0].sum(2), torch.ones(1, 1536, device="cuda"))
+    assert torch.equal(attn[1].sum(2)[0, :900], torch.ones(900, device="cuda")) and attn[1].sum(2)[0, 900:].abs().sum() == 0
+    idx = attn[0, 0].argmax(1)
+    assert (idx[1:] >= idx[:-1]).all() and idx[-1] == 511
+    assert torch.isfinite(o).all() and o.abs().max() <= 1.0 and o[0].std() > 0.01
+    assert z[1, :, 900:].abs().max() == 0                                   # flow output masked beyond y_lengths
+    one = {k: (v[1:2, ..., :300] if v.dim() > 1 else v[1:2]) for k, v in b.items()}
+    one["x_lengths"] = b["x_lengths"][1:2]
+    o1, *_ = m.infer(*_dev_args(one), noise_w=nw[1:2, :, :300], noise_z=nz[1:2].cuda(), **kw)
+    S = (900 - 32) * hp.total_upsample                                      # receptive-field margin, see the B=34 test
+    assert rms((o[1, 0, :S] - o1[0, 0, :S]).cpu()) < 2e-5

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""HBM traffic of the hot path's kernels from rocprofv3 PMC counters (run ON THE GPU BOX).
+
+Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 PMC sections): FETCH_SIZE and WRITE_SIZE are collected in
+SEPARATE passes (FETCH_SIZE takes 3 of the 4 TCC slots), each pass is `rocprofv3 --kernel-trace --pmc <counter>` only (no
+sys/hip/hsa tracing next to --pmc), both counters are reported in KB by rocprofv3, and on gfx950 FETCH_SIZE counts wide
+coalesced reads at half their size, so it is DOUBLED before it is compared with a byte count (WRITE_SIZE is uncalibrated
+and reported as is).  Output: one JSON mapping bench.py kernel-family names to average bytes per launch.
+
+    python tools/collect_traffic.py profiles/r01_traffic.json        # wraps `python bench.py --steps 3 --warmup 1`
+"""
+import collections, csv, glob, json, os, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAMILY = {"<2, 2, 2, 2,": "conv1d_mfma<128x128>", "<2, 2, 1, 2,": "conv1d_mfma<64x128>", "<2, 2, 1, 1,": "conv1d_mfma<64x64>",
+          "<1, 4, 1, 1,": "conv1d_mfma<32x128>", "<1, 4, 1, 2,": "conv1d_mfma<32x256>"}
+
+
+def family(kname):
+    if "conv1d_mfma_kernel" in kname:
+        for k, v in FAMILY.items():
+            if "conv1d_mfma_kernel" + k in kname:
+                return v
+    if "conv1d_splitk_kernel" in kname:
+        return "conv1d_splitk<32x32>"
+    if "resblock_fused_kernel" in kname:
+        return "resblock_fused"
+    if "attention_kernel" in kname:
+        return "attention_relpos"
+    if "layernorm_kernel" in kname:
+        return "layernorm"
+    return None
+
+
+def one_pass(counter, extra_args):
+    d = tempfile.mkdtemp(prefix="bv2pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra_args
+    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
+    tot, n = collections.Counter(), collections.Counter()
+    for cc in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        seen = collections.defaultdict(set)
+        for r in csv.DictReader(open(cc)):
+            if r["Counter_Name"] != counter:
+                continue
+            f = family(r["Kernel_Name"])
+            if f is None:
+                continue
+            tot[f] += float(r["Counter_Value"])
+            seen[f].add(r["Dispatch_Id"])
+        for f, s in seen.items():
+            n[f] += len(s)
+    return {f: (tot[f] / n[f], n[f]) for f in tot if n[f]}
+
+
+def main():
+    out = sys.argv[1]
+    extra = sys.argv[2:]
+    fetch = one_pass("FETCH_SIZE", extra)
+    write = one_pass("WRITE_SIZE", extra)
+    res = {"_method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around `bench.py --steps 3 --warmup 1`; "
+                      "KB -> bytes; FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md); WRITE_SIZE uncalibrated",
+           "kernels": {}}
+    for f in sorted(set(fetch) | set(write)):
+        fk, n = fetch.get(f, (0.0, 0))
+        wk, _ = write.get(f, (0.0, 0))
+        res["kernels"][f] = dict(launches=n, fetch_bytes_raw=fk * 1024, fetch_bytes=2 * fk * 1024, write_bytes=wk * 1024,
+                                 traffic_bytes=2 * fk * 1024 + wk * 1024)
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
