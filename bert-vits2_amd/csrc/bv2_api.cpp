@@ -313,6 +313,32 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
   } catch (...) { return -100; }
 }
 
+int bv2_test_resblock_fused(void* stream, const float* x, float* out, const float* w1_host, const float* b1_host,
+                            const float* w2_host, const float* b2_host, float* wpack_dev, int B, int C, int k, int dil, int L,
+                            float slope) {
+  try {
+    const int cin_pad = t_round_up(C, 16);
+    const size_t one = (size_t)bv2_test_conv_pack_floats(C, C, k), boff = (size_t)k * cin_pad * t_round_up(C, 128);
+    std::vector<float> pk(2 * one, 0.f);
+    const float* ws[2] = {w1_host, w2_host};
+    const float* bs[2] = {b1_host, b2_host};
+    for (int h = 0; h < 2; ++h) {
+      for (int j = 0; j < k; ++j)
+        for (int ci = 0; ci < C; ++ci)
+          for (int co = 0; co < C; ++co)
+            pk[h * one + (size_t)conv_w_index(j, ci, co, cin_pad, k)] = ws[h][((size_t)co * C + ci) * k + j];
+      for (int co = 0; co < C; ++co) pk[h * one + boff + co] = bs[h][co];
+    }
+    if (hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
+    FusedLaunch F;
+    std::memset(&F, 0, sizeof(F));
+    F.nprob = 1; F.B = B; F.C = C; F.L = L; F.slope = slope;
+    F.p[0].x = x; F.p[0].out = out; F.p[0].w1 = wpack_dev; F.p[0].b1 = wpack_dev + boff;
+    F.p[0].w2 = wpack_dev + one; F.p[0].b2 = wpack_dev + one + boff; F.p[0].k = k; F.p[0].dil = dil;
+    return launch_resblock_fused(static_cast<hipStream_t>(stream), F);
+  } catch (...) { return -100; }
+}
+
 int bv2_test_attention(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,
                        int B, int H, int D, int T, int W) {
   AttnArgs a;

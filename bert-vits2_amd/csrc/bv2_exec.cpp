@@ -3,6 +3,7 @@
 // (the one data-dependent size, T_y, is read by the CALLER between run_encode and run_decode — the same single
 // sync the reference has at commons.py:120-122), so each phase is hipGraph-capturable.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "bv2_internal.h"
@@ -499,32 +500,72 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
       const std::string tn = "dec.ups." + std::to_string(i);
       c.tap(tn.c_str(), x, (int64_t)B * U.cout * Lo);
     }
-    // the n_rbk ResBlock1 branches run side by side: 2 launches per dilation step, each carrying all branches
+    // the n_rbk ResBlock1 branches run side by side
     const int nb = m.n_rbk;
-    for (int d = 0; d < m.n_rbd; ++d) {
-      ConvLaunch c1, c2;
-      c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
-      for (int jj = 0; jj < nb; ++jj) {
-        const int j = nb - 1 - jj;                              // widest kernel first: longest workgroups start first
-        float* cur = S[1 + j];
-        float* tmp = S[1 + nb + j];
-        const float* xin = d == 0 ? x : cur;
-        ConvProb p = c.prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
-        p.pre_act = PRE_LRELU; p.slope = 0.1f;
-        c1.p[jj] = p;
-        p = c.prob(m.rb[i][j][d][1], tmp, cur, Lo, 1);
-        p.pre_act = PRE_LRELU; p.slope = 0.1f;
-        p.res = xin; p.res_mode = RES_ADD;
-        c2.p[jj] = p;
+    bool fused = U.cout <= 32 && nb <= 3 && !getenv("BV2_NO_FUSED_RESBLOCK");
+    for (int j = 0; j < nb && fused; ++j)
+      for (int d = 0; d < m.n_rbd; ++d)
+        fused = fused && resblock_fused_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
+    float* branch_out[BV2_MAX_RESBLOCK_KERNELS];
+    if (fused) {
+      // narrow stages: ONE launch per dilation step = the whole (conv, conv) pair of every branch, intermediate in LDS;
+      // the pair ping-pongs between the branch's two buffers (a tile reads its neighbours' halo: no in-place update)
+      for (int j = 0; j < nb; ++j) branch_out[j] = nullptr;
+      for (int d = 0; d < m.n_rbd; ++d) {
+        FusedLaunch F;
+        std::memset(&F, 0, sizeof(F));
+        F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.slope = 0.1f;
+        for (int jj = 0; jj < nb; ++jj) {
+          const int j = nb - 1 - jj;                            // widest kernel first
+          float* a = S[1 + j];
+          float* b2 = S[1 + nb + j];
+          const float* xin = d == 0 ? x : branch_out[j];
+          float* xout = (xin == a) ? b2 : a;
+          FusedProb& p = F.p[jj];
+          p.x = xin; p.out = xout;
+          p.w1 = c.W(m.rb[i][j][d][0].w_off); p.b1 = c.W(m.rb[i][j][d][0].b_off);
+          p.w2 = c.W(m.rb[i][j][d][1].w_off); p.b2 = c.W(m.rb[i][j][d][1].b_off);
+          p.k = m.rb[i][j][d][0].k; p.dil = cf.resblock_dilation_sizes[j][d];
+          branch_out[j] = xout;
+        }
+        if (!c.rc) {
+          const int pi = c.prof_begin("dec.resblock.fused");
+          if (pi >= 0 && c.h->prof_mode == 3)
+            c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
+                          std::to_string(Lo) + " B" + std::to_string(B);
+          const int r = launch_resblock_fused(c.s, F);
+          c.prof_end(pi, "resblock_fused", resblock_fused_flops(F), resblock_fused_bytes(F));
+          if (r) c.fail("dec.resblock.fused", r);
+        }
       }
-      c.conv(c1, "dec.resblock.convs1");
-      c.conv(c2, "dec.resblock.convs2");
+    } else {
+      // wide stages: 2 launches per dilation step, each carrying all branches
+      for (int d = 0; d < m.n_rbd; ++d) {
+        ConvLaunch c1, c2;
+        c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
+        for (int jj = 0; jj < nb; ++jj) {
+          const int j = nb - 1 - jj;                            // widest kernel first: longest workgroups start first
+          float* cur = S[1 + j];
+          float* tmp = S[1 + nb + j];
+          const float* xin = d == 0 ? x : cur;
+          ConvProb p = c.prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
+          p.pre_act = PRE_LRELU; p.slope = 0.1f;
+          c1.p[jj] = p;
+          p = c.prob(m.rb[i][j][d][1], tmp, cur, Lo, 1);
+          p.pre_act = PRE_LRELU; p.slope = 0.1f;
+          p.res = xin; p.res_mode = RES_ADD;
+          c2.p[jj] = p;
+        }
+        c.conv(c1, "dec.resblock.convs1");
+        c.conv(c2, "dec.resblock.convs2");
+      }
+      for (int j = 0; j < nb; ++j) branch_out[j] = S[1 + j];
     }
     for (int j = 0; j < nb; ++j) {
       const std::string tn = "dec.rb." + std::to_string(i) + "." + std::to_string(j);
-      c.tap(tn.c_str(), S[1 + j], (int64_t)B * U.cout * Lo);
+      c.tap(tn.c_str(), branch_out[j], (int64_t)B * U.cout * Lo);
     }
-    for (int j = 0; j < 3; ++j) src[j] = j < nb ? S[1 + j] : nullptr;
+    for (int j = 0; j < 3; ++j) src[j] = j < nb ? branch_out[j] : nullptr;
     nsrc = nb;
     Lc = Lo;
   }

@@ -80,6 +80,21 @@ double conv_flops(const ConvLaunch& L);
 double conv_bytes(const ConvLaunch& L);
 
 // --------------------------------------------------------------------------------------------------------------
+// fused ResBlock1 pair for the narrow Generator stages (kernels/resblock_fused.hip):
+//   out = x + conv2(lrelu(conv1(lrelu(x), k, dil) + b1), k, 1) + b2     on dense [B][C][L] tensors, C <= 32
+struct FusedProb {
+  const float* x; float* out;                     // out must not alias x (tiles read their neighbours' halo)
+  const float* w1; const float* b1;               // packed weights (conv_w_index) / bias of convs1[d]
+  const float* w2; const float* b2;               // ... of convs2[d]
+  int k, dil;
+};
+struct FusedLaunch { FusedProb p[3]; int nprob, B, C, L; float slope; };
+bool resblock_fused_supported(int C, int k, int dil);
+int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F);
+double resblock_fused_flops(const FusedLaunch& F);
+double resblock_fused_bytes(const FusedLaunch& F);
+
+// --------------------------------------------------------------------------------------------------------------
 // conv_post + tanh (kernels/misc.hip): out[b][t] = tanh( sum_{c,j} w[c][j] * lrelu_slope( in_scale*sum_s x_s[b][c][t-pad+j] ) )
 struct ConvPostArgs {
   const float* x[3]; int nsrc; float in_scale; int64_t x_bstride; int x_rstride;

@@ -1,0 +1,189 @@
+// resblock_fused.hip — one (dilated conv, conv) pair of a HiFi-GAN ResBlock1 in ONE kernel, for the narrow stages of the
+// Generator (C <= 32):   out = x + conv2(lrelu(conv1(lrelu(x), dil d) + b1), dil 1) + b2      (reference modules.py:296-309)
+//
+// Why: at C = 32 / 16 the layer-wise convolutions have an arithmetic intensity of 28-56 FLOP/B — they are bound by
+// moving [C, 98k-196k] activations, not by the matrix core.  Keeping the intermediate activation of the
+// pair in LDS removes one full write + read of it (5 tensor passes -> 3: read x, re-read x for the residual, write out),
+// halves the launch count of these stages and doubles the MFMA work per byte.
+//
+// Tile: 224 output columns (7 x 32; 896 B = 7 cache lines, so tiles stay line-aligned).  The intermediate is computed on
+// 256 columns (8 x 32) starting 16 columns early, which covers conv2's halo (k-1)/2 <= 16; x is staged on
+// 256 + (k-1)*d <= 320 columns.  8 waves: in phase 1 wave w owns intermediate columns [32w, 32w+32), in phase 2 waves
+// 0..6 own output columns [32w, 32w+32).  M = 32 rows (the whole channel dim; rows >= C meet zero weights).
+// Operands: A (weights, fragment order, one contiguous 1 KB unit per (group, tap)) streams global -> registers through an
+// 8-deep ring exactly as in the split-K kernel (all 8 waves read the same units: L1 hits); B comes from LDS.
+// Zero padding: x outside [0, L) is staged as 0; the intermediate outside [0, L) is FORCED to 0 (it is conv2's padding,
+// not conv1 applied to padding).
+#include <hip/hip_runtime.h>
+#include "../bv2_kernels.h"
+
+namespace bv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 rf_ld4(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float rf_ld(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+constexpr int RF_BN = 224;        // output columns per tile
+constexpr int RF_TW = 256;        // intermediate columns per tile
+constexpr int RF_LEAD = 16;       // intermediate starts this many columns before the outputs
+constexpr int RF_XS = 5;          // 64-column strips of the staged x tile
+constexpr int RF_XP = RF_XS * 64; // x tile pitch
+constexpr int RF_TP = RF_TW + 4;  // intermediate pitch
+constexpr int RF_PD = 8;          // weight prefetch ring depth
+
+// acc += sum over all (group, tap) units of W_unit x B(unit), B read from the LDS tile `bs` (pitch bp) at column
+// col0 + tap * tstep; weights of unit u live at wp + lane offset + u * 1 KB.
+__device__ __forceinline__ void rf_gemm(f32x16& acc, const float* wp, unsigned w_lane, int groups, int k, const float* bs,
+                                        int bp, int col0, int tstep, int lh) {
+  const int U = groups * k;
+  f32x4 ar[RF_PD];
+  int lu = 0;
+  auto load_unit = [&](int slot) __attribute__((always_inline)) {
+    const int uc = lu < U ? lu : U - 1;                           // past the end: re-read the last unit, result unused
+    ar[slot] = rf_ld4(wp, w_lane + (unsigned)uc * 1024u);
+    ++lu;
+  };
+#pragma unroll
+  for (int i = 0; i < RF_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  int g = 0, j = 0;
+  for (int u0 = 0; u0 < U; u0 += RF_PD) {
+#pragma unroll
+    for (int i = 0; i < RF_PD; ++i) {
+      if (u0 + i < U) {
+        const float* b = bs + (8 * g + lh) * bp + col0 + j * tstep;
+        const float b0 = b[0], b1 = b[2 * bp], b2 = b[4 * bp], b3 = b[6 * bp];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].y, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].z, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].w, b3, acc, 0, 0, 0);
+        if (++j == k) { j = 0; ++g; }
+      }
+      load_unit(i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                               // [C][RF_XP]   lrelu(x), zero outside [0, L)
+  float* Tm = smem + 32 * RF_XP;                  // [C][RF_TP]   lrelu(conv1 + b1), zero outside [0, L)
+  const FusedProb& P = F.p[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * RF_BN;
+  const int C = F.C, L = F.L, k = P.k, dil = P.dil;
+  const int groups = (C + 7) / 8;
+  const int h1 = ((k - 1) / 2) * dil, h2 = (k - 1) / 2;
+  const float slope = F.slope;
+  const float* xp = P.x + (int64_t)b * C * L;
+  const unsigned w_lane = 16u * (unsigned)(lh * 32 + l31);
+
+  // ---- stage lrelu(x) for columns [t0 - LEAD - h1, t0 - LEAD - h1 + TW + 2*h1): wave w owns rows 4w..4w+3
+  {
+    const int tb = t0 - RF_LEAD - h1;
+    const int XW = RF_TW + 2 * h1;
+    float xr[4][RF_XS];
+    unsigned tc[RF_XS];
+    bool ok[RF_XS];
+#pragma unroll
+    for (int s = 0; s < RF_XS; ++s) {
+      const int t = tb + lane + 64 * s;
+      ok[s] = (lane + 64 * s < XW) && t >= 0 && t < L;
+      tc[s] = 4u * (unsigned)(t < 0 ? 0 : (t >= L ? L - 1 : t));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = wid * 4 + r;
+      row = row < C ? row : C - 1;
+#pragma unroll
+      for (int s = 0; s < RF_XS; ++s) xr[r][s] = rf_ld(xp, (unsigned)row * 4u * (unsigned)L + tc[s]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int s = 0; s < RF_XS; ++s) {
+        float v = xr[r][s];
+        v = v < 0.f ? v * slope : v;
+        Xs[(wid * 4 + r) * RF_XP + lane + 64 * s] = (ok[s] && wid * 4 + r < C) ? v : 0.f;
+      }
+  }
+  __syncthreads();
+
+  // ---- phase 1: intermediate columns [32*wid, 32*wid + 32)
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    rf_gemm(acc, P.w1, w_lane, groups, k, Xs, RF_XP, 32 * wid + l31, dil, lh);
+    const int t = t0 - RF_LEAD + 32 * wid + l31;
+    const bool tin = t >= 0 && t < L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < C) {
+        float v = acc[r] + P.b1[row];
+        v = v < 0.f ? v * slope : v;
+        Tm[row * RF_TP + 32 * wid + l31] = tin ? v : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: output columns [32*wid, 32*wid + 32) of the tile, waves 0..6
+  if (wid < RF_BN / 32) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    rf_gemm(acc, P.w2, w_lane, groups, k, Tm, RF_TP, RF_LEAD + 32 * wid + l31 - h2, 1, lh);
+    const int t = t0 + 32 * wid + l31;
+    if (t < L) {
+      float* op = P.out + (int64_t)b * C * L;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < C) op[(int64_t)row * L + t] = acc[r] + P.b2[row] + xp[(int64_t)row * L + t];
+      }
+    }
+  }
+}
+
+bool resblock_fused_supported(int C, int k, int dil) {
+  return C >= 8 && C <= 32 && C % 8 == 0 && k % 2 == 1 && (k - 1) / 2 <= RF_LEAD && RF_TW + (k - 1) * dil <= RF_XP &&
+         RF_LEAD + RF_BN + (k - 1) / 2 <= RF_TW;
+}
+
+int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F) {
+  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1) return -1;
+  for (int i = 0; i < F.nprob; ++i)
+    if (!resblock_fused_supported(F.C, F.p[i].k, F.p[i].dil)) return -2;
+  if ((int64_t)F.C * F.L >= (1ll << 29)) return -2;              // 32-bit byte offsets inside one batch item
+  dim3 grid((F.L + RF_BN - 1) / RF_BN, F.B, F.nprob);
+  const size_t lds = sizeof(float) * (size_t)(32 * RF_XP + 32 * RF_TP);
+  auto kern = resblock_fused_kernel;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, F);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+double resblock_fused_flops(const FusedLaunch& F) {
+  double f = 0;
+  for (int i = 0; i < F.nprob; ++i) f += 2.0 * (2.0 * F.C * F.C * F.p[i].k) * (double)F.L * F.B;
+  return f;
+}
+
+double resblock_fused_bytes(const FusedLaunch& F) {   // x read once (+ once more for the residual), out written once
+  double by = 0;
+  for (int i = 0; i < F.nprob; ++i) by += 4.0 * (3.0 * F.C * (double)F.L * F.B + 2.0 * F.C * F.C * F.p[i].k);
+  return by;
+}
+
+}  // namespace bv2

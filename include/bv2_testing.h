@@ -23,6 +23,12 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
                     int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale, int ksplit,
                     int64_t slab_stride);
 
+/* fused ResBlock1 pair (kernels/resblock_fused.hip): out = x + conv2(lrelu(conv1(lrelu(x), k, dil) + b1), k, 1) + b2 on
+ * [B][C][L]; w*_host [C][C][k], b*_host [C] are HOST pointers; wpack_dev needs 2 * bv2_test_conv_pack_floats(C, C, k) floats */
+int bv2_test_resblock_fused(void* stream, const float* x, float* out, const float* w1_host, const float* b1_host,
+                            const float* w2_host, const float* b2_host, float* wpack_dev, int B, int C, int k, int dil, int L,
+                            float slope);
+
 /* windowed relative-position attention; qkv [B][3*H*D + H*(2W+1)][ld] (q rows pre-divided by sqrt(D); the last H*(2W+1)
  * rows are the relative-key logits q_i·Ek[r]/sqrt(D)), ld % 32 == 0, mask [B][T], erv [2W+1][D], out [B][H*D][T] (all DEVICE) */
 int bv2_test_attention(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,

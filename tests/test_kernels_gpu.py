@@ -21,6 +21,8 @@ def _lib():
     lib.bv2_test_conv1d.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                     C.c_int, C.c_int64])
+    lib.bv2_test_resblock_fused.restype = C.c_int
+    lib.bv2_test_resblock_fused.argtypes = [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_float]
     lib.bv2_test_attention.restype = C.c_int
     lib.bv2_test_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5
     lib.bv2_test_layernorm.restype = C.c_int
@@ -145,6 +147,28 @@ def test_conv1d_mfma_fused_epilogues(tile):
         assert rc == 0
         torch.cuda.synchronize()
         assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,Cc,k,dil,L", [(1, 32, 11, 5, 1000), (2, 16, 11, 5, 700), (1, 32, 3, 1, 224), (2, 32, 7, 3, 449),
+                                           (1, 16, 3, 3, 100), (1, 32, 11, 1, 5000), (1, 8, 5, 2, 300)])
+def test_resblock_fused_pair(B, Cc, k, dil, L):
+    """out = x + conv2(lrelu(conv1(lrelu(x), dil)), 1): tile seams (L not a multiple of 224), both zero paddings,
+    C = 16 (half-empty MFMA rows), C = 8."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(Cc * 100 + k * 10 + dil)
+    x = torch.randn(B, Cc, L, generator=g)
+    w1 = torch.randn(Cc, Cc, k, generator=g) / math.sqrt(Cc * k)
+    w2 = torch.randn(Cc, Cc, k, generator=g) / math.sqrt(Cc * k)
+    b1, b2 = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    xd = x.double()
+    t = F.conv1d(F.leaky_relu(xd, 0.1), w1.double(), b1.double(), padding=(k - 1) // 2 * dil, dilation=dil)
+    ref = xd + F.conv1d(F.leaky_relu(t, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)
+    xg = x.cuda()
+    out = torch.full((B, Cc, L), float("nan"), device="cuda")
+    wp = torch.empty(2 * lib.bv2_test_conv_pack_floats(Cc, Cc, k), device="cuda")
+    assert lib.bv2_test_resblock_fused(None, P(xg), P(out), P(w1), P(b1), P(w2), P(b2), P(wp), B, Cc, k, dil, L, 0.1) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 2e-5
 
 
 def _ref_attention(qkv, mask, erk, erv, H, W):
