@@ -127,6 +127,26 @@ int bv2_attach_weights(bv2_handle* h, const void* dev_blob, int64_t bytes) {
   BV2_CATCH(h)
 }
 
+int bv2_set_generator_dtype(bv2_handle* h, int dtype) {
+  if (!h) return -1;
+  if (dtype != BV2_F32 && dtype != BV2_BF16) { h->err = "bv2_set_generator_dtype: BV2_F32 or BV2_BF16"; return -1; }
+  if (dtype == BV2_BF16) {
+    const Model& m = h->model;
+    bool ok = m.conv_pre.wb_off >= 0 && m.post_c % 8 == 0 && m.post_c <= 64;
+    for (int i = 0; i < m.n_ups && ok; ++i) {
+      ok = m.ups[i].cl.wb_off >= 0 && conv_cl_bf16_supported(m.ups[i].cl.cin, m.ups[i].cl.cout, m.ups[i].cl.k, 1);
+      for (int j = 0; j < m.n_rbk && ok; ++j)
+        for (int d = 0; d < m.n_rbd && ok; ++d)
+          ok = m.rb[i][j][d][0].wb_off >= 0 &&
+               conv_cl_bf16_supported(m.rb[i][j][d][0].cin, m.rb[i][j][d][0].cout, m.rb[i][j][d][0].k,
+                                      m.cfg.resblock_dilation_sizes[j][d]);
+    }
+    if (!ok) { h->err = "bv2_set_generator_dtype: this Generator configuration has no bf16 kernel (channels must be multiples of 16, tile must fit LDS)"; return -2; }
+  }
+  h->gen_dtype = dtype;
+  return 0;
+}
+
 int64_t bv2_workspace_bytes(const bv2_handle* h, int B, int T, int Ty_max) {
   if (!h || B < 1 || T < 1 || Ty_max < 1) return -1;
   return workspace_bytes(h->model, B, T, Ty_max);
@@ -336,6 +356,85 @@ int bv2_test_resblock_fused(void* stream, const float* x, float* out, const floa
     F.p[0].x = x; F.p[0].out = out; F.p[0].w1 = wpack_dev; F.p[0].b1 = wpack_dev + boff;
     F.p[0].w2 = wpack_dev + one; F.p[0].b2 = wpack_dev + one + boff; F.p[0].k = k; F.p[0].dil = dil;
     return launch_resblock_fused(static_cast<hipStream_t>(stream), F);
+  } catch (...) { return -100; }
+}
+
+static inline uint16_t t_f2bf(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+int64_t bv2_test_conv_cl_pack_bytes(int cin, int cout, int k) {
+  return cl_w_elems(cin, t_round_up(cout, 32), k) * 2 + (int64_t)t_round_up(cout, 32) * 4;
+}
+
+int bv2_test_conv_cl_bf16(void* stream, const void* x0, const void* x1, const void* x2, int nsrc, const float* w_host,
+                          const float* bias_host, void* wpack_dev, void* out, const void* res, const float* bias2, int B, int cin,
+                          int cout, int k, int dil, int pad_left, int L, int pre_lrelu, float slope) {
+  try {
+    if (!conv_cl_bf16_supported(cin, cout, k, dil)) return -2;
+    const int cout_pad = t_round_up(cout, 32);
+    const int64_t ne = cl_w_elems(cin, cout_pad, k);
+    if (w_host) {
+      std::vector<uint16_t> pk((size_t)ne, 0);
+      for (int j = 0; j < k; ++j)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co)
+            pk[(size_t)cl_w_index(j, ci, co, cin, k)] = t_f2bf(w_host[((size_t)co * cin + ci) * k + j]);
+      std::vector<float> bb((size_t)cout_pad, 0.f);
+      if (bias_host) for (int co = 0; co < cout; ++co) bb[(size_t)co] = bias_host[co];
+      if (hipMemcpy(wpack_dev, pk.data(), (size_t)ne * 2, hipMemcpyHostToDevice) != hipSuccess) return -6;
+      if (hipMemcpy(static_cast<char*>(wpack_dev) + ne * 2, bb.data(), (size_t)cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    }
+    ClLaunch cl;
+    std::memset(&cl, 0, sizeof(cl));
+    ClProb& p = cl.p[0];
+    p.x[0] = static_cast<const uint16_t*>(x0); p.x[1] = static_cast<const uint16_t*>(x1); p.x[2] = static_cast<const uint16_t*>(x2);
+    p.nsrc = nsrc; p.in_scale = 1.f / (float)nsrc; p.x_bstride = (int64_t)cin * L; p.Lin = L;
+    p.w = static_cast<const uint16_t*>(wpack_dev);
+    p.bias = bias_host ? reinterpret_cast<const float*>(static_cast<char*>(wpack_dev) + ne * 2) : nullptr;
+    p.bias2 = bias2; p.bias2_bstride = cout;
+    p.out = static_cast<uint16_t*>(out); p.out_bstride = (int64_t)cout * L;
+    p.res = static_cast<const uint16_t*>(res); p.res_bstride = p.out_bstride;
+    p.cin = cin; p.cout = cout; p.cout_pad = cout_pad; p.k = k; p.dil = dil;
+    p.pad_left = pad_left < 0 ? ((k - 1) / 2) * dil : pad_left;
+    p.pre_lrelu = pre_lrelu; p.slope = slope;
+    cl.nprob = 1; cl.B = B; cl.L = L;
+    return launch_conv_cl_bf16(static_cast<hipStream_t>(stream), cl, nullptr);
+  } catch (...) { return -100; }
+}
+
+int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i, int j, int d, int e, int32_t* dims,
+                          float* w_out, float* bias_out) {
+  if (!h || !host_blob || !dims) return -1;
+  try {
+    const Model& m = h->model;
+    const ConvW* w = nullptr;
+    int pad_left = 0;
+    if (kind == 0) { w = &m.conv_pre; pad_left = (w->k - 1) / 2; }
+    else if (kind == 1 && i >= 0 && i < m.n_ups) { w = &m.ups[i].cl; pad_left = m.ups[i].cl_pad_left; }
+    else if (kind == 2 && i >= 0 && i < m.n_ups && j >= 0 && j < m.n_rbk && d >= 0 && d < m.n_rbd && (e == 0 || e == 1)) {
+      w = &m.rb[i][j][d][e];
+      pad_left = ((w->k - 1) / 2) * (e == 0 ? m.cfg.resblock_dilation_sizes[j][d] : 1);
+    }
+    if (!w || w->wb_off < 0) return -2;
+    dims[0] = w->cin; dims[1] = w->cout; dims[2] = w->k; dims[3] = pad_left;
+    const float* blob = static_cast<const float*>(host_blob);
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(blob + w->wb_off);
+    if (w_out)
+      for (int co = 0; co < w->cout; ++co)
+        for (int ci = 0; ci < w->cin; ++ci)
+          for (int jj = 0; jj < w->k; ++jj) {
+            const uint32_t u = (uint32_t)wb[cl_w_index(jj, ci, co, w->cin, w->k)] << 16;
+            float f;
+            std::memcpy(&f, &u, 4);
+            w_out[((size_t)co * w->cin + ci) * w->k + jj] = f;
+          }
+    if (bias_out)
+      for (int co = 0; co < w->cout; ++co) bias_out[co] = w->b_off >= 0 ? blob[w->b_off + co] : 0.f;
+    return 0;
   } catch (...) { return -100; }
 }
 

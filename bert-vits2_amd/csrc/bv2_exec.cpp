@@ -578,6 +578,116 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
   c.chk(launch_conv_post(c.s, a), "dec.conv_post");
 }
 
+// Generator.forward in bf16, channels-last (kernels/gen_bf16.hip).  Same launch structure as the wide-stage fp32 path: per
+// stage one ConvTranspose launch (a single conv with C_out' = u*C_out) and per dilation step two launches carrying the
+// n_rbk branches; every tensor between launches is bf16 [B][L][C].  Rounding points (mirrored by oracle/bv2_oracle.py
+// generator_bf16): weights, (z*mask), every stored activation, and the pre-activated conv inputs are rounded to bf16
+// (RNE); accumulation, bias, residual and the branch mean are fp32; conv_post + tanh are fp32 on bf16 inputs.
+static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride, const float* ymask, int B, int L, float* o) {
+  const Model& m = c.m;
+  const bv2_config& cf = m.cfg;
+  const int C = cf.inter_channels, c0 = cf.upsample_initial_channel;
+  auto U16 = [](float* p) { return reinterpret_cast<uint16_t*>(p); };
+  auto Wb = [&](const ConvW& w) { return reinterpret_cast<const uint16_t*>(c.W(w.wb_off)); };
+  auto prob = [&](const ConvW& w, const uint16_t* x, uint16_t* out, int Lc, int dil) {
+    ClProb p;
+    std::memset(&p, 0, sizeof(p));
+    p.x[0] = x; p.nsrc = 1; p.in_scale = 1.f; p.x_bstride = (int64_t)w.cin * Lc; p.Lin = Lc;
+    p.w = Wb(w); p.bias = c.W(w.b_off);
+    p.out = out; p.out_bstride = (int64_t)w.cout * Lc; p.res_bstride = p.out_bstride;
+    p.cin = w.cin; p.cout = w.cout; p.cout_pad = w.cout_pad; p.k = w.k; p.dil = dil; p.pad_left = ((w.k - 1) / 2) * dil;
+    p.slope = 0.1f;
+    return p;
+  };
+  auto launch = [&](ClLaunch& cl, const char* tag, double flops) {
+    if (c.rc) return;
+    const char* vn = "conv_cl_bf16";
+    const int pi = c.prof_begin(tag);
+    if (pi >= 0 && c.h->prof_mode == 3) {
+      const ClProb& q = cl.p[0];
+      c.cur_shape = " n" + std::to_string(cl.nprob) + " " + std::to_string(q.cin) + ">" + std::to_string(q.cout) + " k" +
+                    std::to_string(q.k) + " L" + std::to_string(cl.L) + " B" + std::to_string(cl.B);
+    }
+    const int r = launch_conv_cl_bf16(c.s, cl, &vn);
+    c.prof_end(pi, vn, flops, conv_cl_bytes(cl));
+    if (r) c.fail(tag, r);
+  };
+  auto flops_of = [&](const ClLaunch& cl) {
+    double f = 0;
+    for (int i = 0; i < cl.nprob; ++i) f += 2.0 * cl.p[i].cout * cl.p[i].cin * cl.p[i].k * (double)cl.L * cl.B;
+    return f;
+  };
+
+  // debug taps (tests): widen a bf16 channels-last tensor into the caller's fp32 [B][C][L] tap buffer
+  auto tap_cl = [&](const std::string& name, const uint16_t* x, int Cc, int Lc) {
+    if (c.h->taps.empty() || c.rc) return;
+    auto it = c.h->taps.find(name);
+    if (it == c.h->taps.end() || it->second.cap < (int64_t)B * Cc * Lc) return;
+    c.chk(launch_uncast_cl(c.s, x, it->second.dst, B, Cc, Lc), "tap");
+  };
+
+  uint16_t* zc = U16(P.set[1][0]);                // dead before stage 1 writes set[1][0]
+  c.chk(launch_cast_cl(c.s, z, z_rstride, (int64_t)C * z_rstride, ymask, z_rstride, zc, B, C, L), "dec.cast");
+  uint16_t* pre = U16(P.pre);
+  {
+    ClLaunch cl;
+    cl.nprob = 1; cl.B = B; cl.L = L;
+    cl.p[0] = prob(m.conv_pre, zc, pre, L, 1);
+    cl.p[0].bias2 = P.gv; cl.p[0].bias2_bstride = P.gv_stride;
+    launch(cl, "dec.conv_pre", flops_of(cl));
+  }
+  tap_cl("dec.pre", pre, c0, L);
+  const uint16_t* src[3] = {pre, nullptr, nullptr};
+  int nsrc = 1, Lc = L;
+  for (int i = 0; i < m.n_ups; ++i) {
+    const UpW& U = m.ups[i];
+    float* const* S = P.set[i & 1];
+    uint16_t* x = U16(S[0]);
+    const int Lo = Lc * U.u;
+    {
+      ClLaunch cl;
+      cl.nprob = 1; cl.B = B; cl.L = Lc;
+      ClProb p = prob(U.cl, src[0], x, Lc, 1);
+      p.x[1] = src[1]; p.x[2] = src[2]; p.nsrc = nsrc; p.in_scale = 1.f / (float)nsrc;
+      p.pre_lrelu = 1; p.pad_left = U.cl_pad_left;
+      cl.p[0] = p;
+      // algorithmic FLOPs: the true taps of the transposed conv (the zero-padded window taps are not counted)
+      launch(cl, "dec.ups", 2.0 * U.cin * U.cout * U.k * (double)Lc * B);
+    }
+    tap_cl("dec.ups." + std::to_string(i), x, U.cout, Lo);
+    const int nb = m.n_rbk;
+    for (int d = 0; d < m.n_rbd; ++d) {
+      ClLaunch c1, c2;
+      c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
+      for (int jj = 0; jj < nb; ++jj) {
+        const int j = nb - 1 - jj;                              // widest kernel first
+        uint16_t* cur = U16(S[1 + j]);
+        uint16_t* tmp = U16(S[1 + nb + j]);
+        const uint16_t* xin = d == 0 ? x : cur;
+        ClProb p = prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
+        p.pre_lrelu = 1;
+        c1.p[jj] = p;
+        p = prob(m.rb[i][j][d][1], tmp, cur, Lo, 1);
+        p.pre_lrelu = 1; p.res = xin;
+        c2.p[jj] = p;
+      }
+      launch(c1, "dec.resblock.convs1", flops_of(c1));
+      launch(c2, "dec.resblock.convs2", flops_of(c2));
+    }
+    for (int j = 0; j < 3; ++j) src[j] = j < nb ? U16(S[1 + j]) : nullptr;
+    for (int j = 0; j < nb; ++j) tap_cl("dec.rb." + std::to_string(i) + "." + std::to_string(j), src[j], U.cout, Lo);
+    nsrc = nb;
+    Lc = Lo;
+  }
+  ConvPostClArgs a;
+  std::memset(&a, 0, sizeof(a));
+  for (int j = 0; j < 3; ++j) a.x[j] = src[j];
+  a.nsrc = nsrc; a.in_scale = 1.f / (float)nsrc;
+  a.w = c.W(m.conv_post.off); a.out = o; a.C = m.post_c; a.k = m.post_k; a.L = Lc; a.B = B;
+  a.slope = 0.01f;                                            // F.leaky_relu default (models.py:553)
+  c.chk(launch_conv_post_cl(c.s, a), "dec.conv_post");
+}
+
 static void phase_b_gemv(Ctx& c, const PlanB& P, const float* g, int B) {
   const Model& m = c.m;
   const bv2_config& cf = m.cfg;
@@ -622,7 +732,8 @@ int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_
   phase_b_gemv(c, P, in.g, B);
   flow_core(c, P, z, ymask, in.g, B, Ty);
   const int L = (in.max_len > 0 && in.max_len < Ty) ? in.max_len : Ty;
-  gen_core(c, P, z, Ty, ymask, B, L, out.o);
+  if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, out.o);
+  else gen_core(c, P, z, Ty, ymask, B, L, out.o);
   return c.rc;
 }
 
@@ -653,7 +764,8 @@ int run_generator(bv2_handle* h, hipStream_t s, int B, int Ty, int L, const floa
   float* ymask = P.ymask;
   c.chk(launch_seq_mask(s, y_lengths, ymask, B, Ty), "y_mask");
   phase_b_gemv(c, P, g, B);
-  gen_core(c, P, z, Ty, ymask, B, L, o);
+  if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, o);
+  else gen_core(c, P, z, Ty, ymask, B, L, o);
   return c.rc;
 }
 

@@ -30,6 +30,7 @@ constexpr int kBlobHeaderFloats = 64;
 struct ConvW {
   int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, w_ld = 0, k = 1;
   int64_t w_off = -1, b_off = -1;    // b_off < 0: no bias
+  int64_t wb_off = -1;               // Generator convs only: bf16 fragment stream (cl_w_index), offset in floats
 };
 struct VecW { int64_t off = -1; int64_t n = 0; };
 struct GemvW { int cout = 0, cin = 0; int64_t w_off = -1, b_off = -1; };
@@ -60,6 +61,10 @@ struct UpW {
   int u = 1, k = 1, cin = 0, cout = 0, ntaps = 1;
   ConvW phase[BV2_MAX_UPS];          // one conv problem per output phase (polyphase ConvTranspose1d)
   int pad_left[BV2_MAX_UPS];
+  // channels-last form (bf16 path): ONE conv cin -> u*cout over the union of the phases' tap windows (zero weights where
+  // a phase does not use a tap); row t of its output is rows t*u .. t*u+u-1 of the upsampled tensor
+  ConvW cl;
+  int cl_pad_left = 0;
 };
 
 struct Model {
@@ -109,6 +114,7 @@ struct bv2_handle {
   const float* blob = nullptr;       // device
   std::string err;
   std::map<std::string, bv2::Tap> taps;
+  int gen_dtype = BV2_F32;           // Generator arithmetic: BV2_F32 (conv_mfma.hip) or BV2_BF16 (gen_bf16.hip)
   // profiling
   bool prof_on = false;
   int prof_mode = 1;                 // 1: every MFMA kernel launch, 2: Generator (dec.*) launches only

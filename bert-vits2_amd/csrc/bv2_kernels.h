@@ -95,6 +95,61 @@ double resblock_fused_flops(const FusedLaunch& F);
 double resblock_fused_bytes(const FusedLaunch& F);
 
 // --------------------------------------------------------------------------------------------------------------
+// bf16 Generator (kernels/gen_bf16.hip): channels-last activations [B][L][C] (C contiguous, bf16), bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16) with fp32 accumulation, fp32 bias / residual arithmetic, one bf16 rounding per stored tensor.
+//
+//   out[b][t][co] = bf16( bias[co] + bias2[b][co] + res[b][t][co]
+//                         + sum_{ci<cin, j<k} W[co][ci][j] * pre( in_scale * sum_s x_s[b][t - pad_left + j*dil][ci] ) )
+//   pre(v) = bf16( lrelu_slope(v) )   (identity when nsrc == 1 and pre_lrelu == 0)
+//
+// GEMM view: M = C_out (A operand = weights), N = time (B operand = activations from an LDS tile), K = (channel group, tap).
+// Packed weight stream ("fragment order", bf16): [m-tile = co/32][unit u = (ci/16)*k + j][lane l][e < 8]
+//   = W[co = mt*32 + (l&31)][ci = 16*(u/k) + 8*(l>>5) + e][tap u%k]        (1 KB per unit, one 16-byte load per lane)
+// A ConvTranspose1d (stride u) is ONE such conv with C_out' = u*C_out: in channels-last memory the u output rows of input
+// step t are contiguous, so out'[t][ph*C_out + co] IS out[t*u + ph][co]  (cl_w_index / bv2_model.cpp pack_up_cl).
+struct ClProb {
+  const uint16_t* x[3];     // sources [B][Lin][cin] bf16 (summed); x[1], x[2] may be null
+  int nsrc; float in_scale;
+  int64_t x_bstride;        // elements between batches
+  int Lin;
+  const uint16_t* w;        // packed bf16 fragments
+  const float* bias;        // [cout_pad] fp32 or null
+  const float* bias2;       // [B][bias2_bstride] fp32 per-batch bias or null
+  int bias2_bstride;
+  uint16_t* out;            // [B][L][cout]
+  int64_t out_bstride;
+  const uint16_t* res;      // residual [B][L][cout] or null (may alias out: each element is read then written by one lane)
+  int64_t res_bstride;
+  int cin, cout, cout_pad, k, dil, pad_left;
+  int pre_lrelu; float slope;
+};
+struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; };
+int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** variant_name);
+bool conv_cl_bf16_supported(int cin, int cout, int k, int dil);
+// element index (bf16 units) of weight (tap j, input channel ci, output channel co) in the packed stream
+inline int64_t cl_w_index(int j, int ci, int co, int cin, int k) {
+  const int64_t U = (int64_t)(cin / 16) * k, u = (int64_t)(ci / 16) * k + j;
+  const int lane = (co & 31) + 32 * ((ci % 16) / 8);
+  return (((int64_t)(co >> 5) * U + u) * 64 + lane) * 8 + (ci % 8);
+}
+inline int64_t cl_w_elems(int cin, int cout_pad, int k) { return (int64_t)(cout_pad / 32) * (cin / 16) * k * 512; }
+double conv_cl_bytes(const ClLaunch& L);
+
+// z[b][c][t] * mask[b][t] (fp32, channel stride z_rstride) -> bf16 channels-last out[b][t][c], t < L
+int launch_cast_cl(hipStream_t stream, const float* z, int z_rstride, int64_t z_bstride, const float* mask, int mask_bstride,
+                   uint16_t* out, int B, int C, int L);
+// debug taps: bf16 channels-last [B][L][C] -> fp32 [B][C][L]
+int launch_uncast_cl(hipStream_t stream, const uint16_t* x, float* out, int B, int C, int L);
+// conv_post + tanh on channels-last bf16 branches: out[b][t] = tanh( sum_{c,j} w[c][j] * lrelu(in_scale*sum_s x_s[b][t-pad+j][c]) )
+struct ConvPostClArgs {
+  const uint16_t* x[3]; int nsrc; float in_scale;
+  const float* w;           // [C][k] fp32
+  float* out;               // [B][L] fp32
+  int C, k, L, B; float slope;
+};
+int launch_conv_post_cl(hipStream_t stream, const ConvPostClArgs& a);
+
+// --------------------------------------------------------------------------------------------------------------
 // conv_post + tanh (kernels/misc.hip): out[b][t] = tanh( sum_{c,j} w[c][j] * lrelu_slope( in_scale*sum_s x_s[b][c][t-pad+j] ) )
 struct ConvPostArgs {
   const float* x[3]; int nsrc; float in_scale; int64_t x_bstride; int x_rstride;

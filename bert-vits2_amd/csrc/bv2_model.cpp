@@ -24,6 +24,15 @@ namespace bv2 {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// fp32 -> bf16, round to nearest even (what torch's .to(torch.bfloat16) and v_cvt_pk_bf16_f32 do)
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
 namespace {
 
 struct Packer {
@@ -31,6 +40,7 @@ struct Packer {
   float* blob = nullptr;
   int64_t cursor = kBlobHeaderFloats;
   std::vector<std::string> missing;
+  bool emit_bf16 = false;                                  // also write the channels-last bf16 fragment stream (dec.*)
 
   bool fill() const { return blob != nullptr; }
 
@@ -100,6 +110,7 @@ struct Packer {
     c.cin_pad = round_up(cin, 16); c.cout_pad = round_up(cout, 32); c.w_ld = round_up(cout, 128);
     c.w_off = alloc((int64_t)k * c.cin_pad * c.w_ld);
     c.b_off = bias ? alloc(c.cout_pad) : -1;
+    if (emit_bf16 && cin % 16 == 0) c.wb_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (fill() && ok) {
       for (int j = 0; j < k; ++j)
         for (int ci = 0; ci < cin; ++ci)
@@ -107,6 +118,30 @@ struct Packer {
             blob[c.w_off + conv_w_index(j, ci, co, c.cin_pad, k)] = src(co, ci, j);
       if (bias)
         for (int co = 0; co < cout; ++co) blob[c.b_off + co] = bsrc(co);
+      if (c.wb_off >= 0) {
+        uint16_t* wb = reinterpret_cast<uint16_t*>(blob + c.wb_off);
+        for (int j = 0; j < k; ++j)
+          for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) wb[cl_w_index(j, ci, co, cin, k)] = f2bf(src(co, ci, j));
+      }
+    }
+    return c;
+  }
+
+  // bf16-only conv (no fp32 copy): weights as a channels-last fragment stream + fp32 bias
+  ConvW conv_cl(int cout, int cin, int k, const std::function<float(int, int, int)>& src,
+                const std::function<float(int)>& bsrc, bool ok) {
+    ConvW c;
+    c.cin = cin; c.cout = cout; c.k = k;
+    c.cin_pad = cin; c.cout_pad = round_up(cout, 32); c.w_ld = c.cout_pad;
+    c.b_off = alloc(c.cout_pad);
+    c.wb_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
+    if (fill() && ok) {
+      uint16_t* wb = reinterpret_cast<uint16_t*>(blob + c.wb_off);
+      for (int j = 0; j < k; ++j)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) wb[cl_w_index(j, ci, co, cin, k)] = f2bf(src(co, ci, j));
+      for (int co = 0; co < cout; ++co) blob[c.b_off + co] = bsrc(co);
     }
     return c;
   }
@@ -292,6 +327,7 @@ int pack_all(Model& m, Packer& P) {
 
   // ---- dec (reference models.py:490-564)
   const int c0 = c.upsample_initial_channel;
+  P.emit_bf16 = true;
   m.conv_pre = P.conv1d("dec.conv_pre", c0, inter, 7);
   m.dec_cond = P.gemv("dec.cond", c0, gin, true);
   m.n_ups = c.n_upsamples; m.n_rbk = c.n_resblock_kernels; m.n_rbd = c.n_resblock_dilations;
@@ -307,6 +343,7 @@ int pack_all(Model& m, Packer& P) {
     std::vector<float> w;                          // folded ConvTranspose1d weight [cin][cout][k]
     const bool ok = P.folded("dec.ups." + std::to_string(i), U.cin, U.cout, U.k, w);
     const HostTensor* bt = P.get("dec.ups." + std::to_string(i) + ".bias", {U.cout});
+    P.emit_bf16 = false;                           // the bf16 path uses the single channels-last form below, not the phases
     for (int ph = 0; ph < U.u; ++ph) {
       // output n = u*s + ph gathers x[s + shift - mtap] * W[ci][co][pp + u*mtap]   
       const int pp = (ph + pad) % U.u, shift = (ph + pad) / U.u;
@@ -318,6 +355,28 @@ int pack_all(Model& m, Packer& P) {
                            },
                            [&](int co) { return bt->data[co]; }, ok && bt);
     }
+    P.emit_bf16 = true;
+    {
+      // channels-last form: tap window = union over phases; phase ph uses window taps [off, off + ntaps), off = plmax - pad_left[ph]
+      int plmax = 0, right = 0;
+      for (int ph = 0; ph < U.u; ++ph) {
+        plmax = U.pad_left[ph] > plmax ? U.pad_left[ph] : plmax;
+        const int r = U.ntaps - 1 - U.pad_left[ph];
+        right = r > right ? r : right;
+      }
+      const int kk = plmax + right + 1, nt = U.ntaps, uu = U.u, kfull = U.k, cout = U.cout, pad_ = pad;
+      U.cl_pad_left = plmax;
+      const int* pl = U.pad_left;
+      U.cl = P.conv_cl(U.u * U.cout, U.cin, kk,
+                       [&, plmax, nt, uu, kfull, cout, pad_, pl](int cop, int ci, int jw) -> float {
+                         const int ph = cop / cout, co = cop % cout;
+                         const int j = jw - (plmax - pl[ph]);
+                         if (j < 0 || j >= nt) return 0.f;
+                         const int pp = (ph + pad_) % uu;
+                         return w[((int64_t)ci * cout + co) * kfull + pp + uu * (nt - 1 - j)];
+                       },
+                       [&, cout](int cop) { return bt->data[cop % cout]; }, ok && bt);
+    }
     ch = U.cout;
     for (int j = 0; j < m.n_rbk; ++j) {
       const int k = c.resblock_kernel_sizes[j];
@@ -328,6 +387,7 @@ int pack_all(Model& m, Packer& P) {
       }
     }
   }
+  P.emit_bf16 = false;
   m.post_c = ch;
   m.conv_post = P.vec("dec.conv_post.weight", {1, ch, m.post_k});
   m.total_floats = P.cursor;

@@ -1,0 +1,342 @@
+// gen_bf16.hip — the HiFi-GAN Generator (reference models.py:538-557, modules.py:296-309) in bf16 on the gfx950 matrix core
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate), activations CHANNELS-LAST [B][L][C] so that
+//   * a tile of consecutive time steps is one contiguous HBM range: staging loads are 16 B per lane, fully coalesced;
+//   * the MFMA B operand (8 consecutive input channels of one time step) is ONE ds_read_b128 from the LDS tile, and the
+//     k taps / dilations of a conv are row shifts of the same tile (read once from HBM, used k times);
+//   * a ConvTranspose1d is an ordinary conv with C_out' = stride*C_out (its u output rows per input step are contiguous);
+//   * the D fragment (lane = time step, 4 consecutive output channels per register group) stores as 8-byte pieces of a row.
+// BASELINE config 3 ("bf16 weights/activations, fp32 accumulate") for the 90 % of the path's FLOPs that live in the
+// Generator; in bf16 its layer-wise arithmetic intensity (117-940 FLOP/B by stage) straddles the machine balance
+// (2.5 PF / 6.3 TB/s = 400 FLOP/B): wide stages are MFMA-bound, narrow stages HBM-bound.
+//
+// conv_cl_bf16_kernel<WN, WM>: workgroup = WN x WM waves; wave (wn, wm) owns output channels [32*(cg*WN+wn), +32) and
+// time steps [t0 + 128*wm, +128) (4 accumulator tiles of 32x32).  Prologue: the whole input tile — (WM*128 + (k-1)*dil)
+// rows x C_in channels — goes HBM -> registers -> (mean of branches, leaky-ReLU, bf16 round) -> LDS, row pitch C_in + 8
+// elements (= odd multiple of 16 B: conflict-free ds_read_b128 for 16 consecutive rows).  Main loop, NO barriers: the
+// wave streams its weight fragments global -> registers through an 8-deep ring (1 KB units, L2-resident, contiguous per
+// 32-channel output tile) and reads B fragments from LDS one unit ahead of the MFMAs.
+#include <hip/hip_runtime.h>
+#include "../bv2_kernels.h"
+
+namespace bv2 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned bf_pack(float a, float b) {     // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  bf16x2 r;
+  r[0] = (__bf16)a; r[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+
+constexpr int CL_PD = 8;          // weight prefetch ring depth (units of 4 MFMAs)
+constexpr int CL_NI = 4;          // 32-column time tiles per wave
+constexpr int CL_WT = CL_NI * 32; // time steps per wave
+
+// Stage rows [tb, tb + rows) x cin channels of up to 3 sources into LDS (pitch in elements), applying
+// pre(v) = bf16(lrelu(in_scale * sum)).  Rows outside [0, Lin) are zero (the conv's padding).
+template <int NT>
+__device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const uint16_t* s0, const uint16_t* s1,
+                                         const uint16_t* s2, int nsrc, float in_scale, bool lrelu, float slope, int tb,
+                                         int rows, int cin, int Lin, int tid) {
+  const int ppr = cin >> 3;                       // 16-byte pieces per row
+  const int total = rows * ppr;
+  const bool raw = nsrc == 1 && !lrelu;
+  for (int base = 0; base < total; base += 4 * NT) {
+    u32x4 v[4][3];
+    int dst[4];
+    bool ok[4], inb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int p = base + q * NT + tid;
+      inb[q] = p < total;
+      p = inb[q] ? p : total - 1;
+      const int r = p / ppr, cb = p - r * ppr;
+      const int t = tb + r;
+      ok[q] = inb[q] && t >= 0 && t < Lin;
+      const int tc = t < 0 ? 0 : (t >= Lin ? Lin - 1 : t);           // clamped: the loads are unconditional
+      const int64_t off = (int64_t)tc * cin + cb * 8;
+      dst[q] = r * pitch + cb * 8;
+      v[q][0] = *reinterpret_cast<const u32x4*>(s0 + off);
+      if (nsrc > 1) v[q][1] = *reinterpret_cast<const u32x4*>(s1 + off);
+      if (nsrc > 2) v[q][2] = *reinterpret_cast<const u32x4*>(s2 + off);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!inb[q]) continue;
+      u32x4 o;
+      if (raw) {
+        o = v[q][0];
+      } else {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float a = bf_lo(v[q][0][w]), b = bf_hi(v[q][0][w]);
+          if (nsrc > 1) { a += bf_lo(v[q][1][w]); b += bf_hi(v[q][1][w]); }
+          if (nsrc > 2) { a += bf_lo(v[q][2][w]); b += bf_hi(v[q][2][w]); }
+          if (nsrc > 1) { a *= in_scale; b *= in_scale; }
+          if (lrelu) { a = a < 0.f ? a * slope : a; b = b < 0.f ? b * slope : b; }
+          o[w] = bf_pack(a, b);
+        }
+      }
+      if (!ok[q]) o = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(xs + dst[q]) = o;
+    }
+  }
+}
+
+// acc[ni] += sum over units u = (s, j) of Wfrag(u) x B(u, ni);  B(u, ni) = 8 channels [16s + 8lh, +8) of LDS row
+// (ni*32 + l31 + j*tstep) relative to xb.  wp points at this wave's contiguous weight stream (+ lane*8 elements).
+__device__ __forceinline__ void cl_gemm(f32x16 (&acc)[CL_NI], const uint16_t* wp, int U, int k, const unsigned short* xb,
+                                        int pitch, int tstep) {
+  bf16x8 ar[CL_PD];
+  int lu = 0;
+  auto load_unit = [&](int slot) __attribute__((always_inline)) {
+    const int uc = lu < U ? lu : U - 1;                             // past the end: re-read the last unit, result unused
+    ar[slot] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)uc * 512);
+    ++lu;
+  };
+#pragma unroll
+  for (int i = 0; i < CL_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  bf16x8 bb[2][CL_NI];                            // B fragments of the current / next unit (parity of the ring slot)
+#pragma unroll
+  for (int ni = 0; ni < CL_NI; ++ni) bb[0][ni] = *reinterpret_cast<const bf16x8*>(xb + ni * 32 * pitch);
+  int s = 0, j = 0;
+  for (int u0 = 0; u0 < U; u0 += CL_PD) {
+#pragma unroll
+    for (int i = 0; i < CL_PD; ++i) {
+      if (u0 + i < U) {
+        int jn = j + 1, sn = s;
+        if (jn == k) { jn = 0; ++sn; }
+        const bool more = u0 + i + 1 < U;
+        const unsigned short* xn = xb + (more ? jn : j) * tstep * pitch + (more ? sn : s) * 16;
+#pragma unroll
+        for (int ni = 0; ni < CL_NI; ++ni) bb[(i & 1) ^ 1][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * pitch);
+#pragma unroll
+        for (int ni = 0; ni < CL_NI; ++ni)
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], bb[i & 1][ni], acc[ni], 0, 0, 0);
+        j = jn; s = sn;
+      }
+      load_unit(i);
+      __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay CL_PD - 1 units
+    }
+  }
+}
+
+template <int WN, int WM>
+__global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
+  constexpr int NT = 64 * WN * WM;
+  constexpr int BT = WM * CL_WT;
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
+  const ClProb& P = L.p[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wid % WN, wm = wid / WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y / ngrp;
+  const int cg = blockIdx.y - b * ngrp;
+  const int mt = cg * WN + wn;
+  const int t0 = blockIdx.x * BT;
+  const int cin = P.cin, k = P.k, dil = P.dil;
+  if (cg * WN * 32 >= P.cout_pad) return;         // whole workgroup beyond this problem's channels (uniform: before the barrier)
+  const int pitch = cin + 8;
+  cl_stage<NT>(xs, pitch, P.x[0] + (int64_t)b * P.x_bstride, P.x[1] ? P.x[1] + (int64_t)b * P.x_bstride : nullptr,
+               P.x[2] ? P.x[2] + (int64_t)b * P.x_bstride : nullptr, P.nsrc, P.in_scale, P.pre_lrelu != 0, P.slope,
+               t0 - P.pad_left, BT + (k - 1) * dil, cin, P.Lin, tid);
+  __syncthreads();
+  if (mt * 32 >= P.cout_pad) return;              // no further barriers below
+
+  f32x16 acc[CL_NI];
+#pragma unroll
+  for (int ni = 0; ni < CL_NI; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+  const int U = (cin >> 4) * k;
+  cl_gemm(acc, P.w + (int64_t)mt * U * 512 + lane * 8, U, k, xs + (wm * CL_WT + l31) * pitch + lh * 8, pitch, dil);
+
+  // epilogue: lane = time step, register group g = 4 consecutive output channels
+  const int cout = P.cout;
+#pragma unroll
+  for (int ni = 0; ni < CL_NI; ++ni) {
+    const int t = t0 + wm * CL_WT + ni * 32 + l31;
+    if (t >= L.L) continue;
+    const int64_t row = (int64_t)t * cout;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = mt * 32 + 8 * g + 4 * lh;
+      if (co >= cout) continue;
+      float v0 = acc[ni][4 * g], v1 = acc[ni][4 * g + 1], v2 = acc[ni][4 * g + 2], v3 = acc[ni][4 * g + 3];
+      if (P.bias) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + co);
+        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+      }
+      if (P.bias2) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias2 + (int64_t)b * P.bias2_bstride + co);
+        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+      }
+      if (P.res) {
+        const u32x2 rr = *reinterpret_cast<const u32x2*>(P.res + (int64_t)b * P.res_bstride + row + co);
+        v0 += bf_lo(rr.x); v1 += bf_hi(rr.x); v2 += bf_lo(rr.y); v3 += bf_hi(rr.y);
+      }
+      u32x2 o;
+      o.x = bf_pack(v0, v1); o.y = bf_pack(v2, v3);
+      *reinterpret_cast<u32x2*>(P.out + (int64_t)b * P.out_bstride + row + co) = o;
+    }
+  }
+}
+
+bool conv_cl_bf16_supported(int cin, int cout, int k, int dil) {
+  if (cin < 16 || cin % 16 || cout < 4 || cout % 4 || k < 1 || dil < 1) return false;
+  // narrowest workgroup tile (128 time steps) must fit the 160 KB LDS
+  return (int64_t)(CL_WT + (k - 1) * dil) * (cin + 8) * 2 <= 160 * 1024;
+}
+
+template <int WN, int WM>
+static int launch_cl_variant(hipStream_t stream, const ClLaunch& L, int nt, size_t lds_rows_extra, int cin) {
+  constexpr int BT = WM * CL_WT;
+  const size_t lds = (size_t)(BT + lds_rows_extra) * (size_t)(cin + 8) * 2;
+  if (lds > 160 * 1024) return -2;
+  const int ngrp = (nt + WN - 1) / WN;
+  dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
+  auto kern = conv_cl_bf16_kernel<WN, WM>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WN * WM), lds, stream, L, ngrp);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** variant_name) {
+  if (L.nprob < 1 || L.nprob > BV2_MAX_PROBS || L.B < 1 || L.L < 1) return -1;
+  int nt = 0, extra = 0;
+  const int cin = L.p[0].cin;
+  for (int i = 0; i < L.nprob; ++i) {
+    const ClProb& p = L.p[i];
+    if (p.cin != cin || !conv_cl_bf16_supported(p.cin, p.cout, p.k, p.dil) || p.cout_pad % 32 || p.cout_pad < p.cout) return -1;
+    if (p.cout_pad / 32 > nt) nt = p.cout_pad / 32;
+    if ((p.k - 1) * p.dil > extra) extra = (p.k - 1) * p.dil;
+  }
+  int r;
+  if (nt >= 8) {
+    if (variant_name) *variant_name = "conv_cl_bf16<8x1>";
+    r = launch_cl_variant<8, 1>(stream, L, nt, extra, cin);
+  } else if (nt >= 3) {
+    if (variant_name) *variant_name = "conv_cl_bf16<4x1>";
+    r = launch_cl_variant<4, 1>(stream, L, nt, extra, cin);
+  } else if (nt == 2) {
+    if (variant_name) *variant_name = "conv_cl_bf16<2x2>";
+    r = launch_cl_variant<2, 2>(stream, L, nt, extra, cin);
+    if (r == -2) r = launch_cl_variant<4, 1>(stream, L, nt, extra, cin);
+  } else {
+    if (variant_name) *variant_name = "conv_cl_bf16<1x4>";
+    r = launch_cl_variant<1, 4>(stream, L, nt, extra, cin);
+    if (r == -2) r = launch_cl_variant<4, 1>(stream, L, nt, extra, cin);
+  }
+  return r;
+}
+
+double conv_cl_bytes(const ClLaunch& L) {   // each input read once, each output written once (+ residual read), weights once
+  double by = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    const ClProb& p = L.p[i];
+    by += 2.0 * ((double)p.cin * p.nsrc * L.L * L.B + (double)p.cout * L.L * L.B * (p.res ? 2 : 1) +
+                 (double)p.cout * p.cin * p.k);
+  }
+  return by;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (z * y_mask)[:, :, :L] fp32 [B][C][Ty] -> bf16 channels-last [B][L][C]   (the input of dec.conv_pre, models.py:1073)
+__global__ void __launch_bounds__(256) cast_cl_kernel(const float* z, int z_rstride, int64_t z_bstride, const float* mask,
+                                                      int mask_bstride, uint16_t* out, int C, int L) {
+  const int b = blockIdx.z, c8 = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= L) return;
+  const float m = mask ? mask[(int64_t)b * mask_bstride + t] : 1.f;
+  const float* src = z + (int64_t)b * z_bstride + (int64_t)(c8 * 8) * z_rstride + t;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = src[(int64_t)e * z_rstride] * m;
+  u32x4 o;
+  o.x = bf_pack(v[0], v[1]); o.y = bf_pack(v[2], v[3]); o.z = bf_pack(v[4], v[5]); o.w = bf_pack(v[6], v[7]);
+  *reinterpret_cast<u32x4*>(out + ((int64_t)b * L + t) * C + c8 * 8) = o;
+}
+
+int launch_cast_cl(hipStream_t stream, const float* z, int z_rstride, int64_t z_bstride, const float* mask, int mask_bstride,
+                   uint16_t* out, int B, int C, int L) {
+  if (C % 8 || B < 1 || L < 1) return -1;
+  dim3 grid((L + 255) / 256, C / 8, B);
+  hipLaunchKernelGGL(cast_cl_kernel, grid, dim3(256), 0, stream, z, z_rstride, z_bstride, mask, mask_bstride, out, C, L);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// debug taps: bf16 channels-last [B][L][C] -> fp32 [B][C][L]
+__global__ void __launch_bounds__(256) uncast_cl_kernel(const uint16_t* x, float* out, int C, int L) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= L) return;
+  out[((int64_t)b * C + c) * L + t] = __uint_as_float((unsigned)x[((int64_t)b * L + t) * C + c] << 16);
+}
+
+int launch_uncast_cl(hipStream_t stream, const uint16_t* x, float* out, int B, int C, int L) {
+  dim3 grid((L + 255) / 256, C, B);
+  hipLaunchKernelGGL(uncast_cl_kernel, grid, dim3(256), 0, stream, x, out, C, L);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv_post + tanh (reference models.py:553-555: leaky_relu default slope 0.01, Conv1d(C, 1, 7, bias=False), tanh) on the
+// mean of the last stage's branches; fp32 arithmetic on bf16 inputs, fp32 waveform out.
+constexpr int CP_TS = 256;
+__global__ void __launch_bounds__(CP_TS) conv_post_cl_kernel(const ConvPostClArgs A) {
+  extern __shared__ float cps[];                  // [C*k] weights, then [(CP_TS + k - 1)][C + 1] activations
+  const int C = A.C, k = A.k, pad = (k - 1) / 2;
+  float* ws = cps;
+  float* ms = cps + C * k;
+  const int mp = C + 1;
+  const int b = blockIdx.y, t0 = blockIdx.x * CP_TS, tid = threadIdx.x;
+  for (int i = tid; i < C * k; i += CP_TS) ws[i] = A.w[i];
+  const int rows = CP_TS + k - 1, ppr = C >> 3;
+  for (int p = tid; p < rows * ppr; p += CP_TS) {
+    const int r = p / ppr, cb = p - r * ppr;
+    const int t = t0 - pad + r;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (t >= 0 && t < A.L) {
+      const int64_t off = ((int64_t)b * A.L + t) * C + cb * 8;
+      for (int s = 0; s < A.nsrc; ++s) {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(A.x[s] + off);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { v[2 * w] += bf_lo(u[w]); v[2 * w + 1] += bf_hi(u[w]); }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = v[e] * A.in_scale;
+        v[e] = a < 0.f ? a * A.slope : a;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ms[r * mp + cb * 8 + e] = v[e];
+  }
+  __syncthreads();
+  const int t = t0 + tid;
+  if (t >= A.L) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c)
+    for (int j = 0; j < k; ++j) acc += ws[c * k + j] * ms[(tid + j) * mp + c];
+  A.out[(int64_t)b * A.L + t] = tanhf(acc);
+}
+
+int launch_conv_post_cl(hipStream_t stream, const ConvPostClArgs& a) {
+  if (a.C % 8 || a.C > 64 || a.k < 1 || a.k > 15 || a.nsrc < 1 || a.nsrc > 3) return -1;
+  dim3 grid((a.L + CP_TS - 1) / CP_TS, a.B);
+  const size_t lds = sizeof(float) * ((size_t)a.C * a.k + (size_t)(CP_TS + a.k - 1) * (a.C + 1));
+  hipLaunchKernelGGL(conv_post_cl_kernel, grid, dim3(CP_TS), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace bv2

@@ -70,6 +70,7 @@ class SynthesizerTrn(nn.Module):
         self._blob: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._taps: Dict[str, torch.Tensor] = {}
+        self.generator_dtype = torch.float32
 
     # ------------------------------------------------------------------ parameter tree
     def _register(self, key: str, value: torch.Tensor) -> None:
@@ -156,6 +157,17 @@ class SynthesizerTrn(nn.Module):
                                "there is no CPU fallback")
         with torch.cuda.device(dev):
             self.attach_blob(self.pack_host_blob().to(dev))
+
+    def set_generator_dtype(self, dtype) -> None:
+        """Arithmetic of the Generator (``dec``): ``torch.float32`` (default, exact fp32 MFMA) or ``torch.bfloat16``
+        (bf16 weights + channels-last bf16 activations, fp32 accumulate — BASELINE config 3; the reference's counterpart
+        is running ``dec`` under ``torch.autocast(bfloat16)``).  Encoder, durations and flow stay fp32 either way."""
+        lib = self._ensure_handle()
+        code = {torch.float32: L.F32, "fp32": L.F32, "f32": L.F32, torch.bfloat16: L.BF16, "bf16": L.BF16}.get(dtype)
+        if code is None:
+            raise ValueError("generator dtype must be torch.float32 or torch.bfloat16")
+        self._check(lib.bv2_set_generator_dtype(self._handle, code), "bv2_set_generator_dtype")
+        self.generator_dtype = torch.bfloat16 if code == L.BF16 else torch.float32
 
     def _workspace(self, B: int, T: int, Ty: int) -> torch.Tensor:
         n = self._lib.bv2_workspace_bytes(self._handle, B, T, Ty)

@@ -80,6 +80,14 @@ int bv2_pack_weights(bv2_handle* h, void* host_blob, int64_t bytes);
  * to the other GPUs with RCCL).  Verifies the blob header against this handle's config. */
 int bv2_attach_weights(bv2_handle* h, const void* dev_blob, int64_t bytes);
 
+/* ---- precision (BASELINE config 3: "bf16 weights/activations, fp32 accumulate") ------------------------------- */
+/* Arithmetic of the HiFi-GAN Generator (dec, reference models.py:538-557 — 90 % of the path's FLOPs): BV2_F32 (default;
+ * v_mfma_f32_32x32x2_f32, exact fp32) or BV2_BF16 (v_mfma_f32_32x32x16_bf16: bf16 weights and channels-last bf16
+ * activations, fp32 accumulation / bias / residual, fp32 conv_post + tanh).  The reference's counterpart is running dec
+ * under torch.autocast(bfloat16).  Text encoder, duration predictors, length regulation and flow stay fp32 in both modes
+ * (durations stay bit-stable).  The packed blob always carries both weight forms, so this is a per-call switch. */
+int bv2_set_generator_dtype(bv2_handle* h, int dtype);
+
 /* ---- workspace ------------------------------------------------------------------------------------------- */
 /* Bytes of caller-provided DEVICE scratch needed by any stage call with batch B, T symbols, Ty_max frames. */
 int64_t bv2_workspace_bytes(const bv2_handle* h, int B, int T, int Ty_max);

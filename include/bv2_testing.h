@@ -5,6 +5,7 @@
 #ifndef BV2_TESTING_H
 #define BV2_TESTING_H
 #include <stdint.h>
+#include "bv2.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -28,6 +29,21 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
 int bv2_test_resblock_fused(void* stream, const float* x, float* out, const float* w1_host, const float* b1_host,
                             const float* w2_host, const float* b2_host, float* wpack_dev, int B, int C, int k, int dil, int L,
                             float slope);
+
+/* channels-last bf16 conv (kernels/gen_bf16.hip): x* / out / res are DEVICE bf16 [B][L][C] tensors, w_host [cout][cin][k]
+ * and bias_host [cout] HOST fp32 (rounded to bf16 / kept fp32 by the packer); wpack_dev needs
+ * bv2_test_conv_cl_pack_bytes(cin, cout, k) bytes; the nsrc sources are averaged; pad_left < 0 means "same" padding */
+int64_t bv2_test_conv_cl_pack_bytes(int cin, int cout, int k);
+int bv2_test_conv_cl_bf16(void* stream, const void* x0, const void* x1, const void* x2, int nsrc, const float* w_host,
+                          const float* bias_host, void* wpack_dev, void* out, const void* res, const float* bias2, int B, int cin,
+                          int cout, int k, int dil, int pad_left, int L, int pre_lrelu, float slope);
+
+/* Decode one Generator conv of a packed HOST blob back to dense form (checks the bf16 packer on a CPU-only box):
+ * kind 0 = dec.conv_pre, 1 = dec.ups[i] in its channels-last single-conv form (C_out' = u*C_out), 2 = resblock conv
+ * rb[i][j][d][e].  dims = {cin, cout, k, pad_left}; w_out [cout][cin][k] (bf16 values widened to fp32) and bias_out [cout]
+ * may be NULL to query dims only.  Returns 0, or a negative status. */
+int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i, int j, int d, int e, int32_t* dims,
+                          float* w_out, float* bias_out);
 
 /* windowed relative-position attention; qkv [B][3*H*D + H*(2W+1)][ld] (q rows pre-divided by sqrt(D); the last H*(2W+1)
  * rows are the relative-key logits q_i·Ek[r]/sqrt(D)), ld % 32 == 0, mask [B][T], erv [2W+1][D], out [B][H*D][T] (all DEVICE) */

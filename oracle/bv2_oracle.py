@@ -350,12 +350,57 @@ def generator(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
 
 
 # --------------------------------------------------------------------------------------------
+# Generator with bf16 storage / fp32 accumulation (BASELINE config 3).  The reference's counterpart is running `dec`
+# under torch.autocast(bfloat16); this restatement pins the rounding points of the bf16 product path so parity can be
+# held tightly: weights, (z*mask) and every stored activation are rounded to bf16 (round-to-nearest-even), each conv
+# input is bf16(leaky_relu(.)) (for the upsampling convs: bf16(leaky_relu(mean of the branches)), mean = fp32 sum of the
+# bf16 branch outputs times fp32(1/n)), accumulation + bias + residual are fp32, conv_post/tanh are fp32 on bf16 inputs.
+
+def _bf(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def resblock1_bf16(sd, p, x, k, dilations, fold_cache=None):
+    for m, d in enumerate(dilations):
+        xt = _bf(F.leaky_relu(x, LRELU_SLOPE))
+        xt = _bf(F.conv1d(xt, _bf(_fw(sd, f"{p}.convs1.{m}", fold_cache)), sd[f"{p}.convs1.{m}.bias"],
+                          padding=(k * d - d) // 2, dilation=d))
+        xt = _bf(F.leaky_relu(xt, LRELU_SLOPE))
+        x = _bf(F.conv1d(xt, _bf(_fw(sd, f"{p}.convs2.{m}", fold_cache)), sd[f"{p}.convs2.{m}.bias"],
+                         padding=(k - 1) // 2) + x)
+    return x
+
+
+def generator_bf16(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
+    x = _bf(F.conv1d(_bf(z), _bf(sd["dec.conv_pre.weight"]), sd["dec.conv_pre.bias"], padding=3) + conv1x1(sd, "dec.cond", g))
+    nk = len(hp.resblock_kernel_sizes)
+    inv = torch.tensor(1.0 / nk, dtype=torch.float32)
+    for i, (u, k) in enumerate(zip(hp.upsample_rates, hp.upsample_kernel_sizes)):
+        x = _bf(F.leaky_relu(x, LRELU_SLOPE))
+        x = _bf(F.conv_transpose1d(x, _bf(_fw(sd, f"dec.ups.{i}", fold_cache)), sd[f"dec.ups.{i}.bias"],
+                                   stride=u, padding=(k - u) // 2))
+        if taps is not None:
+            taps[f"dec.ups.{i}"] = x
+        xs = None
+        for j in range(nk):
+            r = resblock1_bf16(sd, f"dec.resblocks.{i * nk + j}", x, hp.resblock_kernel_sizes[j],
+                               hp.resblock_dilation_sizes[j], fold_cache)
+            xs = r if xs is None else xs + r
+        x = xs * inv if nk > 1 else xs
+        if taps is not None:
+            taps[f"dec.stage.{i}"] = x
+    x = F.leaky_relu(x)                                                 # default slope 0.01 (models.py:553), fp32
+    x = F.conv1d(x, sd["dec.conv_post.weight"], None, padding=3)
+    return torch.tanh(x)
+
+
+# --------------------------------------------------------------------------------------------
 # the whole path
 
 @torch.no_grad()
 def infer(sd, hp, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, *, noise_w, noise_z,
           noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8, max_len=None, sdp_ratio=0.0,
-          w_ceil_override=None, fold_cache=None, want_taps=False):
+          w_ceil_override=None, fold_cache=None, want_taps=False, generator_dtype="fp32"):
     """reference models.py:1026-1074 with both RNG draws made explicit inputs:
     noise_w [B,2,T] replaces models.py:248-251, noise_z [B,C,>=T_y] replaces randn_like at :1071.
     Returns a dict with the reference's return values plus intermediate taps."""
@@ -373,7 +418,8 @@ def infer(sd, hp, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, *, 
     z_p = m_e + noise_z[:, :, :Ty] * torch.exp(logs_e) * noise_scale
     z = flow_reverse(sd, hp, z_p, y_mask, g, fold_cache)
     taps = {} if want_taps else None
-    o = generator(sd, hp, (z * y_mask)[:, :, :max_len], g, fold_cache, taps)
+    gen = generator_bf16 if generator_dtype == "bf16" else generator
+    o = gen(sd, hp, (z * y_mask)[:, :, :max_len], g, fold_cache, taps)
     out = dict(o=o, attn=attn, y_mask=y_mask, z=z, z_p=z_p, m_p=m_e, logs_p=logs_e,
                enc_x=h, enc_m=m_p, enc_logs=logs_p, x_mask=x_mask, logw=logw, logw_sdp=logw_sdp, logw_dp=logw_dp,
                w_ceil=w_ceil, y_lengths=y_lengths, g=g)
