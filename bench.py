@@ -28,6 +28,10 @@ if ROOT not in sys.path:
 from bert_vits2_amd import hparams as H, models, sharding, synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix = fp32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA
+PEAK_HBM_GBPS = 8000.0             # same guide: HBM3E
+CONFIGS = {2: dict(batch=1, symbols=128, dtype="f32"), 3: dict(batch=32, symbols=128, dtype="bf16"),
+           5: dict(batch=8, symbols=512, dtype="f32")}
 GEN_FLOP_PER_FRAME = 651.6e6       # Generator algorithmic FLOPs per latent frame
 
 
@@ -36,8 +40,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (config 2: 1)")
-    ap.add_argument("--symbols", type=int, default=128)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
+                    help="BASELINE.json config: 2 = B=1 T=128 fp32 (the metric's config, default), 3 = B=32 T=128 bf16 Generator, "
+                         "5 = long-form B=8 T=512")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (overrides the config's)")
+    ap.add_argument("--symbols", type=int, default=None, help="symbols per utterance (overrides the config's)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="Generator arithmetic (overrides the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel family")
@@ -128,7 +136,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)     # RCCL
 
     hp = H.default_v23()
-    B, T = args.batch, args.symbols
+    cfgd = CONFIGS[args.config]
+    B = args.batch if args.batch is not None else cfgd["batch"]
+    T = args.symbols if args.symbols is not None else cfgd["symbols"]
+    gen_dtype = args.dtype or cfgd["dtype"]
     kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
 
     # ---- weights: rank 0 folds/packs the seeded synthetic checkpoint, every other rank receives the blob over RCCL
@@ -140,6 +151,8 @@ def main():
     log(f"rank {rank}/{world}: packing / distributing weights")
     t_bcast = sharding.distribute_weights(model, dev, src=0)
     log("weights attached")
+    if gen_dtype == "bf16":
+        model.set_generator_dtype(torch.bfloat16)
 
     # ---- this rank's utterances (weak scaling: same per-GPU work, different utterances)
     batch = synth.synthetic_batch([T] * B, first_index=rank * B)
@@ -191,10 +204,17 @@ def main():
         roof = None
         if prof:
             dom = max(prof, key=lambda r: r["total_ms"])
-            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             gen_ms = sum(r["total_ms"] for r in prof) / args.steps
-            roof = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            # the roof that binds the dominant kernel: its layer-wise arithmetic intensity against the machine balance
+            peak_tf = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["name"] else PEAK_FP32_MFMA_TFLOPS
+            ai = dom["flops"] / max(dom["bytes"], 1.0)
+            secs = dom["total_ms"] * 1e-3
+            if ai >= peak_tf * 1e12 / (PEAK_HBM_GBPS * 1e9):
+                ach, peak, unit, bound = dom["flops"] / secs / 1e12, peak_tf, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = dom["bytes"] / secs / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
+            roof = dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit,
+                        frac=round(ach / peak, 4), arithmetic_intensity_flop_per_byte=round(ai, 1),
                         traffic=(pmc_traffic(dom["name"]) or {}).get("bytes_per_launch"),
                         traffic_detail=pmc_traffic(dom["name"]),
                         alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
@@ -228,8 +248,9 @@ def main():
             metric="audio-seconds/sec (44.1 kHz), SynthesizerTrn.infer(), 128-phoneme utterance", value=round(value, 2),
             unit="audio-seconds/sec", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="f32", data="synthetic",
-            config=dict(workload=f"BASELINE config 2: B={B} x T={T} symbols per GPU, fp32, T_y={Ty} frames "
+            dtype=gen_dtype, data="synthetic",
+            config=dict(workload=f"BASELINE config {args.config}: B={B} x T={T} symbols per GPU, "
+                                 f"{'bf16 Generator (fp32 accumulate; encoder/durations/flow fp32)' if gen_dtype == 'bf16' else 'fp32'}, T_y={Ty} frames "
                                  f"({Ty * hp.total_upsample} samples, {Ty * hp.total_upsample / hp.sampling_rate:.3f} s) per utterance, "
                                  f"transformer flow, synthetic seeded weights, durations pinned to 3 frames/symbol",
                         utterances_per_gpu=B, symbols=T, frames=Ty, parallelism=f"utterance-sharded x{world}",

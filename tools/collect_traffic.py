@@ -23,6 +23,10 @@ def family(kname):
                 return v
     if "conv1d_splitk_kernel" in kname:
         return "conv1d_splitk<32x32>"
+    if "conv_cl_bf16_kernel" in kname:
+        for k, v in {"<8, 1>": "conv_cl_bf16<8x1>", "<4, 1>": "conv_cl_bf16<4x1>", "<2, 2>": "conv_cl_bf16<2x2>", "<1, 4>": "conv_cl_bf16<1x4>"}.items():
+            if "conv_cl_bf16_kernel" + k in kname:
+                return v
     if "resblock_fused_kernel" in kname:
         return "resblock_fused"
     if "attention_kernel" in kname:
