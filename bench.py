@@ -30,8 +30,8 @@ from bert_vits2_amd import hparams as H, models, sharding, synth  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix = fp32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA
 PEAK_HBM_GBPS = 8000.0             # same guide: HBM3E
-CONFIGS = {2: dict(batch=1, symbols=128, dtype="f32"), 3: dict(batch=32, symbols=128, dtype="bf16"),
-           5: dict(batch=8, symbols=512, dtype="f32")}
+CONFIGS = {2: dict(batch=1, symbols=128, dtype="f32", flow="f32"), 3: dict(batch=32, symbols=128, dtype="bf16", flow="f16"),
+           5: dict(batch=8, symbols=512, dtype="bf16", flow="f16")}
 GEN_FLOP_PER_FRAME = 651.6e6       # Generator algorithmic FLOPs per latent frame
 
 
@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (overrides the config's)")
     ap.add_argument("--symbols", type=int, default=None, help="symbols per utterance (overrides the config's)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="Generator arithmetic (overrides the config's)")
+    ap.add_argument("--flow-dtype", choices=("f32", "f16"), default=None, help="transformer-flow conv arithmetic (overrides the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel family")
@@ -140,6 +141,7 @@ def main():
     B = args.batch if args.batch is not None else cfgd["batch"]
     T = args.symbols if args.symbols is not None else cfgd["symbols"]
     gen_dtype = args.dtype or cfgd["dtype"]
+    flow_dtype = args.flow_dtype or cfgd["flow"]
     kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
 
     # ---- weights: rank 0 folds/packs the seeded synthetic checkpoint, every other rank receives the blob over RCCL
@@ -153,6 +155,8 @@ def main():
     log("weights attached")
     if gen_dtype == "bf16":
         model.set_generator_dtype(torch.bfloat16)
+    if flow_dtype == "f16":
+        model.set_flow_dtype(torch.float16)
 
     # ---- this rank's utterances (weak scaling: same per-GPU work, different utterances)
     batch = synth.synthetic_batch([T] * B, first_index=rank * B)
@@ -248,9 +252,11 @@ def main():
             metric="audio-seconds/sec (44.1 kHz), SynthesizerTrn.infer(), 128-phoneme utterance", value=round(value, 2),
             unit="audio-seconds/sec", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype=gen_dtype, data="synthetic",
+            dtype=gen_dtype if gen_dtype == "f32" or flow_dtype == "f32" else "bf16+f16", data="synthetic",
             config=dict(workload=f"BASELINE config {args.config}: B={B} x T={T} symbols per GPU, "
-                                 f"{'bf16 Generator (fp32 accumulate; encoder/durations/flow fp32)' if gen_dtype == 'bf16' else 'fp32'}, T_y={Ty} frames "
+                                 f"{'bf16 Generator (fp32 accumulate)' if gen_dtype == 'bf16' else 'fp32 Generator'}, "
+                                 f"{'fp16 flow convs (fp32 accumulate / LayerNorm / softmax)' if flow_dtype == 'f16' else 'fp32 flow'}, "
+                                 f"fp32 text encoder / durations / spline, T_y={Ty} frames "
                                  f"({Ty * hp.total_upsample} samples, {Ty * hp.total_upsample / hp.sampling_rate:.3f} s) per utterance, "
                                  f"transformer flow, synthetic seeded weights, durations pinned to 3 frames/symbol",
                         utterances_per_gpu=B, symbols=T, frames=Ty, parallelism=f"utterance-sharded x{world}",

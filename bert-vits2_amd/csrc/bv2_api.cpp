@@ -147,6 +147,25 @@ int bv2_set_generator_dtype(bv2_handle* h, int dtype) {
   return 0;
 }
 
+int bv2_set_flow_dtype(bv2_handle* h, int dtype) {
+  if (!h) return -1;
+  if (dtype != BV2_F32 && dtype != BV2_F16) { h->err = "bv2_set_flow_dtype: BV2_F32 or BV2_F16"; return -1; }
+  if (dtype == BV2_F16) {
+    const Model& m = h->model;
+    bool ok = m.cfg.use_transformer_flow != 0;
+    for (int a = 0; a < m.n_coupling && ok; ++a)
+      for (int i = 0; i < m.coupling[a].enc.n_layers && ok; ++i) {
+        const EncLayerW& L = m.coupling[a].enc.layer[i];
+        ok = L.qkv.wh_off >= 0 && L.o.wh_off >= 0 && L.ffn1.wh_off >= 0 && L.ffn2.wh_off >= 0 &&
+             conv_f16_supported(L.qkv.cin, L.qkv.cout, 1, 1, false) && conv_f16_supported(L.o.cin, L.o.cout, 1, 1, false) &&
+             conv_f16_supported(L.ffn1.cin, L.ffn1.cout, L.ffn1.k, 1, true) && conv_f16_supported(L.ffn2.cin, L.ffn2.cout, L.ffn2.k, 1, false);
+      }
+    if (!ok) { h->err = "bv2_set_flow_dtype: fp16 needs the transformer flow with channel counts that are multiples of 16"; return -2; }
+  }
+  h->flow_dtype = dtype;
+  return 0;
+}
+
 int64_t bv2_workspace_bytes(const bv2_handle* h, int B, int T, int Ty_max) {
   if (!h || B < 1 || T < 1 || Ty_max < 1) return -1;
   return workspace_bytes(h->model, B, T, Ty_max);
@@ -403,6 +422,44 @@ int bv2_test_conv_cl_bf16(void* stream, const void* x0, const void* x1, const vo
     p.pre_lrelu = pre_lrelu; p.slope = slope;
     cl.nprob = 1; cl.B = B; cl.L = L;
     return launch_conv_cl_bf16(static_cast<hipStream_t>(stream), cl, nullptr);
+  } catch (...) { return -100; }
+}
+
+int bv2_test_conv_f16(void* stream, const void* x, int in_ct, const float* in_mask, const float* w_host, const float* bias_host,
+                      void* wpack_dev, void* out, int out_ct, const float* res, int res_mode, const float* out_mask, int mask_pre,
+                      int mask_post, int act, int B, int cin, int cout, int k, int dil, int L, int out_rstride) {
+  try {
+    if (!conv_f16_supported(cin, cout, k, dil, !out_ct)) return -2;
+    const int cout_pad = t_round_up(cout, 32);
+    const int64_t ne = cl_w_elems(cin, cout_pad, k);
+    if (w_host) {
+      std::vector<uint16_t> pk((size_t)ne, 0);
+      for (int j = 0; j < k; ++j)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) {
+            const _Float16 hv = (_Float16)w_host[((size_t)co * cin + ci) * k + j];
+            std::memcpy(&pk[(size_t)cl_w_index(j, ci, co, cin, k)], &hv, 2);
+          }
+      std::vector<float> bb((size_t)cout_pad, 0.f);
+      if (bias_host) for (int co = 0; co < cout; ++co) bb[(size_t)co] = bias_host[co];
+      if (hipMemcpy(wpack_dev, pk.data(), (size_t)ne * 2, hipMemcpyHostToDevice) != hipSuccess) return -6;
+      if (hipMemcpy(static_cast<char*>(wpack_dev) + ne * 2, bb.data(), (size_t)cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    }
+    HcLaunch hl;
+    std::memset(&hl, 0, sizeof(hl));
+    HcProb& p = hl.p;
+    p.x = x; p.in_ct = in_ct; p.x_bstride = (int64_t)cin * L; p.x_rstride = L; p.Lin = L;
+    p.in_mask = in_mask; p.in_mask_bstride = L;
+    p.w = static_cast<const uint16_t*>(wpack_dev);
+    p.bias = bias_host ? reinterpret_cast<const float*>(static_cast<char*>(wpack_dev) + ne * 2) : nullptr;
+    p.out = out; p.out_ct = out_ct;
+    p.out_rstride = out_ct ? (out_rstride > 0 ? out_rstride : L) : 0;
+    p.out_bstride = out_ct ? (int64_t)cout * p.out_rstride : (int64_t)cout * L;
+    p.res = res; p.res_bstride = p.out_bstride; p.res_mode = res_mode;
+    p.out_mask = out_mask; p.out_mask_bstride = L; p.mask_pre = mask_pre; p.mask_post = mask_post; p.act = act;
+    p.cin = cin; p.cout = cout; p.cout_pad = cout_pad; p.k = k; p.dil = dil; p.pad_left = ((k - 1) / 2) * dil;
+    hl.B = B; hl.L = L;
+    return launch_conv_f16(static_cast<hipStream_t>(stream), hl, nullptr);
   } catch (...) { return -100; }
 }
 

@@ -106,6 +106,31 @@ struct Ctx {
     cl.p[0] = p; cl.nprob = 1; cl.B = B; cl.L = L;
     return conv(cl, tag, max_split, slab_stride);
   }
+  // fp16 Encoder conv (kernels/enc_f16.hip) on dense tensors: in_ct/out_ct select fp32 [B][C][T] vs fp16 [B][T][C]
+  HcProb hprob(const ConvW& w, const void* x, bool in_ct, void* out, bool out_ct, int L) const {
+    HcProb p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x; p.in_ct = in_ct; p.x_bstride = (int64_t)w.cin * L; p.x_rstride = L; p.Lin = L;
+    p.in_mask_bstride = L; p.out_mask_bstride = L;
+    p.w = reinterpret_cast<const uint16_t*>(W(w.wh_off)); p.bias = W(w.b_off);
+    p.out = out; p.out_ct = out_ct; p.out_bstride = (int64_t)w.cout * L; p.out_rstride = L;
+    p.res_bstride = p.out_bstride;
+    p.cin = w.cin; p.cout = w.cout; p.cout_pad = w.cout_pad; p.k = w.k; p.dil = 1; p.pad_left = (w.k - 1) / 2;
+    return p;
+  }
+  void conv_h(const HcProb& p, int B, int L, const char* tag) {
+    if (rc) return;
+    HcLaunch hl;
+    hl.p = p; hl.B = B; hl.L = L;
+    const char* vn = "conv_f16";
+    const int pi = prof_begin(tag);
+    if (pi >= 0 && h->prof_mode == 3)
+      cur_shape = " n1 " + std::to_string(p.cin) + ">" + std::to_string(p.cout) + " k" + std::to_string(p.k) + " L" +
+                  std::to_string(L) + " B" + std::to_string(B);
+    const int r = launch_conv_f16(s, hl, &vn);
+    prof_end(pi, vn, conv_f16_flops(hl), conv_f16_bytes(hl));
+    if (r) fail(tag, r);
+  }
   void ln(const LnArgs& a, const char* tag) {
     if (rc) return;
     if (int r = launch_layernorm(s, a)) fail(tag, r);
@@ -129,14 +154,20 @@ inline int attn_ld(int T) { return (T + 31) / 32 * 32; }
 inline int qkv_rows(const EncoderW& e) { return 3 * e.hidden + e.heads * (2 * kAttnWindow + 1); }
 
 void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask, const float* spk, int spk_bstride,
-                 int B, int T, const char* tapname) {
+                 int B, int T, const char* tapname, bool f16 = false) {
   const int H = e.hidden, ld = attn_ld(T), R = qkv_rows(e);
   // cond_layer_idx == 2 > 0: the speaker add always rides on the previous layer's LN2 epilogue
   for (int i = 0; i < e.n_layers; ++i) {
     const EncLayerW& L = e.layer[i];
     ConvProb p = c.prob(L.qkv, b.x, b.qkv, T);
     p.out_rstride = ld; p.out_bstride = (int64_t)R * ld;      // rows padded to 32 columns: aligned tile loads
-    c.conv1(p, B, T, "enc.qkv");
+    if (f16) {
+      HcProb q = c.hprob(L.qkv, b.x, true, b.qkv, true, T);
+      q.out_rstride = ld; q.out_bstride = (int64_t)R * ld;
+      c.conv_h(q, B, T, "enc.qkv");
+    } else {
+      c.conv1(p, B, T, "enc.qkv");
+    }
     AttnArgs a;
     a.qkv = b.qkv; a.ld = ld; a.mask = mask; a.erv = c.W(L.erv.off); a.out = b.att;
     a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow;
@@ -146,20 +177,38 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       c.prof_end(pi, "attention_relpos", attention_flops(a), 4.0 * B * 4 * H * (double)T);
       if (r) c.fail("attention", r);
     }
-    p = c.prob(L.o, b.att, b.s, T);
-    p.res = b.x; p.res_mode = RES_ADD;
-    int ns = c.conv1(p, B, T, "enc.o", kSlabs, b.slab);
+    int ns = 1;
+    if (f16) {
+      HcProb q = c.hprob(L.o, b.att, true, b.s, true, T);
+      q.res = b.x; q.res_mode = RES_ADD;
+      c.conv_h(q, B, T, "enc.o");
+    } else {
+      p = c.prob(L.o, b.att, b.s, T);
+      p.res = b.x; p.res_mode = RES_ADD;
+      ns = c.conv1(p, B, T, "enc.o", kSlabs, b.slab);
+    }
     LnArgs l;
     std::memset(&l, 0, sizeof(l));
     l.a = b.s; l.nslab = ns; l.slab_stride = b.slab;
     l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T;
     c.ln(l, "enc.ln1");
-    p = c.prob(L.ffn1, b.x, b.f1, T);
-    p.in_mask = mask; p.act = ACT_RELU;
-    c.conv1(p, B, T, "enc.ffn1");
-    p = c.prob(L.ffn2, b.f1, b.s, T);
-    p.in_mask = mask; p.out_mask = mask; p.mask_pre = 1; p.res = b.x; p.res_mode = RES_ADD;
-    ns = c.conv1(p, B, T, "enc.ffn2", kSlabs, b.slab);
+    if (f16) {
+      // FFN (attentions.py:438-446): hidden activation relu(conv_1(x*mask))*mask kept as fp16 channels-last in b.f1
+      HcProb q = c.hprob(L.ffn1, b.x, true, b.f1, false, T);
+      q.in_mask = mask; q.act = ACT_RELU; q.out_mask = mask; q.mask_post = 1;
+      c.conv_h(q, B, T, "enc.ffn1");
+      q = c.hprob(L.ffn2, b.f1, false, b.s, true, T);
+      q.out_mask = mask; q.mask_pre = 1; q.res = b.x; q.res_mode = RES_ADD;
+      c.conv_h(q, B, T, "enc.ffn2");
+      ns = 1;
+    } else {
+      p = c.prob(L.ffn1, b.x, b.f1, T);
+      p.in_mask = mask; p.act = ACT_RELU;
+      c.conv1(p, B, T, "enc.ffn1");
+      p = c.prob(L.ffn2, b.f1, b.s, T);
+      p.in_mask = mask; p.out_mask = mask; p.mask_pre = 1; p.res = b.x; p.res_mode = RES_ADD;
+      ns = c.conv1(p, B, T, "enc.ffn2", kSlabs, b.slab);
+    }
     l.a = b.s; l.nslab = ns; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off);
     if (i + 1 == kCondLayer && i + 1 < e.n_layers) { l.vec = spk; l.vec_bstride = spk_bstride; l.mask = mask; }
     if (i + 1 == e.n_layers) l.mask = mask;
@@ -430,7 +479,7 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
     c.conv1(p, B, Ty, "flow.pre");
     const float* hres = P.h;
     if (cf.use_transformer_flow) {
-      run_encoder(c, K.enc, P.enc, ymask, gv_flow + a * H, P.gv_stride, B, Ty, nullptr);
+      run_encoder(c, K.enc, P.enc, ymask, gv_flow + a * H, P.gv_stride, B, Ty, nullptr, c.h->flow_dtype == BV2_F16);
     } else {
       const int nl = K.wn_layers;
       const float* gl = gv_flow + (int64_t)a * 2 * H * nl;

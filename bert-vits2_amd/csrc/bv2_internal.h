@@ -31,6 +31,7 @@ struct ConvW {
   int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, w_ld = 0, k = 1;
   int64_t w_off = -1, b_off = -1;    // b_off < 0: no bias
   int64_t wb_off = -1;               // Generator convs only: bf16 fragment stream (cl_w_index), offset in floats
+  int64_t wh_off = -1;               // flow Encoder convs only: fp16 fragment stream (cl_w_index), offset in floats
 };
 struct VecW { int64_t off = -1; int64_t n = 0; };
 struct GemvW { int cout = 0, cin = 0; int64_t w_off = -1, b_off = -1; };
@@ -115,6 +116,7 @@ struct bv2_handle {
   std::string err;
   std::map<std::string, bv2::Tap> taps;
   int gen_dtype = BV2_F32;           // Generator arithmetic: BV2_F32 (conv_mfma.hip) or BV2_BF16 (gen_bf16.hip)
+  int flow_dtype = BV2_F32;          // transformer-flow Encoder convs: BV2_F32 (conv_mfma.hip) or BV2_F16 (enc_f16.hip)
   // profiling
   bool prof_on = false;
   int prof_mode = 1;                 // 1: every MFMA kernel launch, 2: Generator (dec.*) launches only

@@ -150,6 +150,36 @@ struct ConvPostClArgs {
 int launch_conv_post_cl(hipStream_t stream, const ConvPostClArgs& a);
 
 // --------------------------------------------------------------------------------------------------------------
+// fp16 convolutions / projections of the attention Encoder stacks (kernels/enc_f16.hip): v_mfma_f32_32x32x16_f16, fp32
+// accumulate.  Sits between the fp32 [B][C][T] tensors of the fp32 kernels (LayerNorm, attention) without conversion passes:
+//   in_ct  = 1: x is fp32 [B][cin][x_rstride] (T contiguous), multiplied by in_mask[b][t] and rounded to fp16 while staged
+//   in_ct  = 0: x is fp16 channels-last [B][Lin][cin]
+//   out_ct = 1: out is fp32 [B][cout][out_rstride]:  v = acc + bias; relu; *mask (mask_pre); res op; *mask (mask_post)
+//   out_ct = 0: out is fp16 channels-last [B][L][cout]:  v = fp16( relu(acc + bias) * mask )
+// w = fp16 fragment stream in cl_w_index order (cin % 16 == 0).
+struct HcProb {
+  const void* x; int in_ct;
+  int64_t x_bstride;        // elements between batches
+  int x_rstride;            // in_ct: floats between channels
+  int Lin;
+  const float* in_mask; int in_mask_bstride;      // in_ct only; null = no mask
+  const uint16_t* w;
+  const float* bias;        // [cout_pad] fp32 or null
+  void* out; int out_ct;
+  int64_t out_bstride;      // elements between batches
+  int out_rstride;          // out_ct: floats between channels
+  const float* res; int64_t res_bstride; int res_mode;   // out_ct only, indexed like out
+  const float* out_mask; int out_mask_bstride;
+  int mask_pre, mask_post, act;
+  int cin, cout, cout_pad, k, dil, pad_left;
+};
+struct HcLaunch { HcProb p; int B, L; };
+int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name);
+bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl);
+double conv_f16_flops(const HcLaunch& L);
+double conv_f16_bytes(const HcLaunch& L);
+
+// --------------------------------------------------------------------------------------------------------------
 // conv_post + tanh (kernels/misc.hip): out[b][t] = tanh( sum_{c,j} w[c][j] * lrelu_slope( in_scale*sum_s x_s[b][c][t-pad+j] ) )
 struct ConvPostArgs {
   const float* x[3]; int nsrc; float in_scale; int64_t x_bstride; int x_rstride;

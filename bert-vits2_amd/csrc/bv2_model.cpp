@@ -33,6 +33,14 @@ static inline uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// fp32 -> fp16, round to nearest even (what torch's .to(torch.float16) and v_cvt_f16_f32 do)
+static inline uint16_t f2h(float f) {
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+
 namespace {
 
 struct Packer {
@@ -41,6 +49,7 @@ struct Packer {
   int64_t cursor = kBlobHeaderFloats;
   std::vector<std::string> missing;
   bool emit_bf16 = false;                                  // also write the channels-last bf16 fragment stream (dec.*)
+  bool emit_f16 = false;                                   // also write the fp16 fragment stream (flow Encoder convs)
 
   bool fill() const { return blob != nullptr; }
 
@@ -111,6 +120,7 @@ struct Packer {
     c.w_off = alloc((int64_t)k * c.cin_pad * c.w_ld);
     c.b_off = bias ? alloc(c.cout_pad) : -1;
     if (emit_bf16 && cin % 16 == 0) c.wb_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
+    if (emit_f16 && cin % 16 == 0) c.wh_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (fill() && ok) {
       for (int j = 0; j < k; ++j)
         for (int ci = 0; ci < cin; ++ci)
@@ -123,6 +133,12 @@ struct Packer {
         for (int j = 0; j < k; ++j)
           for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co) wb[cl_w_index(j, ci, co, cin, k)] = f2bf(src(co, ci, j));
+      }
+      if (c.wh_off >= 0) {
+        uint16_t* wh = reinterpret_cast<uint16_t*>(blob + c.wh_off);
+        for (int j = 0; j < k; ++j)
+          for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) wh[cl_w_index(j, ci, co, cin, k)] = f2h(src(co, ci, j));
       }
     }
     return c;
@@ -311,7 +327,9 @@ int pack_all(Model& m, Packer& P) {
     C.flipped = (a % 2) == 0;                      // a+1 Flips have been applied before coupling a
     C.pre = P.conv1d(p + ".pre", hid, half, 1, true, false, 0, -1, /*rev_in=*/C.flipped, false);
     if (c.use_transformer_flow) {
+      P.emit_f16 = true;                           // BASELINE config 5 "fp16 flow": q/k/v/o and FFN convs also as fp16 streams
       C.enc = pack_encoder(P, p + ".enc", hid, filt, c.n_heads, c.n_layers_trans_flow, kFlowKernel, gin);
+      P.emit_f16 = false;
     } else {
       const int nl = c.n_flow_layer;
       C.wn_layers = nl;

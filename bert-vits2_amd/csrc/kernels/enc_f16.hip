@@ -1,0 +1,307 @@
+// enc_f16.hip — the convolutions / projections of the attention Encoder stacks (reference attentions.py:103-120:
+// conv_q/k/v, conv_o, FFN conv_1 / conv_2) in fp16 on the gfx950 matrix core (v_mfma_f32_32x32x16_f16, fp32 accumulate).
+// BASELINE config 5 "fp16 flow + fp32 spline" / config 3: at batch 32 the flow's fp32 FFN convs are 40 % of the step once
+// the Generator runs in bf16; here they move to the half-precision MFMA rate while LayerNorm, softmax, the residual stream
+// and the attention core stay fp32.
+//
+//   GEMM view: M = C_out (A operand = fp16 weight fragments, streamed global -> registers through an 8-deep ring),
+//              N = time (B operand = 8 consecutive input channels of one time step: ONE ds_read_b128 from the LDS tile),
+//              K = (16-channel group, tap).
+//
+// The LDS tile is channels-last [rows = 32*NI + (k-1)*dil][pitch = ck + 8] fp16 (pitch = odd multiple of 16 B: the
+// ds_read_b128 of 32 consecutive rows are conflict-free); C_in is walked in chunks of <= 256 channels so that the tile fits
+// twice per CU for any C_in (FFN conv_2 has C_in = 768).  Two input forms and two output forms, so that the kernel sits
+// directly between the fp32 [B][C][T] tensors of the surrounding fp32 kernels with no conversion pass:
+//   IN_CT : fp32 [B][C][T] (+ per-column mask) -> rounded to fp16 and TRANSPOSED while it is staged (lane = 16 time steps x
+//           4 channel pairs: 64-byte global segments, conflict-free 4-byte LDS writes);
+//   IN_CL : fp16 channels-last [B][T][C] (the FFN hidden activation), 16-byte pieces;
+//   OUT_CT: fp32 [B][C][ld] with bias, masks and the residual add (the D fragment's lane index is the time step: each
+//           register stores 32 consecutive floats of one channel row);
+//   OUT_CL: fp16 [B][T][C] with bias, ReLU and mask (FFN hidden).
+// Weight stream: cl_w_index (bv2_kernels.h) in fp16, [m-tile][unit = (ci/16)*k + tap][lane][8] — 1 KB per unit.
+#include <hip/hip_runtime.h>
+#include "../bv2_kernels.h"
+
+namespace bv2 {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HC_PD = 8;          // weight prefetch ring depth (units of NI MFMAs)
+constexpr int HC_CK = 256;        // input channels per LDS chunk
+
+__device__ __forceinline__ unsigned h_pack(float a, float b) {       // round-to-nearest-even (v_cvt_f16_f32)
+  f16x2 r;
+  r[0] = (_Float16)a; r[1] = (_Float16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+
+// acc[ni] += sum over units u = (s, j) of Wfrag(u) x B(u, ni);  B(u, ni) = channels [16s + 8lh, +8) of LDS row
+// (ni*32 + l31 + j*tstep) relative to xb.  wp = this wave's contiguous weight stream (+ lane*8 elements).
+template <int NI>
+__device__ __forceinline__ void hc_gemm(f32x16 (&acc)[NI], const uint16_t* wp, int U, int k, const unsigned short* xb,
+                                        int pitch, int tstep) {
+  f16x8 ar[HC_PD];
+  int lu = 0;
+  auto load_unit = [&](int slot) __attribute__((always_inline)) {
+    const int uc = lu < U ? lu : U - 1;                             // past the end: re-read the last unit, result unused
+    ar[slot] = *reinterpret_cast<const f16x8*>(wp + (int64_t)uc * 512);
+    ++lu;
+  };
+#pragma unroll
+  for (int i = 0; i < HC_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  f16x8 bb[2][NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bb[0][ni] = *reinterpret_cast<const f16x8*>(xb + ni * 32 * pitch);
+  int s = 0, j = 0;
+  for (int u0 = 0; u0 < U; u0 += HC_PD) {
+#pragma unroll
+    for (int i = 0; i < HC_PD; ++i) {
+      if (u0 + i < U) {
+        int jn = j + 1, sn = s;
+        if (jn == k) { jn = 0; ++sn; }
+        const bool more = u0 + i + 1 < U;
+        const unsigned short* xn = xb + (more ? jn : j) * tstep * pitch + (more ? sn : s) * 16;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bb[(i & 1) ^ 1][ni] = *reinterpret_cast<const f16x8*>(xn + ni * 32 * pitch);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[i], bb[i & 1][ni], acc[ni], 0, 0, 0);
+        j = jn; s = sn;
+      }
+      load_unit(i);
+      __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay HC_PD - 1 units
+    }
+  }
+}
+
+// fp32 [C][T] rows -> fp16 channels-last LDS tile (rows tb .. tb+rows-1, channels c0 .. c0+ck-1), x mask, zero padding
+template <int NT>
+__device__ __forceinline__ void hc_stage_ct(unsigned short* xs, int pitch, const float* x, int x_rstride, const float* mask,
+                                            int tb, int rows, int c0, int ck, int Lin, int tid) {
+  const int lane = tid & 63, wid = tid >> 6;
+  const int tl = lane & 15, cq = lane >> 4;       // 16 time steps x 4 channel pairs per wave instruction
+  const int tblocks = (rows + 15) >> 4, cblocks = ck >> 3;
+  const int units = tblocks * cblocks;
+  constexpr int NWV = NT / 64;
+  unsigned* xs32 = reinterpret_cast<unsigned*>(xs);
+  const int p32 = pitch >> 1;
+  for (int u0 = wid; u0 < units; u0 += 4 * NWV) {
+    float a[4], b[4], m[4];
+    int dst[4];
+    bool wr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int u = u0 + q * NWV;
+      const bool inb = u < units;
+      u = inb ? u : units - 1;
+      const int cbk = u / tblocks, tbk = u - cbk * tblocks;
+      const int r = tbk * 16 + tl;
+      const int t = tb + r;
+      const bool ok = t >= 0 && t < Lin;
+      const int tc = t < 0 ? 0 : (t >= Lin ? Lin - 1 : t);           // clamped: the loads are unconditional
+      const int c = c0 + cbk * 8 + cq * 2;
+      const float* src = x + (int64_t)c * x_rstride + tc;
+      a[q] = src[0];
+      b[q] = src[x_rstride];
+      m[q] = ok ? (mask ? mask[tc] : 1.f) : 0.f;
+      wr[q] = inb && r < rows;
+      dst[q] = r * p32 + cbk * 4 + cq;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (wr[q]) xs32[dst[q]] = h_pack(a[q] * m[q], b[q] * m[q]);
+  }
+}
+
+// fp16 channels-last [L][cin] rows -> LDS tile (16-byte pieces)
+template <int NT>
+__device__ __forceinline__ void hc_stage_cl(unsigned short* xs, int pitch, const uint16_t* x, int cin, int tb, int rows,
+                                            int c0, int ck, int Lin, int tid) {
+  const int ppr = ck >> 3;
+  const int total = rows * ppr;
+  for (int base = 0; base < total; base += 4 * NT) {
+    u32x4 v[4];
+    int dst[4];
+    bool ok[4], inb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int p = base + q * NT + tid;
+      inb[q] = p < total;
+      p = inb[q] ? p : total - 1;
+      const int r = p / ppr, cb = p - r * ppr;
+      const int t = tb + r;
+      ok[q] = t >= 0 && t < Lin;
+      const int tc = t < 0 ? 0 : (t >= Lin ? Lin - 1 : t);
+      dst[q] = r * pitch + cb * 8;
+      v[q] = *reinterpret_cast<const u32x4*>(x + (int64_t)tc * cin + c0 + cb * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (inb[q]) *reinterpret_cast<u32x4*>(xs + dst[q]) = ok[q] ? v[q] : u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
+template <int WN, int NI, bool IN_CT, bool OUT_CT>
+__global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, const int ngrp) {
+  constexpr int NT = 64 * WN, BT = 32 * NI;
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
+  const HcProb& P = L.p;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y / ngrp;
+  const int cg = blockIdx.y - b * ngrp;
+  const int mt = cg * WN + wid;
+  const int t0 = blockIdx.x * BT;
+  const int cin = P.cin, k = P.k, dil = P.dil;
+  const int rows = BT + (k - 1) * dil;
+  const bool active = mt * 32 < P.cout_pad;
+  const int Utot = (cin >> 4) * k;
+
+  f32x16 acc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+
+  for (int c0 = 0; c0 < cin; c0 += HC_CK) {
+    const int ck = cin - c0 < HC_CK ? cin - c0 : HC_CK;
+    const int pitch = ck + 8;
+    if (c0) __syncthreads();                       // every wave is done reading the previous chunk's tile
+    if (IN_CT)
+      hc_stage_ct<NT>(xs, pitch, static_cast<const float*>(P.x) + (int64_t)b * P.x_bstride, P.x_rstride,
+                      P.in_mask ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr, t0 - P.pad_left, rows, c0, ck, P.Lin, tid);
+    else
+      hc_stage_cl<NT>(xs, pitch, static_cast<const uint16_t*>(P.x) + (int64_t)b * P.x_bstride, cin, t0 - P.pad_left, rows,
+                      c0, ck, P.Lin, tid);
+    __syncthreads();
+    if (active)
+      hc_gemm<NI>(acc, P.w + ((int64_t)mt * Utot + (int64_t)(c0 >> 4) * k) * 512 + lane * 8, (ck >> 4) * k, k,
+                  xs + l31 * pitch + lh * 8, pitch, dil);
+  }
+  if (!active) return;
+
+  const int cout = P.cout;
+  if (OUT_CT) {
+    float* outp = static_cast<float*>(P.out) + (int64_t)b * P.out_bstride;
+    const float* resp = P.res ? P.res + (int64_t)b * P.res_bstride : nullptr;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int t = t0 + ni * 32 + l31;
+      if (t >= L.L) continue;
+      const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + t] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co >= cout) continue;
+        float v = acc[ni][r];
+        if (P.bias) v += P.bias[co];
+        if (P.act == ACT_RELU) v = fmaxf(v, 0.f);
+        if (P.mask_pre) v *= om;
+        const int64_t oidx = (int64_t)co * P.out_rstride + t;
+        if (P.res_mode == RES_ADD) v += resp[oidx];
+        else if (P.res_mode == RES_RSUB) v = resp[oidx] - v;
+        if (P.mask_post) v *= om;
+        outp[oidx] = v;
+      }
+    }
+  } else {
+    uint16_t* outp = static_cast<uint16_t*>(P.out) + (int64_t)b * P.out_bstride;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int t = t0 + ni * 32 + l31;
+      if (t >= L.L) continue;
+      const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + t] : 1.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = mt * 32 + 8 * g + 4 * lh;
+        if (co >= cout) continue;
+        float v0 = acc[ni][4 * g], v1 = acc[ni][4 * g + 1], v2 = acc[ni][4 * g + 2], v3 = acc[ni][4 * g + 3];
+        if (P.bias) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + co);
+          v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+        }
+        if (P.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        if (P.mask_pre || P.mask_post) { v0 *= om; v1 *= om; v2 *= om; v3 *= om; }
+        u32x2 o;
+        o.x = h_pack(v0, v1); o.y = h_pack(v2, v3);
+        *reinterpret_cast<u32x2*>(outp + (int64_t)t * cout + co) = o;
+      }
+    }
+  }
+}
+
+bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl) {
+  if (cin < 16 || cin % 16 || cout < 1 || k < 1 || dil < 1) return false;
+  if (out_cl && cout % 4) return false;
+  const int ck = cin < HC_CK ? cin : HC_CK;
+  return (int64_t)(64 + (k - 1) * dil) * (ck + 8) * 2 <= 160 * 1024;
+}
+
+template <int WN, int NI, bool IN_CT, bool OUT_CT>
+static int launch_hc(hipStream_t stream, const HcLaunch& L, int nt) {
+  constexpr int BT = 32 * NI;
+  const HcProb& p = L.p;
+  const int ck = p.cin < HC_CK ? p.cin : HC_CK;
+  const size_t lds = (size_t)(BT + (p.k - 1) * p.dil) * (size_t)(ck + 8) * 2;
+  if (lds > 160 * 1024) return -2;
+  const int ngrp = (nt + WN - 1) / WN;
+  dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, 1);
+  auto kern = conv_f16_kernel<WN, NI, IN_CT, OUT_CT>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WN), lds, stream, L, ngrp);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int WN, int NI>
+static int launch_hc_io(hipStream_t stream, const HcLaunch& L, int nt) {
+  const bool ict = L.p.in_ct != 0, oct = L.p.out_ct != 0;
+  if (ict && oct) return launch_hc<WN, NI, true, true>(stream, L, nt);
+  if (ict) return launch_hc<WN, NI, true, false>(stream, L, nt);
+  if (oct) return launch_hc<WN, NI, false, true>(stream, L, nt);
+  return launch_hc<WN, NI, false, false>(stream, L, nt);
+}
+
+int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name) {
+  const HcProb& p = L.p;
+  if (L.B < 1 || L.L < 1 || !conv_f16_supported(p.cin, p.cout, p.k, p.dil, !p.out_ct) || p.cout_pad % 32 || p.cout_pad < p.cout)
+    return -1;
+  if (!p.out_ct && (p.res_mode != RES_NONE)) return -1;            // the residual add lives in the fp32 [C][T] epilogue
+  const int nt = p.cout_pad / 32;
+  // waves per workgroup (each owns one 32-channel output tile): the count in {8, 6, 4} that wastes the fewest wave slots
+  int wn = 8, best = 1 << 30;
+  const int cand[3] = {8, 6, 4};
+  for (int c : cand) {
+    const int waste = (nt + c - 1) / c * c - nt;
+    if (waste < best) { best = waste; wn = c; }
+  }
+  // time steps per workgroup: 128 when that still gives every CU a workgroup, else 64
+  const long wg128 = (long)((L.L + 127) / 128) * L.B * ((nt + wn - 1) / wn);
+  int ni = wg128 >= 256 ? 4 : 2;
+  {
+    const int ck = p.cin < HC_CK ? p.cin : HC_CK;
+    if ((int64_t)(128 + (p.k - 1) * p.dil) * (ck + 8) * 2 > 160 * 1024) ni = 2;
+  }
+  static const char* names[3][2] = {{"conv_f16<8w,64>", "conv_f16<8w,128>"}, {"conv_f16<6w,64>", "conv_f16<6w,128>"},
+                                    {"conv_f16<4w,64>", "conv_f16<4w,128>"}};
+  if (variant_name) *variant_name = names[wn == 8 ? 0 : (wn == 6 ? 1 : 2)][ni == 4 ? 1 : 0];
+  if (wn == 8) return ni == 4 ? launch_hc_io<8, 4>(stream, L, nt) : launch_hc_io<8, 2>(stream, L, nt);
+  if (wn == 6) return ni == 4 ? launch_hc_io<6, 4>(stream, L, nt) : launch_hc_io<6, 2>(stream, L, nt);
+  return ni == 4 ? launch_hc_io<4, 4>(stream, L, nt) : launch_hc_io<4, 2>(stream, L, nt);
+}
+
+double conv_f16_flops(const HcLaunch& L) { return 2.0 * L.p.cout * L.p.cin * L.p.k * (double)L.L * L.B; }
+
+double conv_f16_bytes(const HcLaunch& L) {   // input read once, output written once (+ residual read), weights once
+  const HcProb& p = L.p;
+  const double n = (double)L.L * L.B;
+  return (p.in_ct ? 4.0 : 2.0) * p.cin * n + (p.out_ct ? 4.0 : 2.0) * p.cout * n + (p.res_mode ? 4.0 * p.cout * n : 0.0) +
+         2.0 * p.cout * p.cin * p.k;
+}
+
+}  // namespace bv2

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("bv2_pack_weights", C.c_int, [_P, _P, C.c_int64]),
     ("bv2_attach_weights", C.c_int, [_P, _P, C.c_int64]),
     ("bv2_set_generator_dtype", C.c_int, [_P, C.c_int]),
+    ("bv2_set_flow_dtype", C.c_int, [_P, C.c_int]),
     ("bv2_workspace_bytes", C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     ("bv2_encode_durations", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64]),
     ("bv2_decode", C.c_int, [_P, _P, C.POINTER(DecodeIn), C.POINTER(DecodeOut), _P, C.c_int64]),

@@ -71,6 +71,7 @@ class SynthesizerTrn(nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._taps: Dict[str, torch.Tensor] = {}
         self.generator_dtype = torch.float32
+        self.flow_dtype = torch.float32
 
     # ------------------------------------------------------------------ parameter tree
     def _register(self, key: str, value: torch.Tensor) -> None:
@@ -168,6 +169,18 @@ class SynthesizerTrn(nn.Module):
             raise ValueError("generator dtype must be torch.float32 or torch.bfloat16")
         self._check(lib.bv2_set_generator_dtype(self._handle, code), "bv2_set_generator_dtype")
         self.generator_dtype = torch.bfloat16 if code == L.BF16 else torch.float32
+
+    def set_flow_dtype(self, dtype) -> None:
+        """Arithmetic of the transformer flow's Encoder convolutions (fused q/k/v, conv_o, FFN): ``torch.float32``
+        (default) or ``torch.float16`` (fp16 weights / conv inputs / FFN hidden, fp32 accumulate — BASELINE config 5
+        "fp16 flow + fp32 spline"; the reference's counterpart is ``flow`` under ``torch.autocast(float16)``).  LayerNorm,
+        the attention core, the residual stream and everything before the flow stay fp32: durations are unchanged."""
+        lib = self._ensure_handle()
+        code = {torch.float32: L.F32, "fp32": L.F32, "f32": L.F32, torch.float16: L.F16, "fp16": L.F16, "f16": L.F16}.get(dtype)
+        if code is None:
+            raise ValueError("flow dtype must be torch.float32 or torch.float16")
+        self._check(lib.bv2_set_flow_dtype(self._handle, code), "bv2_set_flow_dtype")
+        self.flow_dtype = torch.float16 if code == L.F16 else torch.float32
 
     def _workspace(self, B: int, T: int, Ty: int) -> torch.Tensor:
         n = self._lib.bv2_workspace_bytes(self._handle, B, T, Ty)

@@ -38,6 +38,14 @@ int bv2_test_conv_cl_bf16(void* stream, const void* x0, const void* x1, const vo
                           const float* bias_host, void* wpack_dev, void* out, const void* res, const float* bias2, int B, int cin,
                           int cout, int k, int dil, int pad_left, int L, int pre_lrelu, float slope);
 
+/* fp16 Encoder conv (kernels/enc_f16.hip).  in_ct: x is DEVICE fp32 [B][cin][L] (in_mask [B][L] optional) else fp16 [B][L][cin];
+ * out_ct: out is DEVICE fp32 [B][cout][out_rstride] (res like out, res_mode 0/1/2 = none/add/rsub) else fp16 [B][L][cout];
+ * w_host [cout][cin][k], bias_host [cout] HOST fp32; wpack_dev needs bv2_test_conv_cl_pack_bytes(cin, cout, k) bytes;
+ * "same" padding; act 1 = ReLU; out_mask [B][L] applied before (mask_pre) and/or after (mask_post) the residual op */
+int bv2_test_conv_f16(void* stream, const void* x, int in_ct, const float* in_mask, const float* w_host, const float* bias_host,
+                      void* wpack_dev, void* out, int out_ct, const float* res, int res_mode, const float* out_mask, int mask_pre,
+                      int mask_post, int act, int B, int cin, int cout, int k, int dil, int L, int out_rstride);
+
 /* Decode one Generator conv of a packed HOST blob back to dense form (checks the bf16 packer on a CPU-only box):
  * kind 0 = dec.conv_pre, 1 = dec.ups[i] in its channels-last single-conv form (C_out' = u*C_out), 2 = resblock conv
  * rb[i][j][d][e].  dims = {cin, cout, k, pad_left}; w_out [cout][cin][k] (bf16 values widened to fp32) and bias_out [cout]

@@ -66,23 +66,45 @@ def conv1x1(sd, p, x):
 # --------------------------------------------------------------------------------------------
 # attentions.py
 
-def rel_attention(sd, p, x, mask_bt, n_heads):
+def _h(x: torch.Tensor) -> torch.Tensor:
+    """fp16 storage rounding (round-to-nearest-even), kept in fp32 for the arithmetic."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+def rel_attention(sd, p, x, mask_bt, n_heads, half=False):
     """MultiHeadAttention with windowed relative positions, reference attentions.py:263-322 (+ helpers
     :324-395), in banded form: logits get q_i·E_k[j-i+4]/sqrt(d) for |j-i| <= 4, outputs get
-    sum_r p[i,i+r]·E_v[r+4]; masked pairs are SET to -1e4 (attentions.py:297)."""
+    sum_r p[i,i+r]·E_v[r+4]; masked pairs are SET to -1e4 (attentions.py:297).
+
+    half=True pins the rounding points of the fp16 product path (bv2_set_flow_dtype): the projection inputs and
+    weights are rounded to fp16 (q rows pre-scaled by 1/sqrt(d), the relative-key logits taken from the fused rows
+    E_k·W_q/sqrt(d) — both rounded AFTER the fold, as the packer does), accumulation / bias / attention core fp32."""
     B, C, T = x.shape
     d = C // n_heads
-    q = conv1x1(sd, p + ".conv_q", x).view(B, n_heads, d, T).transpose(2, 3)      # [B,H,T,d]
-    k = conv1x1(sd, p + ".conv_k", x).view(B, n_heads, d, T).transpose(2, 3)
-    v = conv1x1(sd, p + ".conv_v", x).view(B, n_heads, d, T).transpose(2, 3)
-    qs = q / math.sqrt(d)
-    scores = qs @ k.transpose(-1, -2)                                              # [B,H,T,T]
     ek, ev = sd[p + ".emb_rel_k"][0], sd[p + ".emb_rel_v"][0]                      # [9,d]
+    if half:
+        isq = 1.0 / math.sqrt(d)
+        xh = _h(x)
+        wq, bq = sd[p + ".conv_q.weight"][:, :, 0].double(), sd[p + ".conv_q.bias"].double()
+        qs = (F.conv1d(xh, _h((wq * isq).float())[:, :, None]) + (bq * isq).float()[None, :, None])
+        qs = qs.view(B, n_heads, d, T).transpose(2, 3)
+        k = (F.conv1d(xh, _h(sd[p + ".conv_k.weight"])) + sd[p + ".conv_k.bias"][None, :, None]).view(B, n_heads, d, T).transpose(2, 3)
+        v = (F.conv1d(xh, _h(sd[p + ".conv_v.weight"])) + sd[p + ".conv_v.bias"][None, :, None]).view(B, n_heads, d, T).transpose(2, 3)
+        wrel = torch.stack([ek.double() @ wq[hh * d:(hh + 1) * d] for hh in range(n_heads)]) * isq          # [H,9,C]
+        brel = torch.stack([ek.double() @ bq[hh * d:(hh + 1) * d] for hh in range(n_heads)]) * isq          # [H,9]
+        ql = F.conv1d(xh, _h(wrel.float()).reshape(n_heads * ek.shape[0], C, 1)) + brel.float().reshape(-1)[None, :, None]
+        ql = ql.view(B, n_heads, ek.shape[0], T).transpose(2, 3)                   # [B,H,T,9]
+    else:
+        q = conv1x1(sd, p + ".conv_q", x).view(B, n_heads, d, T).transpose(2, 3)  # [B,H,T,d]
+        k = conv1x1(sd, p + ".conv_k", x).view(B, n_heads, d, T).transpose(2, 3)
+        v = conv1x1(sd, p + ".conv_v", x).view(B, n_heads, d, T).transpose(2, 3)
+        qs = q / math.sqrt(d)
+        ql = qs @ ek.t()                                                           # [B,H,T,9]
+    scores = qs @ k.transpose(-1, -2)                                              # [B,H,T,T]
     idx = torch.arange(T)
     rel = idx[None, :] - idx[:, None]                                              # j - i
     band = rel.abs() <= WINDOW
     ridx = (rel + WINDOW).clamp(0, 2 * WINDOW)
-    ql = qs @ ek.t()                                                               # [B,H,T,9]
     scores = scores + torch.where(band, ql.gather(-1, ridx.expand(B, n_heads, T, T)), torch.zeros(()))
     pair = (mask_bt[:, None, :, None] * mask_bt[:, None, None, :]) != 0
     scores = torch.where(pair, scores, torch.full((), -1e4, dtype=scores.dtype))
@@ -96,19 +118,27 @@ def rel_attention(sd, p, x, mask_bt, n_heads):
             relw[:, :, lo:hi, r + WINDOW] = pa[:, :, i, i + r]
     out = out + relw @ ev
     out = out.transpose(2, 3).reshape(B, C, T)
+    if half:
+        return F.conv1d(_h(out), _h(sd[p + ".conv_o.weight"]), sd[p + ".conv_o.bias"])
     return conv1x1(sd, p + ".conv_o", out)
 
 
-def ffn(sd, p, x, mask, k):
-    """reference attentions.py:438-464: mask, same-pad conv, ReLU, mask, same-pad conv, mask."""
+def ffn(sd, p, x, mask, k, half=False):
+    """reference attentions.py:438-464: mask, same-pad conv, ReLU, mask, same-pad conv, mask.
+    half=True: conv inputs / weights / the hidden activation rounded to fp16, fp32 accumulation + bias."""
     pl, pr = (k - 1) // 2, k // 2
+    if half:
+        h = F.conv1d(F.pad(_h(x * mask), (pl, pr)), _h(sd[p + ".conv_1.weight"]), sd[p + ".conv_1.bias"])
+        h = _h(torch.relu(h) * mask)
+        h = F.conv1d(F.pad(h, (pl, pr)), _h(sd[p + ".conv_2.weight"]), sd[p + ".conv_2.bias"])
+        return h * mask
     h = F.conv1d(F.pad(x * mask, (pl, pr)), sd[p + ".conv_1.weight"], sd[p + ".conv_1.bias"])
     h = torch.relu(h)
     h = F.conv1d(F.pad(h * mask, (pl, pr)), sd[p + ".conv_2.weight"], sd[p + ".conv_2.bias"])
     return h * mask
 
 
-def encoder(sd, p, x, mask, g, n_layers, n_heads, ksize):
+def encoder(sd, p, x, mask, g, n_layers, n_heads, ksize, half=False):
     """attentions.Encoder.forward, reference attentions.py:103-120. mask [B,1,T] float, g [B,gin,1]."""
     x = x * mask
     mbt = mask[:, 0, :]
@@ -116,9 +146,9 @@ def encoder(sd, p, x, mask, g, n_layers, n_heads, ksize):
         if i == COND_LAYER and g is not None:
             gg = F.linear(g.transpose(1, 2), sd[p + ".spk_emb_linear.weight"], sd[p + ".spk_emb_linear.bias"])
             x = (x + gg.transpose(1, 2)) * mask
-        y = rel_attention(sd, f"{p}.attn_layers.{i}", x, mbt, n_heads)
+        y = rel_attention(sd, f"{p}.attn_layers.{i}", x, mbt, n_heads, half)
         x = channel_layer_norm(x + y, sd[f"{p}.norm_layers_1.{i}.gamma"], sd[f"{p}.norm_layers_1.{i}.beta"])
-        y = ffn(sd, f"{p}.ffn_layers.{i}", x, mask, ksize)
+        y = ffn(sd, f"{p}.ffn_layers.{i}", x, mask, ksize, half)
         x = channel_layer_norm(x + y, sd[f"{p}.norm_layers_2.{i}.gamma"], sd[f"{p}.norm_layers_2.{i}.beta"])
     return x * mask
 
@@ -292,7 +322,7 @@ def _fw(sd, prefix, cache):
     return cache[prefix]
 
 
-def flow_reverse(sd, hp, z_p, y_mask, g, fold_cache=None):
+def flow_reverse(sd, hp, z_p, y_mask, g, fold_cache=None, flow_dtype="fp32"):
     """TransformerCouplingBlock / ResidualCouplingBlock reverse: for each coupling, Flip first, then the
     coupling (reference models.py:143-144, 443-444; modules.py:374-381, 561-580, 437-456); mean_only."""
     from_flows = hp.n_flow_layer if hp.use_transformer_flow else 4
@@ -304,7 +334,7 @@ def flow_reverse(sd, hp, z_p, y_mask, g, fold_cache=None):
         x0, x1 = x[:, :half], x[:, half:]
         h = conv1x1(sd, p + ".pre", x0) * y_mask
         if hp.use_transformer_flow:
-            h = encoder(sd, p + ".enc", h, y_mask, g, hp.n_layers_trans_flow, hp.n_heads, 5)
+            h = encoder(sd, p + ".enc", h, y_mask, g, hp.n_layers_trans_flow, hp.n_heads, 5, half=(flow_dtype == "fp16"))
         else:
             h = wn(sd, p + ".enc", h, y_mask, g, hp.n_flow_layer, hp.hidden_channels, 5, 1, fold_cache)
         m = conv1x1(sd, p + ".post", h) * y_mask
@@ -400,7 +430,7 @@ def generator_bf16(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
 @torch.no_grad()
 def infer(sd, hp, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, *, noise_w, noise_z,
           noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8, max_len=None, sdp_ratio=0.0,
-          w_ceil_override=None, fold_cache=None, want_taps=False, generator_dtype="fp32"):
+          w_ceil_override=None, fold_cache=None, want_taps=False, generator_dtype="fp32", flow_dtype="fp32"):
     """reference models.py:1026-1074 with both RNG draws made explicit inputs:
     noise_w [B,2,T] replaces models.py:248-251, noise_z [B,C,>=T_y] replaces randn_like at :1071.
     Returns a dict with the reference's return values plus intermediate taps."""
@@ -416,7 +446,7 @@ def infer(sd, hp, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, *, 
     y_lengths, y_mask, attn, m_e, logs_e = length_regulate(w_ceil, x_mask, m_p, logs_p)
     Ty = y_mask.shape[2]
     z_p = m_e + noise_z[:, :, :Ty] * torch.exp(logs_e) * noise_scale
-    z = flow_reverse(sd, hp, z_p, y_mask, g, fold_cache)
+    z = flow_reverse(sd, hp, z_p, y_mask, g, fold_cache, flow_dtype)
     taps = {} if want_taps else None
     gen = generator_bf16 if generator_dtype == "bf16" else generator
     o = gen(sd, hp, (z * y_mask)[:, :, :max_len], g, fold_cache, taps)

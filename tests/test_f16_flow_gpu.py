@@ -1,0 +1,170 @@
+"""GPU: the fp16 transformer flow (BASELINE config 5 "fp16 flow + fp32 spline"; kernels/enc_f16.hip) — the single kernel in
+its four input/output forms against a torch reference with the SAME rounding points, then the whole flow and infer()
+against the fp16-storage oracle (oracle flow_dtype="fp16"), the fp32 oracle and the reference golden outputs.
+
+Tolerances.  The kernel reference shares every rounding point with the kernel (fp16 inputs/weights, fp32 accumulate), so
+fp32-output forms differ only by summation order (<= 2e-5 of the output scale) and fp16-output forms by rare 1-ulp flips
+(2^-10 relative).  Whole flow: relative RMS of z <= 2e-3 against the fp16 oracle (expected ~1e-4: the attention core and
+LayerNorm are fp32 on both sides) and <= 5e-3 against the fp32 oracle (the fp16-storage oracle itself sits 3e-4 from
+fp32); end to end the waveform must stay inside north_star's 1e-3 absolute RMS of the reference golden output.  Durations
+and the alignment path are exact: everything before the flow is fp32."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import bv2_oracle as O, cases, mel
+from tests.helpers import cached_state_dict, load_golden, rms, valid_wave_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from bert_vits2_amd import lib as L
+    lib = L.load()
+    lib.bv2_test_conv_cl_pack_bytes.restype = C.c_int64
+    lib.bv2_test_conv_cl_pack_bytes.argtypes = [C.c_int] * 3
+    lib.bv2_test_conv_f16.restype = C.c_int
+    lib.bv2_test_conv_f16.argtypes = ([C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p] + [C.c_int] * 10)
+    return lib
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def h16(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+F16_CASES = [
+    # B, cin, cout, k, L, in_ct, out_ct, in_mask, act, res_mode, mask_pre, mask_post, ld_extra
+    (2, 192, 594, 1, 77, 1, 1, 0, 0, 0, 0, 0, 19),      # fused q/k/v (+ relative-key rows): fp32 in, fp32 out, padded rows
+    (1, 192, 192, 1, 384, 1, 1, 0, 0, 1, 0, 0, 0),      # conv_o + residual
+    (2, 192, 768, 5, 200, 1, 0, 1, 1, 0, 0, 1, 0),      # FFN conv_1: masked fp32 in, ReLU + mask, fp16 channels-last out
+    (2, 768, 192, 5, 200, 0, 1, 0, 0, 1, 1, 0, 0),      # FFN conv_2: fp16 in (3 LDS chunks), mask + residual, fp32 out
+    (1, 768, 192, 3, 33, 0, 1, 0, 0, 2, 0, 1, 0),       # reversed residual, short
+    (3, 96, 192, 3, 131, 1, 0, 1, 0, 0, 0, 0, 0),       # narrow input, no activation
+    (1, 320, 100, 5, 1000, 1, 1, 1, 1, 0, 0, 1, 0),     # two uneven chunks (256 + 64), odd cout, 128-wide tiles
+    (16, 192, 768, 5, 384, 1, 0, 1, 1, 0, 0, 1, 0),     # enough columns for the 128-step tile variant
+]
+
+
+@pytest.mark.parametrize("B,cin,cout,k,L,in_ct,out_ct,in_mask,act,res_mode,mask_pre,mask_post,ld_extra", F16_CASES)
+def test_conv_f16_kernel(B, cin, cout, k, L, in_ct, out_ct, in_mask, act, res_mode, mask_pre, mask_post, ld_extra):
+    lib = _lib()
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k + L)
+    x = torch.randn(B, cin, L, generator=g)
+    if not in_ct:
+        x = h16(x)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias = torch.randn(cout, generator=g)
+    lens = torch.randint(L // 2, L + 1, (B,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).float()
+    ld = L + ld_extra
+    r = torch.randn(B, cout, L, generator=g) if res_mode else None
+    xin = h16(x * mask[:, None, :]) if in_mask else h16(x)
+    pl = (k - 1) // 2
+    ref = F.conv1d(F.pad(xin.double(), (pl, k - 1 - pl)), h16(w).double(), bias.double())
+    if act:
+        ref = ref.clamp_min(0)
+    om = mask[:, None, :].double()
+    if mask_pre:
+        ref = ref * om
+    if res_mode == 1:
+        ref = ref + r.double()
+    elif res_mode == 2:
+        ref = r.double() - ref
+    if mask_post:
+        ref = ref * om
+    xd = x.cuda() if in_ct else x.transpose(1, 2).contiguous().to(torch.float16).cuda()
+    md = mask.cuda()
+    if out_ct:
+        out = torch.full((B, cout, ld), float("nan"), device="cuda")
+        rd = None
+        if r is not None:
+            rd = torch.zeros(B, cout, ld, device="cuda")
+            rd[:, :, :L] = r.cuda()
+    else:
+        out = torch.full((B, L, cout), float("nan"), dtype=torch.float16, device="cuda")
+        rd = None
+    wp = torch.empty(lib.bv2_test_conv_cl_pack_bytes(cin, cout, k), dtype=torch.uint8, device="cuda")
+    rc = lib.bv2_test_conv_f16(None, P(xd), in_ct, P(md) if in_mask else None, P(w), P(bias), P(wp), P(out), out_ct, P(rd),
+                               res_mode, P(md) if (mask_pre or mask_post) else None, mask_pre, mask_post, act, B, cin, cout, k, 1,
+                               L, ld)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = (out[:, :, :L] if out_ct else out.float().transpose(1, 2)).cpu().double()
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs()
+    tol = (0.0 if out_ct else 2.0 ** -10) * ref.abs() + 3e-5 * scale
+    assert bool((err <= tol).all()), (err.max().item(), scale, (err > tol).float().mean().item())
+
+
+def _gpu_model(hp, seed):
+    from bert_vits2_amd import models
+    m = models.from_hparams(hp)
+    m.load_state_dict(cached_state_dict(hp, seed), strict=False)
+    return m.to("cuda").eval()
+
+
+def _relrms(a, b):
+    return rms(a - b) / max(rms(b), 1e-30)
+
+
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged"])
+def test_stage_flow_f16_vs_f16_oracle(name):
+    hp, seed, batch, nw, nz, kw = cases.build_case(name)
+    sd = cached_state_dict(hp, seed)
+    ref32 = O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"], batch["bert"],
+                    batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, **kw)
+    with torch.no_grad():
+        z16 = O.flow_reverse(sd, hp, ref32["z_p"], ref32["y_mask"], ref32["g"], None, "fp16")
+    m = _gpu_model(hp, seed)
+    m.set_flow_dtype(torch.float16)
+    z = m.stage_flow(ref32["z_p"], ref32["y_lengths"], ref32["g"])
+    torch.cuda.synchronize()
+    ym = ref32["y_mask"]
+    e16, e32 = _relrms(z.cpu() * ym, z16 * ym), _relrms(z.cpu() * ym, ref32["z"] * ym)
+    print(f"\n[{name}] fp16 flow: rel RMS of z vs fp16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}")
+    assert torch.isfinite(z).all()
+    assert e16 < 2e-3, e16
+    assert e32 < 5e-3, e32
+    # the fp32 path is untouched by the switch
+    m.set_flow_dtype(torch.float32)
+    zf = m.stage_flow(ref32["z_p"], ref32["y_lengths"], ref32["g"])
+    assert _relrms(zf.cpu() * ym, ref32["z"] * ym) < 1e-5
+
+
+@pytest.mark.parametrize("gen", ["fp32", "bf16"])
+def test_infer_f16_flow_end_to_end_vs_reference_golden(gen):
+    name = "mix_b2_ragged"
+    hp, seed, batch, nw, nz, kw = cases.build_case(name)
+    meta, gold = load_golden(name)
+    m = _gpu_model(hp, seed)
+    m.set_flow_dtype(torch.float16)
+    if gen == "bf16":
+        m.set_generator_dtype(torch.bfloat16)
+    args = (batch["x"].cuda(), batch["x_lengths"].cuda(), batch["sid"].cuda(), batch["tone"].cuda(), batch["language"].cuda(),
+            batch["bert"].cuda(), batch["ja_bert"].cuda(), batch["en_bert"].cuda())
+    o, attn, y_mask, (z, z_p, m_p, logs_p) = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), w_ceil=gold["w_ceil"], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(attn.cpu(), gold["attn"])               # durations / path: fp32 front end, exact
+    S = o.shape[2]
+    vm = valid_wave_mask(gold["y_lengths"], hp.total_upsample, S).expand_as(gold["o"])
+    d = (o.cpu() - gold["o"])[vm]
+    rel = rms(d) / rms(gold["o"][vm])
+    ml = mel.mel_l1(o.cpu()[:, 0].numpy(), gold["o"][:, 0].numpy(), gold["y_lengths"].numpy() * hp.total_upsample)
+    ez = _relrms(z.cpu() * gold["y_mask"], gold["z"] * gold["y_mask"])
+    print(f"\n[{name}] fp16 flow + {gen} Generator vs REFERENCE golden: z rel RMS {ez:.3e}, waveform rel RMS {rel:.3e} "
+          f"(abs {rms(d):.3e}), mel-L1 {ml:.3e}")
+    assert ez < 5e-3, ez
+    if gen == "fp32":
+        assert rms(d) < 1e-3, rms(d)                           # north_star: waveform within 1e-3 RMS of the reference
+        assert rel < 5e-3, rel
+    else:
+        assert rel < 5e-2, rel
