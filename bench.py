@@ -30,7 +30,7 @@ from bert_vits2_amd import hparams as H, models, sharding, synth  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix = fp32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA
 PEAK_HBM_GBPS = 8000.0             # same guide: HBM3E
-CONFIGS = {2: dict(batch=1, symbols=128, dtype="f32", flow="f32"), 3: dict(batch=32, symbols=128, dtype="bf16", flow="f16"),
+CONFIGS = {2: dict(batch=1, symbols=128, dtype="f32", flow="f32"), 3: dict(batch=32, symbols=128, dtype="bf16", flow="f16", graph=1),
            5: dict(batch=8, symbols=512, dtype="bf16", flow="f16")}
 GEN_FLOP_PER_FRAME = 651.6e6       # Generator algorithmic FLOPs per latent frame
 
@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--symbols", type=int, default=None, help="symbols per utterance (overrides the config's)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="Generator arithmetic (overrides the config's)")
     ap.add_argument("--flow-dtype", choices=("f32", "f16"), default=None, help="transformer-flow conv arithmetic (overrides the config's)")
+    ap.add_argument("--graph", type=int, default=None, choices=(0, 1),
+                    help="replay each phase as a captured hipGraph (default: the config's setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel family")
@@ -157,6 +159,7 @@ def main():
         model.set_generator_dtype(torch.bfloat16)
     if flow_dtype == "f16":
         model.set_flow_dtype(torch.float16)
+    use_graph = bool(cfgd.get("graph", 0)) if args.graph is None else bool(args.graph)
 
     # ---- this rank's utterances (weak scaling: same per-GPU work, different utterances)
     batch = synth.synthetic_batch([T] * B, first_index=rank * B)
@@ -169,12 +172,13 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    model.enable_graphs(use_graph)
     for i in range(args.warmup):
         out = call()
         if i == 0:
             torch.cuda.synchronize()
             log("first infer() done")
-    model.profile(2)                   # HIP events around the Generator's kernel launches only (dominant family)
+    model.profile(0 if use_graph else 2)   # HIP events around the Generator's kernel launches only (dominant family)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -188,9 +192,21 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
-    prof = model.profile_report()
+    prof = model.profile_report() if not use_graph else None
     model.profile(0)
     Ty = y_mask.shape[2]
+    if use_graph:
+        # events cannot be recorded inside a captured graph: the roofline leg times the same launches in an eager pass
+        # of the same K steps right after the timed (graph-replayed) region
+        model.enable_graphs(False)
+        call()
+        model.profile(2)
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            call()
+        torch.cuda.synchronize()
+        prof = model.profile_report()
+        model.profile(0)
 
     if world > 1:
         import torch.distributed as dist
@@ -261,7 +277,7 @@ def main():
                                  f"transformer flow, synthetic seeded weights, durations pinned to 3 frames/symbol",
                         utterances_per_gpu=B, symbols=T, frames=Ty, parallelism=f"utterance-sharded x{world}",
                         rtf=round(dt / audio_s, 6), x_realtime_per_gpu=round(value / world, 2),
-                        weight_broadcast_ms=round(t_bcast * 1e3, 3)),
+                        hipgraph=use_graph, weight_broadcast_ms=round(t_bcast * 1e3, 3)),
             roofline=roof, cpu_baseline=cpu)
         if full:
             line["kernel_families_untimed_pass"] = full

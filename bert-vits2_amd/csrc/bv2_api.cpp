@@ -1,5 +1,6 @@
 // bv2_api.cpp — the extern "C" surface declared in include/bv2.h.
 #include <cstring>
+#include <functional>
 #include <new>
 
 #include "bv2_internal.h"
@@ -241,6 +242,73 @@ int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const b
   d.noise_z = noise_z; d.nz_bstride = nz_bstride; d.nz_cstride = nz_cstride; d.noise_scale = noise_scale;
   return bv2_decode(h, stream, &d, dec_out, ws, wsb);
   BV2_CATCH(h)
+}
+
+// ---- hipGraph capture -----------------------------------------------------------------------------------------
+struct bv2_graph {
+  hipGraphExec_t exec = nullptr;
+  int nodes = 0;
+};
+
+static int capture_phase(bv2_handle* h, bv2_stream stream, bv2_graph** graph, const char* what,
+                         const std::function<int(hipStream_t)>& run) {
+  if (!graph) { h->err = std::string(what) + ": graph is null"; return -1; }
+  *graph = nullptr;
+  if (!h->blob) { h->err = std::string(what) + ": no weights attached"; return -4; }
+  if (h->prof_on || !h->taps.empty()) { h->err = std::string(what) + ": switch profiling and taps off before capturing"; return -1; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!s) { h->err = std::string(what) + ": capture needs a non-default stream"; return -1; }
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    h->err = std::string(what) + ": hipStreamBeginCapture failed";
+    return -6;
+  }
+  const int rc = run(s);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess || !g) { (void)hipGetLastError(); h->err = std::string(what) + ": hipStreamEndCapture failed"; return -6; }
+  bv2_graph* out = new bv2_graph();
+  size_t n = 0;
+  if (hipGraphGetNodes(g, nullptr, &n) == hipSuccess) out->nodes = (int)n;
+  const hipError_t ei = hipGraphInstantiate(&out->exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ei != hipSuccess) { (void)hipGetLastError(); delete out; h->err = std::string(what) + ": hipGraphInstantiate failed"; return -6; }
+  *graph = out;
+  return 0;
+}
+
+int bv2_graph_capture_encode(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* out, void* ws,
+                             int64_t wsb, bv2_graph** graph) {
+  if (!h) return -1;
+  BV2_TRY
+  if (!in || !out || in->B < 1 || in->T < 1) { h->err = "bv2_graph_capture_encode: bad argument"; return -1; }
+  return capture_phase(h, stream, graph, "bv2_graph_capture_encode",
+                       [&](hipStream_t s) { return run_encode(h, s, *in, *out, ws, wsb); });
+  BV2_CATCH(h)
+}
+
+int bv2_graph_capture_decode(bv2_handle* h, bv2_stream stream, const bv2_decode_in* in, const bv2_decode_out* out, void* ws,
+                             int64_t wsb, bv2_graph** graph) {
+  if (!h) return -1;
+  BV2_TRY
+  if (!in || !out || in->B < 1 || in->T < 1 || in->Ty < 1 || !out->o) { h->err = "bv2_graph_capture_decode: bad argument"; return -1; }
+  return capture_phase(h, stream, graph, "bv2_graph_capture_decode",
+                       [&](hipStream_t s) { return run_decode(h, s, *in, *out, ws, wsb); });
+  BV2_CATCH(h)
+}
+
+int bv2_graph_launch(bv2_graph* g, bv2_stream stream) {
+  if (!g || !g->exec) return -1;
+  return hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -6;
+}
+
+int bv2_graph_num_nodes(const bv2_graph* g) { return g ? g->nodes : -1; }
+
+void bv2_graph_destroy(bv2_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  delete g;
 }
 
 int bv2_set_tap(bv2_handle* h, const char* name, float* dev_dst, int64_t cap) {

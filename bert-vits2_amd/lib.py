@@ -89,6 +89,11 @@ SYMBOLS = [
     ("bv2_stage_generator", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
     ("bv2_infer", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.c_int64, C.c_float,
                             C.c_int32, C.c_int32, C.POINTER(DecodeOut), C.POINTER(C.c_int32), _P, C.c_int64]),
+    ("bv2_graph_capture_encode", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.POINTER(_P)]),
+    ("bv2_graph_capture_decode", C.c_int, [_P, _P, C.POINTER(DecodeIn), C.POINTER(DecodeOut), _P, C.c_int64, C.POINTER(_P)]),
+    ("bv2_graph_launch", C.c_int, [_P, _P]),
+    ("bv2_graph_num_nodes", C.c_int, [_P]),
+    ("bv2_graph_destroy", None, [_P]),
     ("bv2_set_tap", C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     ("bv2_profile_enable", C.c_int, [_P, C.c_int]),
     ("bv2_profile_reset", C.c_int, [_P]),

@@ -72,6 +72,9 @@ class SynthesizerTrn(nn.Module):
         self._taps: Dict[str, torch.Tensor] = {}
         self.generator_dtype = torch.float32
         self.flow_dtype = torch.float32
+        self._graphs_on = False
+        self._graphs: Dict[tuple, dict] = {}
+        self._cap_stream = None
 
     # ------------------------------------------------------------------ parameter tree
     def _register(self, key: str, value: torch.Tensor) -> None:
@@ -123,6 +126,7 @@ class SynthesizerTrn(nn.Module):
 
     def __del__(self):
         try:
+            self._drop_graphs()
             if self._lib is not None and self._handle:
                 self._lib.bv2_destroy(self._handle)
         except Exception:
@@ -148,6 +152,7 @@ class SynthesizerTrn(nn.Module):
         assert dev_blob.is_cuda and dev_blob.dtype == torch.uint8 and dev_blob.is_contiguous()
         self._check(lib.bv2_attach_weights(self._handle, C.c_void_p(dev_blob.data_ptr()), dev_blob.numel()),
                     "bv2_attach_weights")
+        self._drop_graphs()
         self._blob = dev_blob
 
     def repack(self) -> None:
@@ -168,6 +173,7 @@ class SynthesizerTrn(nn.Module):
         if code is None:
             raise ValueError("generator dtype must be torch.float32 or torch.bfloat16")
         self._check(lib.bv2_set_generator_dtype(self._handle, code), "bv2_set_generator_dtype")
+        self._drop_graphs()
         self.generator_dtype = torch.bfloat16 if code == L.BF16 else torch.float32
 
     def set_flow_dtype(self, dtype) -> None:
@@ -180,6 +186,7 @@ class SynthesizerTrn(nn.Module):
         if code is None:
             raise ValueError("flow dtype must be torch.float32 or torch.float16")
         self._check(lib.bv2_set_flow_dtype(self._handle, code), "bv2_set_flow_dtype")
+        self._drop_graphs()
         self.flow_dtype = torch.float16 if code == L.F16 else torch.float32
 
     def _workspace(self, B: int, T: int, Ty: int) -> torch.Tensor:
@@ -187,8 +194,44 @@ class SynthesizerTrn(nn.Module):
         if n < 0:
             raise RuntimeError("bv2_workspace_bytes failed")
         if self._ws is None or self._ws.numel() < n or self._ws.device != self.device:
+            self._drop_graphs()                    # captured graphs bake in the workspace address
             self._ws = torch.empty(int(n * 1.25), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    # ------------------------------------------------------------------ hipGraph replay of the two phases
+    def enable_graphs(self, on: bool = True) -> None:
+        """Record each phase once per shape as a hipGraph (``bv2_graph_capture_*``) and replay it on later calls: one
+        ``hipGraphLaunch`` per phase instead of ~270 kernel launches.  Inputs are copied into buffers the graph owns, so
+        results are identical to the eager path; outputs are returned as fresh tensors."""
+        self._graphs_on = bool(on)
+        if not on:
+            self._drop_graphs()
+
+    def _drop_graphs(self) -> None:
+        graphs, self._graphs = getattr(self, "_graphs", {}), {}
+        for g in graphs.values():
+            if self._lib is not None and g.get("graph"):
+                self._lib.bv2_graph_destroy(g["graph"])
+
+    def _capture(self, fn, *args):
+        """Run one capture call on a dedicated non-default stream (the legacy default stream cannot be captured)."""
+        dev = self.device
+        if self._cap_stream is None or self._cap_stream.device != dev:
+            self._cap_stream = torch.cuda.Stream(device=dev)
+        torch.cuda.current_stream(dev).synchronize()      # buffers the graph will touch are idle while it is recorded
+        g = C.c_void_p()
+        self._check(fn(self._handle, C.c_void_p(self._cap_stream.cuda_stream), *args, C.byref(g)), fn.__name__)
+        return g
+
+    def _graph_entry(self, key, build):
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 16:                   # bounded cache: drop the oldest shape
+                old = next(iter(self._graphs))
+                self._lib.bv2_graph_destroy(self._graphs.pop(old)["graph"])
+            ent = build()
+            self._graphs[key] = ent
+        return ent
 
     def set_tap(self, name: Optional[str], tensor: Optional[torch.Tensor] = None) -> None:
         """Debug: copy a named intermediate into ``tensor`` (fp32, CUDA) during the next calls."""
@@ -223,13 +266,38 @@ class SynthesizerTrn(nn.Module):
             raise ValueError("noise_w must be [B,2,T]")
         hp = self.hp
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        out = dict(g=e(B, hp.gin_channels), x=e(B, hp.hidden_channels, T), m_p=e(B, hp.inter_channels, T),
-                   logs_p=e(B, hp.inter_channels, T), x_mask=e(B, T), logw_sdp=e(B, T), logw_dp=e(B, T), logw=e(B, T),
-                   w_ceil=e(B, T), y_lengths=torch.empty(B, dtype=torch.int64, device=dev))
+        okeys = ("g", "x", "m_p", "logs_p", "x_mask", "logw_sdp", "logw_dp", "logw", "w_ceil", "y_lengths")
+        mk_out = lambda: dict(g=e(B, hp.gin_channels), x=e(B, hp.hidden_channels, T), m_p=e(B, hp.inter_channels, T),
+                              logs_p=e(B, hp.inter_channels, T), x_mask=e(B, T), logw_sdp=e(B, T), logw_dp=e(B, T),
+                              logw=e(B, T), w_ceil=e(B, T), y_lengths=torch.empty(B, dtype=torch.int64, device=dev))
+        if self._graphs_on and not self._taps:
+            ws = self._workspace(B, T, 1)
+            ins = dict(x=x, x_lengths=x_lengths, sid=sid, tone=tone, language=language, bert=bert, ja_bert=ja_bert,
+                       en_bert=en_bert, noise_w=noise_w)
+
+            def build():
+                sin = {k: torch.empty_like(v) for k, v in ins.items()}
+                sout = mk_out()
+                ein = L.EncodeIn(B, T, *[_ptr(sin[k]) for k in ("x", "x_lengths", "sid", "tone", "language", "bert", "ja_bert",
+                                                                "en_bert", "noise_w")],
+                                 float(noise_scale_w), float(sdp_ratio), float(length_scale))
+                eout = L.EncodeOut(*[_ptr(sout[k]) for k in okeys])
+                with torch.cuda.device(dev):
+                    g = self._capture(self._lib.bv2_graph_capture_encode, C.byref(ein), C.byref(eout),
+                                      C.c_void_p(ws.data_ptr()), ws.numel())
+                return dict(graph=g, sin=sin, sout=sout)
+
+            ent = self._graph_entry(("A", B, T, float(noise_scale_w), float(sdp_ratio), float(length_scale)), build)
+            for k, v in ins.items():
+                ent["sin"][k].copy_(v)
+            with torch.cuda.device(dev):
+                if self._lib.bv2_graph_launch(ent["graph"], C.c_void_p(torch.cuda.current_stream().cuda_stream)):
+                    raise RuntimeError("bv2_graph_launch (encode) failed")
+            return {k: v.clone() for k, v in ent["sout"].items()}
+        out = mk_out()
         ein = L.EncodeIn(B, T, _ptr(x), _ptr(x_lengths), _ptr(sid), _ptr(tone), _ptr(language), _ptr(bert), _ptr(ja_bert),
                          _ptr(en_bert), _ptr(noise_w), float(noise_scale_w), float(sdp_ratio), float(length_scale))
-        eout = L.EncodeOut(*[_ptr(out[k]) for k in ("g", "x", "m_p", "logs_p", "x_mask", "logw_sdp", "logw_dp", "logw",
-                                                    "w_ceil", "y_lengths")])
+        eout = L.EncodeOut(*[_ptr(out[k]) for k in okeys])
         ws = self._workspace(B, T, 1)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -249,12 +317,38 @@ class SynthesizerTrn(nn.Module):
         L_dec = Ty if (max_len is None or max_len <= 0 or max_len >= Ty) else int(max_len)
         S = L_dec * hp.total_upsample
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        out = dict(o=e(B, 1, S), attn=e(B, 1, Ty, T) if want_attn else None, y_mask=e(B, 1, Ty), z=e(B, Ci, Ty),
-                   z_p=e(B, Ci, Ty), m_p=e(B, Ci, Ty), logs_p=e(B, Ci, Ty))
+        okeys = ("o", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")
+        mk_out = lambda: dict(o=e(B, 1, S), attn=e(B, 1, Ty, T) if want_attn else None, y_mask=e(B, 1, Ty), z=e(B, Ci, Ty),
+                              z_p=e(B, Ci, Ty), m_p=e(B, Ci, Ty), logs_p=e(B, Ci, Ty))
+        if self._graphs_on and not self._taps:
+            ws = self._workspace(B, T, Ty)
+            ikeys = ("m_p", "logs_p", "x_mask", "w_ceil", "y_lengths", "g")
+
+            def build():
+                sin = {k: torch.empty_like(enc[k]) for k in ikeys}
+                sin["noise_z"] = torch.empty(B, Ci, Ty, dtype=torch.float32, device=dev)
+                sout = mk_out()
+                din = L.DecodeIn(B, T, int(Ty), int(L_dec), *[_ptr(sin[k]) for k in ikeys], _ptr(sin["noise_z"]),
+                                 sin["noise_z"].stride(0), sin["noise_z"].stride(1), float(noise_scale))
+                dout = L.DecodeOut(*[_ptr(sout[k]) for k in okeys])
+                with torch.cuda.device(dev):
+                    g = self._capture(self._lib.bv2_graph_capture_decode, C.byref(din), C.byref(dout),
+                                      C.c_void_p(ws.data_ptr()), ws.numel())
+                return dict(graph=g, sin=sin, sout=sout)
+
+            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale)), build)
+            for k in ikeys:
+                ent["sin"][k].copy_(enc[k])
+            ent["sin"]["noise_z"].copy_(noise_z[:, :, :Ty])
+            with torch.cuda.device(dev):
+                if self._lib.bv2_graph_launch(ent["graph"], C.c_void_p(torch.cuda.current_stream().cuda_stream)):
+                    raise RuntimeError("bv2_graph_launch (decode) failed")
+            return {k: (None if v is None else v.clone()) for k, v in ent["sout"].items()}
+        out = mk_out()
         din = L.DecodeIn(B, T, int(Ty), int(L_dec), _ptr(enc["m_p"]), _ptr(enc["logs_p"]), _ptr(enc["x_mask"]),
                          _ptr(enc["w_ceil"]), _ptr(enc["y_lengths"]), _ptr(enc["g"]), _ptr(noise_z),
                          noise_z.stride(0), noise_z.stride(1), float(noise_scale))
-        dout = L.DecodeOut(*[_ptr(out[k]) for k in ("o", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")])
+        dout = L.DecodeOut(*[_ptr(out[k]) for k in okeys])
         ws = self._workspace(B, T, Ty)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -176,6 +176,23 @@ int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const b
               const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, float noise_scale, int32_t max_len,
               int32_t Ty_cap, const bv2_decode_out* dec_out, int32_t* Ty_out, void* workspace, int64_t workspace_bytes);
 
+/* ---- hipGraph capture (BASELINE config 3: "hipGraph-captured decode") ----------------------------------------- */
+/* Both phases are fixed launch sequences on the caller's stream with no allocation, host sync or device->host copy,
+ * so they can be recorded once and replayed: bv2_graph_capture_* puts `stream` (which must NOT be the legacy default
+ * stream) into capture mode, records the phase exactly as bv2_encode_durations / bv2_decode would launch it, and
+ * instantiates an executable graph.  The graph bakes in every pointer and scalar of in/out/workspace: the caller keeps
+ * those buffers alive and at the same addresses (refill the inputs in place before each replay) and re-captures when a
+ * shape (B, T, Ty, max_len), a scalar argument or a dtype switch changes.  bv2_graph_launch replays on any stream.
+ * Taps and profiling must be off while capturing. */
+typedef struct bv2_graph bv2_graph;
+int bv2_graph_capture_encode(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* out,
+                             void* workspace, int64_t workspace_bytes, bv2_graph** graph);
+int bv2_graph_capture_decode(bv2_handle* h, bv2_stream stream, const bv2_decode_in* in, const bv2_decode_out* out,
+                             void* workspace, int64_t workspace_bytes, bv2_graph** graph);
+int bv2_graph_launch(bv2_graph* graph, bv2_stream stream);
+int bv2_graph_num_nodes(const bv2_graph* graph);
+void bv2_graph_destroy(bv2_graph* graph);
+
 /* ---- debugging / measurement ------------------------------------------------------------------------------ */
 /* Ask the executor to copy a named intermediate (e.g. "dec.ups.0", "dec.stage.2", "flow.3.h", "enc.layer.1")
  * into dev_dst (capacity in floats) the next time it is produced.  name==NULL clears all taps. */
