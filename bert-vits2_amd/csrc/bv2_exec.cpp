@@ -705,7 +705,32 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     }
     tap_cl("dec.ups." + std::to_string(i), x, U.cout, Lo);
     const int nb = m.n_rbk;
-    for (int d = 0; d < m.n_rbd; ++d) {
+    bool whole = nb <= 3 && !getenv("BV2_NO_FUSED_RESBLOCK");
+    for (int j = 0; j < nb && whole; ++j) whole = m.rbcl_w_off[i][j] >= 0;
+    if (whole) {
+      // narrow stages: every branch's whole ResBlock (all dilation pairs) in ONE launch, intermediates in LDS
+      RbClLaunch F;
+      std::memset(&F, 0, sizeof(F));
+      F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.nd = m.n_rbd; F.slope = 0.1f;
+      for (int jj = 0; jj < nb; ++jj) {
+        const int j = nb - 1 - jj;                                // widest kernel first
+        RbClProb& p = F.p[jj];
+        p.x = x; p.out = U16(S[1 + j]);
+        p.w = reinterpret_cast<const uint16_t*>(c.W(m.rbcl_w_off[i][j])); p.bias = c.W(m.rbcl_b_off[i][j]);
+        p.k = cf.resblock_kernel_sizes[j];
+        for (int d = 0; d < m.n_rbd; ++d) p.dil[d] = cf.resblock_dilation_sizes[j][d];
+      }
+      if (!c.rc) {
+        const int pi = c.prof_begin("dec.resblock.whole");
+        if (pi >= 0 && c.h->prof_mode == 3)
+          c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
+                        std::to_string(Lo) + " B" + std::to_string(B);
+        const int r = launch_resblock_cl_bf16(c.s, F);
+        c.prof_end(pi, "resblock_cl_bf16", resblock_cl_bf16_flops(F), resblock_cl_bf16_bytes(F));
+        if (r) c.fail("dec.resblock.whole", r);
+      }
+    }
+    for (int d = 0; d < m.n_rbd && !whole; ++d) {
       ClLaunch c1, c2;
       c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
       for (int jj = 0; jj < nb; ++jj) {

@@ -94,6 +94,9 @@ struct Model {
   int n_ups = 0, n_rbk = 0, n_rbd = 0;
   UpW ups[BV2_MAX_UPS];
   ConvW rb[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS][BV2_MAX_RESBLOCK_DILATIONS][2];
+  // whole-ResBlock bf16 streams of the narrow stages (kernels/resblock_cl_bf16.hip); -1 where the stage is too wide
+  int64_t rbcl_w_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
+  int64_t rbcl_b_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
   VecW conv_post;
   int post_c = 0, post_k = 7;
   int total_up = 1;

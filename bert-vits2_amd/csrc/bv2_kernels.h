@@ -135,6 +135,21 @@ inline int64_t cl_w_index(int j, int ci, int co, int cin, int k) {
 inline int64_t cl_w_elems(int cin, int cout_pad, int k) { return (int64_t)(cout_pad / 32) * (cin / 16) * k * 512; }
 double conv_cl_bytes(const ClLaunch& L);
 
+// a whole ResBlock1 (nd (dilated conv, conv) pairs with residuals) of a narrow Generator stage in one launch, bf16
+// channels-last, intermediates in LDS (kernels/resblock_cl_bf16.hip).  x / out: [B][L][C], C = 16 or 32, out != x.
+//   w    : ONE contiguous bf16 fragment stream [d][conv e][unit u < Upad][lane][8]  (unit = cl_w_index order of m-tile 0,
+//          Upad = resblock_cl_bf16_units(C, k) = (C/16)*k rounded up to RBCL_PD, padding units zero) + RBCL_PD tail units
+//   bias : fp32 [2*nd][32]  (row 2d+e = bias of conv e of pair d, zero padded to 32)
+#define BV2_RBCL_MAX_D 4
+constexpr int RBCL_PD = 8;        // weight ring depth = unit padding of the stream
+struct RbClProb { const uint16_t* x; uint16_t* out; const uint16_t* w; const float* bias; int k; int dil[BV2_RBCL_MAX_D]; int halo; };
+struct RbClLaunch { RbClProb p[3]; int nprob, B, C, L, nd; float slope; };
+bool resblock_cl_bf16_supported(int C, int k, const int* dil, int nd);
+int resblock_cl_bf16_units(int C, int k);
+int launch_resblock_cl_bf16(hipStream_t stream, const RbClLaunch& L);
+double resblock_cl_bf16_flops(const RbClLaunch& L);
+double resblock_cl_bf16_bytes(const RbClLaunch& L);
+
 // z[b][c][t] * mask[b][t] (fp32, channel stride z_rstride) -> bf16 channels-last out[b][t][c], t < L
 int launch_cast_cl(hipStream_t stream, const float* z, int z_rstride, int64_t z_bstride, const float* mask, int mask_bstride,
                    uint16_t* out, int B, int C, int L);

@@ -403,6 +403,24 @@ int pack_all(Model& m, Packer& P) {
         m.rb[i][j][d][0] = P.conv1d(rp + ".convs1." + std::to_string(d), ch, ch, k, true, true);
         m.rb[i][j][d][1] = P.conv1d(rp + ".convs2." + std::to_string(d), ch, ch, k, true, true);
       }
+      // narrow stages: the 2*n_rbd convs of the block once more as ONE contiguous bf16 stream (+ one bias block) for the
+      // whole-ResBlock kernel; copied out of the per-conv streams just written (m-tile 0 = the whole channel dim)
+      m.rbcl_w_off[i][j] = m.rbcl_b_off[i][j] = -1;
+      if (m.n_rbd <= BV2_RBCL_MAX_D && resblock_cl_bf16_supported(ch, k, c.resblock_dilation_sizes[j], m.n_rbd)) {
+        const int U = (ch / 16) * k, Upad = resblock_cl_bf16_units(ch, k);
+        m.rbcl_w_off[i][j] = P.alloc(((int64_t)(2 * m.n_rbd * Upad + RBCL_PD) * 512 + 1) / 2);
+        m.rbcl_b_off[i][j] = P.alloc((int64_t)2 * m.n_rbd * 32);
+        if (P.fill()) {
+          uint16_t* dst = reinterpret_cast<uint16_t*>(P.blob + m.rbcl_w_off[i][j]);
+          for (int d = 0; d < m.n_rbd; ++d)
+            for (int e = 0; e < 2; ++e) {
+              const ConvW& cw = m.rb[i][j][d][e];
+              std::memcpy(dst + (int64_t)(2 * d + e) * Upad * 512, reinterpret_cast<const uint16_t*>(P.blob + cw.wb_off),
+                          sizeof(uint16_t) * (size_t)U * 512);
+              std::memcpy(P.blob + m.rbcl_b_off[i][j] + (2 * d + e) * 32, P.blob + cw.b_off, sizeof(float) * (size_t)ch);
+            }
+        }
+      }
     }
   }
   P.emit_bf16 = false;
