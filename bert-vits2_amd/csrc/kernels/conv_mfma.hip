@@ -41,7 +41,7 @@ __device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
 
 
 template <int WM, int WN, int MI, int NI, int CK, int XS>
-__global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles) {
+__global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles, const int per_xcd) {
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
   constexpr int XP = XS * 64;                     // X tile row pitch (floats)
@@ -60,7 +60,13 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   const int wm = wid / WN, wn = wid % WN;
   const int b = blockIdx.y / mtiles;
   const int m0 = (blockIdx.y - b * mtiles) * BM;
-  const int t0 = blockIdx.x * BN;
+  // XCD-aware placement: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), gridDim.x is a multiple
+  // of 8, so XCD = blockIdx.x % 8 for every (y, z).  Give each XCD a CONTIGUOUS range of time tiles: neighbouring tiles
+  // share (k-1)*dil halo columns (up to 50 of 64) and the C_out/BM sibling tiles share the whole X tile — in one L2 those
+  // re-reads are hits instead of a second fetch from HBM.
+  const int vt = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int t0 = vt * BN;
+  if (t0 >= L.L) return;
   if (m0 >= P.cout_pad) return;                   // problems in one launch may have different C_out
 
   // problem fields used in the main loop, hoisted into registers (P lives in the kernarg segment; re-reading it costs
@@ -440,20 +446,21 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int m
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   if (BN + max_extra > XS * 64) return -2;        // halo does not fit the staged tile
   const int mtiles = (max_cout_pad + BM - 1) / BM;
-  dim3 grid((L.L + BN - 1) / BN, mtiles * L.B, L.nprob);
+  const int per_xcd = ((L.L + BN - 1) / BN + 7) / 8;
+  dim3 grid(per_xcd * 8, mtiles * L.B, L.nprob);
   const int nxbuf = max_chunks > 1 ? 2 : 1;     // a single-chunk problem never re-stages its X tile
   if (ck == 32) {
     const size_t lds = sizeof(float) * (size_t)(2 * 8 * BM * 4 + 2 * 32 * XS * 64);
     const size_t lds1 = sizeof(float) * (size_t)(2 * 8 * BM * 4 + nxbuf * 32 * XS * 64);
     auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 32, XS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles, per_xcd);
   } else {
     const size_t lds = sizeof(float) * (size_t)(2 * 4 * BM * 4 + 2 * 16 * XS * 64);
     const size_t lds1 = sizeof(float) * (size_t)(2 * 4 * BM * 4 + nxbuf * 16 * XS * 64);
     auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 16, XS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles, per_xcd);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -568,15 +575,20 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     // latency is also hidden by the co-resident workgroups.  BV2_TILE_TARGET overrides (tuning experiments).
     static const long target = [] { const char* e = getenv("BV2_TILE_TARGET"); return e ? atol(e) : 1536L; }();
     tile = TILE_32x128;
-    long best_blocks = -1;
+    double best_score = -1.0;
     bool reached = false;
     for (const TileCfg& t : kTiles) {
       if (t.bm > max_cout_pad && t.bm != 32) continue;
       if (max_cout_pad % t.bm && t.bm != 32) continue;
       if (t.bn + max_extra > t.xs * 64) continue;
-      const long blocks = (long)((L.L + t.bn - 1) / t.bn) * ((max_cout_pad + t.bm - 1) / t.bm) * L.B * L.nprob;
-      if (blocks >= target) { tile = t.id; reached = true; break; }
-      if (blocks > best_blocks) { best_blocks = blocks; tile = t.id; }   // nothing reaches the target: most workgroups, largest first
+      const long nb = (L.L + t.bn - 1) / t.bn;
+      const long blocks = nb * ((max_cout_pad + t.bm - 1) / t.bm) * L.B * L.nprob;
+      // tiles never span batch items: the fraction of a tile row that holds real columns (L = 128 under a 256-wide tile
+      // leaves half of every workgroup idle)
+      const double useful = (double)L.L / (double)(nb * t.bn);
+      if (blocks >= target && useful >= 0.75) { tile = t.id; reached = true; break; }
+      const double score = (double)(blocks < target ? blocks : target) * useful;
+      if (score > best_score) { best_score = score; tile = t.id; }   // nothing reaches the target: most useful workgroups, largest first
     }
     (void)reached;
   }

@@ -16,6 +16,8 @@
 // wave streams its weight fragments global -> registers through an 8-deep ring (1 KB units, L2-resident, contiguous per
 // 32-channel output tile) and reads B fragments from LDS one unit ahead of the MFMAs.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "../bv2_kernels.h"
 
 namespace bv2 {
@@ -36,8 +38,6 @@ __device__ __forceinline__ unsigned bf_pack(float a, float b) {     // round-to-
 }
 
 constexpr int CL_PD = 8;          // weight prefetch ring depth (units of 4 MFMAs)
-constexpr int CL_NI = 4;          // 32-column time tiles per wave
-constexpr int CL_WT = CL_NI * 32; // time steps per wave
 
 // Stage rows [tb, tb + rows) x cin channels of up to 3 sources into LDS (pitch in elements), applying
 // pre(v) = bf16(lrelu(in_scale * sum)).  Rows outside [0, Lin) are zero (the conv's padding).
@@ -90,48 +90,59 @@ __device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const ui
   }
 }
 
-// acc[ni] += sum over units u = (s, j) of Wfrag(u) x B(u, ni);  B(u, ni) = 8 channels [16s + 8lh, +8) of LDS row
-// (ni*32 + l31 + j*tstep) relative to xb.  wp points at this wave's contiguous weight stream (+ lane*8 elements).
-__device__ __forceinline__ void cl_gemm(f32x16 (&acc)[CL_NI], const uint16_t* wp, int U, int k, const unsigned short* xb,
-                                        int pitch, int tstep) {
-  bf16x8 ar[CL_PD];
+// acc[mi][ni] += sum over units u = (s, j) of Wfrag(mi, u) x B(u, ni);  B(u, ni) = 8 channels [16s + 8lh, +8) of LDS row
+// (ni*32 + l31 + j*tstep) relative to xb.  wp points at the wave's FIRST m-tile's contiguous weight stream (+ lane*8
+// elements); m-tile mi's stream starts mstride elements later.  Register blocking MI x NI: every B fragment read from LDS
+// feeds MI MFMAs and every A fragment NI MFMAs (at MI = 1 the B reads alone need the full 128 B/clk LDS bandwidth at the
+// MFMA issue rate).
+template <int MI, int NI, int PD>
+__device__ __forceinline__ void cl_gemm(f32x16 (&acc)[MI][NI], const uint16_t* wp, int64_t mstride, int U, int k,
+                                        const unsigned short* xb, int pitch, int tstep) {
+  bf16x8 ar[PD][MI];
   int lu = 0;
   auto load_unit = [&](int slot) __attribute__((always_inline)) {
     const int uc = lu < U ? lu : U - 1;                             // past the end: re-read the last unit, result unused
-    ar[slot] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)uc * 512);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) ar[slot][mi] = *reinterpret_cast<const bf16x8*>(wp + mi * mstride + (int64_t)uc * 512);
     ++lu;
   };
 #pragma unroll
-  for (int i = 0; i < CL_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
-  bf16x8 bb[2][CL_NI];                            // B fragments of the current / next unit (parity of the ring slot)
+  for (int i = 0; i < PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  bf16x8 bb[2][NI];                               // B fragments of the current / next unit (parity of the ring slot)
 #pragma unroll
-  for (int ni = 0; ni < CL_NI; ++ni) bb[0][ni] = *reinterpret_cast<const bf16x8*>(xb + ni * 32 * pitch);
+  for (int ni = 0; ni < NI; ++ni) bb[0][ni] = *reinterpret_cast<const bf16x8*>(xb + ni * 32 * pitch);
   int s = 0, j = 0;
-  for (int u0 = 0; u0 < U; u0 += CL_PD) {
+  for (int u0 = 0; u0 < U; u0 += PD) {
 #pragma unroll
-    for (int i = 0; i < CL_PD; ++i) {
+    for (int i = 0; i < PD; ++i) {
       if (u0 + i < U) {
         int jn = j + 1, sn = s;
         if (jn == k) { jn = 0; ++sn; }
         const bool more = u0 + i + 1 < U;
         const unsigned short* xn = xb + (more ? jn : j) * tstep * pitch + (more ? sn : s) * 16;
 #pragma unroll
-        for (int ni = 0; ni < CL_NI; ++ni) bb[(i & 1) ^ 1][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * pitch);
+        for (int ni = 0; ni < NI; ++ni) bb[(i & 1) ^ 1][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * pitch);
 #pragma unroll
-        for (int ni = 0; ni < CL_NI; ++ni)
-          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], bb[i & 1][ni], acc[ni], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i][mi], bb[i & 1][ni], acc[mi][ni], 0, 0, 0);
         j = jn; s = sn;
       }
       load_unit(i);
-      __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay CL_PD - 1 units
+      __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay PD - 1 units
     }
   }
 }
 
-template <int WN, int WM>
+// workgroup = WN x WM waves; wave (wn, wm) owns MI 32-channel output tiles starting at 32*MI*(cg*WN + wn) and NI 32-step
+// time tiles starting at t0 + 32*NI*wm
+template <int WN, int WM, int MI, int NI>
 __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
   constexpr int NT = 64 * WN * WM;
-  constexpr int BT = WM * CL_WT;
+  constexpr int WT = 32 * NI;
+  constexpr int BT = WM * WT;
+  constexpr int PD = MI == 1 ? CL_PD : CL_PD / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
   const ClProb& P = L.p[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -140,73 +151,129 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
   const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y / ngrp;
   const int cg = blockIdx.y - b * ngrp;
-  const int mt = cg * WN + wn;
+  const int mt0 = (cg * WN + wn) * MI;
   const int t0 = blockIdx.x * BT;
   const int cin = P.cin, k = P.k, dil = P.dil;
-  if (cg * WN * 32 >= P.cout_pad) return;         // whole workgroup beyond this problem's channels (uniform: before the barrier)
+  if (cg * WN * MI * 32 >= P.cout_pad) return;    // whole workgroup beyond this problem's channels (uniform: before the barrier)
   const int pitch = cin + 8;
   cl_stage<NT>(xs, pitch, P.x[0] + (int64_t)b * P.x_bstride, P.x[1] ? P.x[1] + (int64_t)b * P.x_bstride : nullptr,
                P.x[2] ? P.x[2] + (int64_t)b * P.x_bstride : nullptr, P.nsrc, P.in_scale, P.pre_lrelu != 0, P.slope,
                t0 - P.pad_left, BT + (k - 1) * dil, cin, P.Lin, tid);
   __syncthreads();
-  if (mt * 32 >= P.cout_pad) return;              // no further barriers below
+  const bool active = mt0 * 32 < P.cout_pad;      // waves beyond this problem's channels still join the epilogue barriers
 
-  f32x16 acc[CL_NI];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int ni = 0; ni < CL_NI; ++ni)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
   const int U = (cin >> 4) * k;
-  cl_gemm(acc, P.w + (int64_t)mt * U * 512 + lane * 8, U, k, xs + (wm * CL_WT + l31) * pitch + lh * 8, pitch, dil);
+  // a wave whose second m-tile lies beyond cout_pad streams the first one twice (results of the copy are dropped)
+  const int64_t mstride = (MI > 1 && (mt0 + 1) * 32 < P.cout_pad) ? (int64_t)U * 512 : 0;
+  if (active)
+    cl_gemm<MI, NI, PD>(acc, P.w + (int64_t)mt0 * U * 512 + lane * 8, mstride, U, k, xs + (wm * WT + l31) * pitch + lh * 8,
+                        pitch, dil);
 
-  // epilogue: lane = time step, register group g = 4 consecutive output channels
+  // ---- epilogue through LDS.  In the D fragment a lane holds 4 consecutive channels of ONE time step, i.e. 8-byte pieces
+  // 2*C bytes apart in HBM: stored (and, for the residual, loaded) directly, every wave instruction touches 32 different
+  // rows.  Instead the workgroup's output tile [BT][WGC channels] is assembled in LDS (the input tile is dead by now) and
+  // moved to / from HBM in 16-byte pieces along the rows: consecutive lanes hit consecutive addresses.
+  constexpr int WGC = WN * MI * 32;               // channels per workgroup
+  constexpr int OP = WGC + 8;                     // LDS pitch of the output tile (odd multiple of 16 B)
   const int cout = P.cout;
-#pragma unroll
-  for (int ni = 0; ni < CL_NI; ++ni) {
-    const int t = t0 + wm * CL_WT + ni * 32 + l31;
-    if (t >= L.L) continue;
-    const int64_t row = (int64_t)t * cout;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = mt * 32 + 8 * g + 4 * lh;
-      if (co >= cout) continue;
-      float v0 = acc[ni][4 * g], v1 = acc[ni][4 * g + 1], v2 = acc[ni][4 * g + 2], v3 = acc[ni][4 * g + 3];
-      if (P.bias) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + co);
-        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
-      }
-      if (P.bias2) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias2 + (int64_t)b * P.bias2_bstride + co);
-        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
-      }
-      if (P.res) {
-        const u32x2 rr = *reinterpret_cast<const u32x2*>(P.res + (int64_t)b * P.res_bstride + row + co);
-        v0 += bf_lo(rr.x); v1 += bf_hi(rr.x); v2 += bf_lo(rr.y); v3 += bf_hi(rr.y);
-      }
-      u32x2 o;
-      o.x = bf_pack(v0, v1); o.y = bf_pack(v2, v3);
-      *reinterpret_cast<u32x2*>(P.out + (int64_t)b * P.out_bstride + row + co) = o;
+  const int ch0 = cg * WGC;
+  const int wch = cout - ch0 < WGC ? cout - ch0 : WGC;             // valid channels of this workgroup (multiple of 8)
+  const int rows = L.L - t0 < BT ? L.L - t0 : BT;
+  const int ppr = wch >> 3;
+  __syncthreads();                                // every wave is done reading the input tile
+  if (P.res) {
+    const uint16_t* rg = P.res + (int64_t)b * P.res_bstride + (int64_t)t0 * cout + ch0;
+    for (int p = tid; p < rows * ppr; p += NT) {
+      const int r = p / ppr, c = p - r * ppr;
+      *reinterpret_cast<u32x4*>(xs + r * OP + c * 8) = *reinterpret_cast<const u32x4*>(rg + (int64_t)r * cout + c * 8);
     }
+    __syncthreads();
+  }
+  if (active) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      if (mi > 0 && (mt0 + mi) * 32 >= P.cout_pad) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int tr = wm * WT + ni * 32 + l31;   // row inside the tile
+        if (tr >= rows) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = (wn * MI + mi) * 32 + 8 * g + 4 * lh;     // channel inside the workgroup's range
+          const int co = ch0 + cl;
+          if (co >= cout) continue;
+          float v0 = acc[mi][ni][4 * g], v1 = acc[mi][ni][4 * g + 1], v2 = acc[mi][ni][4 * g + 2], v3 = acc[mi][ni][4 * g + 3];
+          if (P.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + co);
+            v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+          }
+          if (P.bias2) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias2 + (int64_t)b * P.bias2_bstride + co);
+            v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+          }
+          unsigned short* slot = xs + tr * OP + cl;
+          if (P.res) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(slot);
+            v0 += bf_lo(rr.x); v1 += bf_hi(rr.x); v2 += bf_lo(rr.y); v3 += bf_hi(rr.y);
+          }
+          u32x2 o;
+          o.x = bf_pack(v0, v1); o.y = bf_pack(v2, v3);
+          *reinterpret_cast<u32x2*>(slot) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  uint16_t* og = P.out + (int64_t)b * P.out_bstride + (int64_t)t0 * cout + ch0;
+  for (int p = tid; p < rows * ppr; p += NT) {
+    const int r = p / ppr, c = p - r * ppr;
+    *reinterpret_cast<u32x4*>(og + (int64_t)r * cout + c * 8) = *reinterpret_cast<const u32x4*>(xs + r * OP + c * 8);
   }
 }
 
 bool conv_cl_bf16_supported(int cin, int cout, int k, int dil) {
-  if (cin < 16 || cin % 16 || cout < 4 || cout % 4 || k < 1 || dil < 1) return false;
+  if (cin < 16 || cin % 16 || cout < 8 || cout % 8 || k < 1 || dil < 1) return false;
   // narrowest workgroup tile (128 time steps) must fit the 160 KB LDS
-  return (int64_t)(CL_WT + (k - 1) * dil) * (cin + 8) * 2 <= 160 * 1024;
+  return (int64_t)(128 + (k - 1) * dil) * (cin + 8) * 2 <= 160 * 1024;
 }
 
-template <int WN, int WM>
+template <int WN, int WM, int MI, int NI>
 static int launch_cl_variant(hipStream_t stream, const ClLaunch& L, int nt, size_t lds_rows_extra, int cin) {
-  constexpr int BT = WM * CL_WT;
-  const size_t lds = (size_t)(BT + lds_rows_extra) * (size_t)(cin + 8) * 2;
+  constexpr int BT = WM * 32 * NI;
+  const size_t lds_in = (size_t)(BT + lds_rows_extra) * (size_t)(cin + 8) * 2;
+  const size_t lds_out = (size_t)BT * (size_t)(WN * MI * 32 + 8) * 2;        // the epilogue re-uses the tile as [BT][channels]
+  const size_t lds = lds_in > lds_out ? lds_in : lds_out;
   if (lds > 160 * 1024) return -2;
-  const int ngrp = (nt + WN - 1) / WN;
+  const int ngrp = (nt + WN * MI - 1) / (WN * MI);
   dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
-  auto kern = conv_cl_bf16_kernel<WN, WM>;
+  auto kern = conv_cl_bf16_kernel<WN, WM, MI, NI>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN * WM), lds, stream, L, ngrp);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// tuning experiments: BV2_CL_VARIANT=<nt>:<id>[,<nt>:<id>...] forces variant <id> for launches with <nt> 32-channel tiles
+static int forced_variant(int nt) {
+  static const char* e = getenv("BV2_CL_VARIANT");
+  if (!e) return -1;
+  for (const char* p = e; *p;) {
+    const int a = atoi(p);
+    const char* c = strchr(p, ':');
+    if (!c) break;
+    const int v = atoi(c + 1);
+    if (a == nt) return v;
+    const char* n = strchr(c, ',');
+    if (!n) break;
+    p = n + 1;
+  }
+  return -1;
 }
 
 int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** variant_name) {
@@ -219,21 +286,31 @@ int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** vari
     if (p.cout_pad / 32 > nt) nt = p.cout_pad / 32;
     if ((p.k - 1) * p.dil > extra) extra = (p.k - 1) * p.dil;
   }
-  int r;
-  if (nt >= 8) {
-    if (variant_name) *variant_name = "conv_cl_bf16<8x1>";
-    r = launch_cl_variant<8, 1>(stream, L, nt, extra, cin);
-  } else if (nt >= 3) {
-    if (variant_name) *variant_name = "conv_cl_bf16<4x1>";
-    r = launch_cl_variant<4, 1>(stream, L, nt, extra, cin);
-  } else if (nt == 2) {
-    if (variant_name) *variant_name = "conv_cl_bf16<2x2>";
-    r = launch_cl_variant<2, 2>(stream, L, nt, extra, cin);
-    if (r == -2) r = launch_cl_variant<4, 1>(stream, L, nt, extra, cin);
-  } else {
-    if (variant_name) *variant_name = "conv_cl_bf16<1x4>";
-    r = launch_cl_variant<1, 4>(stream, L, nt, extra, cin);
-    if (r == -2) r = launch_cl_variant<4, 1>(stream, L, nt, extra, cin);
+  // variant ids: 0 = 8x1 (8 waves x [32 ch x 128 t]), 1 = 4x1, 2 = 2x2, 3 = 1x4, then the 2 x NI register-blocked forms
+  // 4 = 4x1 MI2 NI4 (4 waves x [64 ch x 128 t]), 5 = 2x2 MI2 NI4, 6 = 2x4 MI2 NI2, 7 = 1x4 MI2 NI4, 8 = 4x2 MI2 NI2, 9 = 1x8 MI2 NI2
+  int v = forced_variant(nt);
+  if (v < 0) v = nt >= 8 ? 0 : (nt >= 3 ? 1 : (nt == 2 ? 2 : 3));
+  static const char* names[] = {"conv_cl_bf16<8x1>", "conv_cl_bf16<4x1>", "conv_cl_bf16<2x2>", "conv_cl_bf16<1x4>",
+                                "conv_cl_bf16<4x1,2x4>", "conv_cl_bf16<2x2,2x4>", "conv_cl_bf16<2x4,2x2>", "conv_cl_bf16<1x4,2x4>",
+                                "conv_cl_bf16<4x2,2x2>", "conv_cl_bf16<1x8,2x2>"};
+  int r = -1;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    switch (v) {
+      case 0: r = launch_cl_variant<8, 1, 1, 4>(stream, L, nt, extra, cin); break;
+      case 1: r = launch_cl_variant<4, 1, 1, 4>(stream, L, nt, extra, cin); break;
+      case 2: r = launch_cl_variant<2, 2, 1, 4>(stream, L, nt, extra, cin); break;
+      case 3: r = launch_cl_variant<1, 4, 1, 4>(stream, L, nt, extra, cin); break;
+      case 4: r = launch_cl_variant<4, 1, 2, 4>(stream, L, nt, extra, cin); break;
+      case 5: r = launch_cl_variant<2, 2, 2, 4>(stream, L, nt, extra, cin); break;
+      case 6: r = launch_cl_variant<2, 4, 2, 2>(stream, L, nt, extra, cin); break;
+      case 7: r = launch_cl_variant<1, 4, 2, 4>(stream, L, nt, extra, cin); break;
+      case 8: r = launch_cl_variant<4, 2, 2, 2>(stream, L, nt, extra, cin); break;
+      case 9: r = launch_cl_variant<1, 8, 2, 2>(stream, L, nt, extra, cin); break;
+      default: return -1;
+    }
+    if (variant_name) *variant_name = names[v];
+    if (r != -2) break;
+    v = 1;                                        // tile did not fit the LDS: the narrowest-in-time variant
   }
   return r;
 }
