@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   // of 8, so XCD = blockIdx.x % 8 for every (y, z).  Give each XCD a CONTIGUOUS range of time tiles: neighbouring tiles
   // share (k-1)*dil halo columns (up to 50 of 64) and the C_out/BM sibling tiles share the whole X tile — in one L2 those
   // re-reads are hits instead of a second fetch from HBM.
-  const int vt = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  // (per_xcd == 0: too few time tiles to split them over the XCDs evenly — plain mapping.)
+  const int vt = per_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   const int t0 = vt * BN;
   if (t0 >= L.L) return;
   if (m0 >= P.cout_pad) return;                   // problems in one launch may have different C_out
@@ -446,8 +447,9 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int m
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   if (BN + max_extra > XS * 64) return -2;        // halo does not fit the staged tile
   const int mtiles = (max_cout_pad + BM - 1) / BM;
-  const int per_xcd = ((L.L + BN - 1) / BN + 7) / 8;
-  dim3 grid(per_xcd * 8, mtiles * L.B, L.nprob);
+  const int ntx = (L.L + BN - 1) / BN;
+  const int per_xcd = (ntx % 8 == 0 || ntx >= 64) ? (ntx + 7) / 8 : 0;      // contiguous per-XCD ranges only if they balance
+  dim3 grid(per_xcd ? per_xcd * 8 : ntx, mtiles * L.B, L.nprob);
   const int nxbuf = max_chunks > 1 ? 2 : 1;     // a single-chunk problem never re-stages its X tile
   if (ck == 32) {
     const size_t lds = sizeof(float) * (size_t)(2 * 8 * BM * 4 + 2 * 32 * XS * 64);
