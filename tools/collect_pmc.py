@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Per-kernel-family PMC counters of a bench.py run (run ON THE GPU BOX): MFMA utilisation and HBM GB/s as rocprofv3
+reports them, next to the HIP-event numbers bench.py prints.
+
+Passes (each `rocprofv3 --kernel-trace --pmc <counters>` only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes — no
+sys/hip/hsa tracing next to --pmc):
+  1. SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE      MFMA busy cycles (summed over the SIMDs) / kernel cycles
+  2. FETCH_SIZE                                    KB read from the fabric (x2 on gfx950, see the guide)
+  3. WRITE_SIZE                                    KB written
+rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (GUI_ACTIVE / duration = 15-18 "GHz" for the long kernels), so
+kernel cycles = GUI_ACTIVE / 8 and the effective clock = that / duration (1.9 GHz under bf16 MFMA load, 2.3 GHz under fp32
+MFMA — the DVFS behaviour MI355X_MICROARCH.md describes).
+Derived per family:  mfma_util = MFMA_BUSY / (GUI_ACTIVE/8 * 4 SIMDs * 256 CUs)  — cross-check against the HIP-event
+numbers: conv1d_mfma<64x64> 0.525 here vs 82 TF / 157.3 TF = 0.52 from bench.py;  hbm_GBps = (2*FETCH + WRITE) / duration,
+duration from the same trace (End - Start of the dispatch).
+
+    python tools/collect_pmc.py out.json [bench.py args...]
+"""
+import collections, csv, glob, json, os, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from collect_traffic import family  # noqa: E402
+
+N_SIMD = 4 * 256
+
+
+def one_pass(counters, extra_args):
+    d = tempfile.mkdtemp(prefix="bv2pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "--output-format", "csv", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--graph", "0"] + extra_args
+    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=900)
+    tot = collections.defaultdict(collections.Counter)
+    n = collections.Counter()
+    dur = collections.Counter()
+    for cc in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        seen = collections.defaultdict(set)
+        rows = list(csv.DictReader(open(cc)))
+        inst = collections.Counter((r["Dispatch_Id"], r["Counter_Name"]) for r in rows)   # rows per dispatch = instances
+        for r in rows:
+            f = family(r["Kernel_Name"])
+            if f is None:
+                continue
+            v = float(r["Counter_Value"])
+            if r["Counter_Name"].startswith("GRBM_"):
+                v /= inst[(r["Dispatch_Id"], r["Counter_Name"])]
+            tot[f][r["Counter_Name"]] += v
+            if r["Dispatch_Id"] not in seen[f]:
+                seen[f].add(r["Dispatch_Id"])
+                if "Start_Timestamp" in r and "End_Timestamp" in r:
+                    dur[f] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+        for f, s in seen.items():
+            n[f] += len(s)
+    return tot, n, dur
+
+
+def main():
+    out = sys.argv[1]
+    extra = sys.argv[2:]
+    t1, n1, d1 = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], extra)
+    t2, n2, d2 = one_pass(["FETCH_SIZE"], extra)
+    t3, n3, d3 = one_pass(["WRITE_SIZE"], extra)
+    res = {"_method": __doc__.split("Derived")[0].strip(), "_bench_args": extra, "kernels": {}}
+    for f in sorted(set(t1) | set(t2) | set(t3)):
+        row = dict(launches=n1.get(f, 0))
+        gui = t1[f].get("GRBM_GUI_ACTIVE", 0.0)
+        if gui:
+            row["mfma_busy_cycles_per_launch"] = t1[f]["SQ_VALU_MFMA_BUSY_CYCLES"] / max(n1[f], 1)
+            row["gui_active_cycles_per_launch"] = gui / max(n1[f], 1)
+            row["mfma_util"] = round(t1[f]["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * N_SIMD), 4)
+        if n2.get(f) and n3.get(f):
+            fb = 2 * t2[f]["FETCH_SIZE"] * 1024 / n2[f]
+            wb = t3[f]["WRITE_SIZE"] * 1024 / n3[f]
+            row["fetch_bytes_per_launch"] = fb
+            row["write_bytes_per_launch"] = wb
+            secs = (d2[f] / n2[f] + d3[f] / n3[f]) / 2 if d2.get(f) and d3.get(f) else None
+            if secs:
+                row["avg_us_in_pmc_pass"] = round(secs * 1e6, 2)
+                row["hbm_GBps"] = round((fb + wb) / secs / 1e9, 1)
+                if gui:
+                    row["effective_clock_GHz"] = round(gui / 8.0 / max(n1[f], 1) / secs / 1e9, 2)
+        res["kernels"][f] = row
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
