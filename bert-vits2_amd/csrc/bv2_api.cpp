@@ -244,6 +244,15 @@ int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const b
   BV2_CATCH(h)
 }
 
+int bv2_pcm16(bv2_stream stream, const float* wave, int64_t wave_bstride, const int64_t* y_lengths, int32_t hop, int32_t B,
+              int64_t S, int16_t* pcm, int64_t pcm_bstride, uint32_t* peak_scratch) {
+  if (!wave || !y_lengths || !pcm || !peak_scratch || wave_bstride < S || pcm_bstride < S) return -1;
+  try {
+    return launch_pcm16(static_cast<hipStream_t>(stream), wave, wave_bstride, y_lengths, hop, B, S, pcm, pcm_bstride,
+                        peak_scratch);
+  } catch (...) { return -100; }
+}
+
 // ---- hipGraph capture -----------------------------------------------------------------------------------------
 struct bv2_graph {
   hipGraphExec_t exec = nullptr;

@@ -101,9 +101,10 @@ struct Ctx {
     if (r) fail(tag, r);
     return L.ksplit;
   }
-  int conv1(const ConvProb& p, int B, int L, const char* tag, int max_split = 1, int64_t slab_stride = 0) {
+  int conv1(const ConvProb& p, int B, int L, const char* tag, int max_split = 1, int64_t slab_stride = 0,
+            const int64_t* lens = nullptr, int len_mul = 1) {
     ConvLaunch cl;
-    cl.p[0] = p; cl.nprob = 1; cl.B = B; cl.L = L;
+    cl.p[0] = p; cl.nprob = 1; cl.B = B; cl.L = L; cl.lens = lens; cl.len_mul = len_mul;
     return conv(cl, tag, max_split, slab_stride);
   }
   // fp16 Encoder conv (kernels/enc_f16.hip) on dense tensors: in_ct/out_ct select fp32 [B][C][T] vs fp16 [B][T][C]
@@ -510,7 +511,8 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
 }
 
 // Generator.forward (reference models.py:538-557)
-static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, const float* ymask, int B, int L, float* o) {
+static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, const float* ymask, int B, int L, float* o,
+                     const int64_t* lens) {
   const Model& m = c.m;
   const bv2_config& cf = m.cfg;
   const int C = cf.inter_channels, c0 = cf.upsample_initial_channel;
@@ -520,12 +522,13 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     p.x_bstride = (int64_t)C * z_rstride; p.x_rstride = z_rstride; p.Lin = L;
     p.in_mask = ymask; p.in_mask_bstride = z_rstride;
     p.bias2 = P.gv; p.bias2_bstride = P.gv_stride;
-    c.conv1(p, B, L, "dec.conv_pre");
+    c.conv1(p, B, L, "dec.conv_pre", 1, 0, lens, 1);
   }
   c.tap("dec.pre", P.pre, (int64_t)B * c0 * L);
   const float* src[3] = {P.pre, nullptr, nullptr};
   int nsrc = 1;
   int Lc = L;
+  int up = 1;                                     // samples per latent frame at the current resolution
   for (int i = 0; i < m.n_ups; ++i) {
     const UpW& U = m.ups[i];
     float* const* S = P.set[i & 1];
@@ -534,7 +537,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     {
       // x = ConvTranspose1d(leaky_relu(mean of the previous stage's branches)) as U.u polyphase stride-1 convs
       ConvLaunch cl;
-      cl.nprob = U.u; cl.B = B; cl.L = Lc;
+      cl.nprob = U.u; cl.B = B; cl.L = Lc; cl.lens = lens; cl.len_mul = up;
       for (int ph = 0; ph < U.u; ++ph) {
         ConvProb p = c.prob(U.phase[ph], src[0], x, Lc);
         p.x[1] = src[1]; p.x[2] = src[2]; p.nsrc = nsrc; p.in_scale = 1.f / (float)nsrc;
@@ -563,7 +566,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
       for (int d = 0; d < m.n_rbd; ++d) {
         FusedLaunch F;
         std::memset(&F, 0, sizeof(F));
-        F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.slope = 0.1f;
+        F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.slope = 0.1f; F.lens = lens; F.len_mul = up * U.u;
         for (int jj = 0; jj < nb; ++jj) {
           const int j = nb - 1 - jj;                            // widest kernel first
           float* a = S[1 + j];
@@ -592,6 +595,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
       for (int d = 0; d < m.n_rbd; ++d) {
         ConvLaunch c1, c2;
         c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
+        c1.lens = c2.lens = lens; c1.len_mul = c2.len_mul = up * U.u;
         for (int jj = 0; jj < nb; ++jj) {
           const int j = nb - 1 - jj;                            // widest kernel first: longest workgroups start first
           float* cur = S[1 + j];
@@ -617,9 +621,11 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     for (int j = 0; j < 3; ++j) src[j] = j < nb ? branch_out[j] : nullptr;
     nsrc = nb;
     Lc = Lo;
+    up *= U.u;
   }
   ConvPostArgs a;
   std::memset(&a, 0, sizeof(a));
+  a.lens = lens; a.len_mul = up;
   for (int j = 0; j < 3; ++j) a.x[j] = src[j];
   a.nsrc = nsrc; a.in_scale = 1.f / (float)nsrc; a.x_bstride = (int64_t)m.post_c * Lc; a.x_rstride = Lc;
   a.w = c.W(m.conv_post.off); a.out = o; a.out_bstride = Lc; a.C = m.post_c; a.k = m.post_k; a.L = Lc; a.B = B;
@@ -632,7 +638,8 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
 // n_rbk branches; every tensor between launches is bf16 [B][L][C].  Rounding points (mirrored by oracle/bv2_oracle.py
 // generator_bf16): weights, (z*mask), every stored activation, and the pre-activated conv inputs are rounded to bf16
 // (RNE); accumulation, bias, residual and the branch mean are fp32; conv_post + tanh are fp32 on bf16 inputs.
-static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride, const float* ymask, int B, int L, float* o) {
+static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride, const float* ymask, int B, int L, float* o,
+                          const int64_t* lens) {
   const Model& m = c.m;
   const bv2_config& cf = m.cfg;
   const int C = cf.inter_channels, c0 = cf.upsample_initial_channel;
@@ -680,14 +687,14 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
   uint16_t* pre = U16(P.pre);
   {
     ClLaunch cl;
-    cl.nprob = 1; cl.B = B; cl.L = L;
+    cl.nprob = 1; cl.B = B; cl.L = L; cl.lens = lens; cl.len_mul = 1;
     cl.p[0] = prob(m.conv_pre, zc, pre, L, 1);
     cl.p[0].bias2 = P.gv; cl.p[0].bias2_bstride = P.gv_stride;
     launch(cl, "dec.conv_pre", flops_of(cl));
   }
   tap_cl("dec.pre", pre, c0, L);
   const uint16_t* src[3] = {pre, nullptr, nullptr};
-  int nsrc = 1, Lc = L;
+  int nsrc = 1, Lc = L, up = 1;
   for (int i = 0; i < m.n_ups; ++i) {
     const UpW& U = m.ups[i];
     float* const* S = P.set[i & 1];
@@ -695,7 +702,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     const int Lo = Lc * U.u;
     {
       ClLaunch cl;
-      cl.nprob = 1; cl.B = B; cl.L = Lc;
+      cl.nprob = 1; cl.B = B; cl.L = Lc; cl.lens = lens; cl.len_mul = up;
       ClProb p = prob(U.cl, src[0], x, Lc, 1);
       p.x[1] = src[1]; p.x[2] = src[2]; p.nsrc = nsrc; p.in_scale = 1.f / (float)nsrc;
       p.pre_lrelu = 1; p.pad_left = U.cl_pad_left;
@@ -711,7 +718,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
       // narrow stages: every branch's whole ResBlock (all dilation pairs) in ONE launch, intermediates in LDS
       RbClLaunch F;
       std::memset(&F, 0, sizeof(F));
-      F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.nd = m.n_rbd; F.slope = 0.1f;
+      F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.nd = m.n_rbd; F.slope = 0.1f; F.lens = lens; F.len_mul = up * U.u;
       for (int jj = 0; jj < nb; ++jj) {
         const int j = nb - 1 - jj;                                // widest kernel first
         RbClProb& p = F.p[jj];
@@ -733,6 +740,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     for (int d = 0; d < m.n_rbd && !whole; ++d) {
       ClLaunch c1, c2;
       c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
+      c1.lens = c2.lens = lens; c1.len_mul = c2.len_mul = up * U.u;
       for (int jj = 0; jj < nb; ++jj) {
         const int j = nb - 1 - jj;                              // widest kernel first
         uint16_t* cur = U16(S[1 + j]);
@@ -752,9 +760,11 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     for (int j = 0; j < nb; ++j) tap_cl("dec.rb." + std::to_string(i) + "." + std::to_string(j), src[j], U.cout, Lo);
     nsrc = nb;
     Lc = Lo;
+    up *= U.u;
   }
   ConvPostClArgs a;
   std::memset(&a, 0, sizeof(a));
+  a.lens = lens; a.len_mul = up;
   for (int j = 0; j < 3; ++j) a.x[j] = src[j];
   a.nsrc = nsrc; a.in_scale = 1.f / (float)nsrc;
   a.w = c.W(m.conv_post.off); a.out = o; a.C = m.post_c; a.k = m.post_k; a.L = Lc; a.B = B;
@@ -806,8 +816,9 @@ int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_
   phase_b_gemv(c, P, in.g, B);
   flow_core(c, P, z, ymask, in.g, B, Ty);
   const int L = (in.max_len > 0 && in.max_len < Ty) ? in.max_len : Ty;
-  if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, out.o);
-  else gen_core(c, P, z, Ty, ymask, B, L, out.o);
+  const int64_t* lens = in.exact_lengths ? in.y_lengths : nullptr;
+  if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, out.o, lens);
+  else gen_core(c, P, z, Ty, ymask, B, L, out.o, lens);
   return c.rc;
 }
 
@@ -838,8 +849,8 @@ int run_generator(bv2_handle* h, hipStream_t s, int B, int Ty, int L, const floa
   float* ymask = P.ymask;
   c.chk(launch_seq_mask(s, y_lengths, ymask, B, Ty), "y_mask");
   phase_b_gemv(c, P, g, B);
-  if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, o);
-  else gen_core(c, P, z, Ty, ymask, B, L, o);
+  if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, o, nullptr);
+  else gen_core(c, P, z, Ty, ymask, B, L, o, nullptr);
   return c.rc;
 }
 

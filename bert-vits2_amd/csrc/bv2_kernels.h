@@ -56,11 +56,16 @@ struct ConvProb {
 
 #define BV2_MAX_PROBS 8
 #define BV2_MAX_KSPLIT 8
+// "exact lengths" (every launch struct below): when `lens` is set, batch item b's INPUT is valid only on
+// [0, min(Lin, lens[b]*len_mul)) — positions past it read as the conv's zero padding, exactly as if the utterance had been
+// run alone.  The reference's decoder is unmasked, so in a padded batch the bias-driven activations past an utterance's end
+// bleed into its last samples; with lens a ragged batch reproduces the per-utterance result.
 struct ConvLaunch {
   ConvProb p[BV2_MAX_PROBS];
   int nprob;
   int B;
   int L;                    // output positions per problem (index t)
+  const int64_t* lens = nullptr; int len_mul = 1;
   int ksplit;               // split-K kernel only: K split across workgroups into `ksplit` partial slabs (1 = none)
   int64_t slab_stride;      // floats between the partial slabs of one output (slab z is written at out + z*slab_stride)
 };
@@ -88,7 +93,7 @@ struct FusedProb {
   const float* w2; const float* b2;               // ... of convs2[d]
   int k, dil;
 };
-struct FusedLaunch { FusedProb p[3]; int nprob, B, C, L; float slope; };
+struct FusedLaunch { FusedProb p[3]; int nprob, B, C, L; float slope; const int64_t* lens = nullptr; int len_mul = 1; };
 bool resblock_fused_supported(int C, int k, int dil);
 int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F);
 double resblock_fused_flops(const FusedLaunch& F);
@@ -123,7 +128,7 @@ struct ClProb {
   int cin, cout, cout_pad, k, dil, pad_left;
   int pre_lrelu; float slope;
 };
-struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; };
+struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; const int64_t* lens = nullptr; int len_mul = 1; };
 int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** variant_name);
 bool conv_cl_bf16_supported(int cin, int cout, int k, int dil);
 // element index (bf16 units) of weight (tap j, input channel ci, output channel co) in the packed stream
@@ -143,7 +148,7 @@ double conv_cl_bytes(const ClLaunch& L);
 #define BV2_RBCL_MAX_D 4
 constexpr int RBCL_PD = 8;        // weight ring depth = unit padding of the stream
 struct RbClProb { const uint16_t* x; uint16_t* out; const uint16_t* w; const float* bias; int k; int dil[BV2_RBCL_MAX_D]; int halo; };
-struct RbClLaunch { RbClProb p[3]; int nprob, B, C, L, nd; float slope; };
+struct RbClLaunch { RbClProb p[3]; int nprob, B, C, L, nd; float slope; const int64_t* lens = nullptr; int len_mul = 1; };
 bool resblock_cl_bf16_supported(int C, int k, const int* dil, int nd);
 int resblock_cl_bf16_units(int C, int k);
 int launch_resblock_cl_bf16(hipStream_t stream, const RbClLaunch& L);
@@ -161,6 +166,7 @@ struct ConvPostClArgs {
   const float* w;           // [C][k] fp32
   float* out;               // [B][L] fp32
   int C, k, L, B; float slope;
+  const int64_t* lens = nullptr; int len_mul = 1;
 };
 int launch_conv_post_cl(hipStream_t stream, const ConvPostClArgs& a);
 
@@ -201,6 +207,7 @@ struct ConvPostArgs {
   const float* w;           // [C][k] fp32 (unpadded)
   float* out; int64_t out_bstride;
   int C, k, L, B; float slope;
+  const int64_t* lens = nullptr; int len_mul = 1;
 };
 int launch_conv_post(hipStream_t stream, const ConvPostArgs& a);
 
@@ -298,5 +305,9 @@ int launch_wn_gate(hipStream_t stream, const float* xin, float* acts, int B, int
 // not last: x = (x + rs[:, :H]) * mask ; outacc (+)= rs[:, H:]   | last: outacc (+)= rs ; finally outacc *= mask
 int launch_wn_res_skip(hipStream_t stream, const float* rs, float* x, float* outacc, const float* mask,
                        int B, int H, int T, int last, int first);
+
+// --- 16-bit PCM of the valid samples, peak-normalised per utterance (gradio convert_to_16_bit_wav, reference webui.py:86) ---
+int launch_pcm16(hipStream_t stream, const float* wave, int64_t bstride, const int64_t* y_lengths, int hop, int B, int64_t S,
+                 int16_t* pcm, int64_t pstride, unsigned* peak_scratch);
 
 }  // namespace bv2

@@ -72,7 +72,13 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 
   // problem fields used in the main loop, hoisted into registers (P lives in the kernarg segment; re-reading it costs
   // an s_load + lgkmcnt wait at every use)
-  const int k = P.k, dil = P.dil, cin = P.cin, Lin = P.Lin, nsrc = P.nsrc;
+  const int k = P.k, dil = P.dil, cin = P.cin, nsrc = P.nsrc;
+  int Lin = P.Lin;
+  if (L.lens) {                                   // exact lengths: this batch item's input ends at lens[b]*len_mul
+    const int64_t lv = L.lens[b] * L.len_mul;
+    Lin = lv < Lin ? (int)lv : Lin;
+    if (t0 >= Lin) return;                        // a tile wholly past the utterance: nobody reads its outputs
+  }
   const float in_scale = P.in_scale, slope = P.slope;
   const bool lrelu = P.pre_act == PRE_LRELU;
   // per-batch base pointers (wave-uniform -> SGPR pairs); element offsets inside one batch item fit 32 bits
@@ -314,7 +320,12 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
   const int l31 = lane & 31, lh = lane >> 5;
   // problem fields hoisted into registers (P lives in the kernarg segment)
-  const int k = P.k, dil = P.dil, cin = P.cin, Lin = P.Lin;
+  const int k = P.k, dil = P.dil, cin = P.cin;
+  int Lin = P.Lin;
+  if (L.lens) {
+    const int64_t lv = L.lens[b] * L.len_mul;
+    Lin = lv < Lin ? (int)lv : Lin;
+  }
   const int groups = P.cin_pad / 8;
   const float in_scale = P.in_scale, slope = P.slope;
   const bool lrelu = P.pre_act == PRE_LRELU;

@@ -155,10 +155,16 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
   const int t0 = blockIdx.x * BT;
   const int cin = P.cin, k = P.k, dil = P.dil;
   if (cg * WN * MI * 32 >= P.cout_pad) return;    // whole workgroup beyond this problem's channels (uniform: before the barrier)
+  int Lin = P.Lin;
+  if (L.lens) {                                   // exact lengths: this batch item's input ends at lens[b]*len_mul
+    const int64_t lv = L.lens[b] * L.len_mul;
+    Lin = lv < Lin ? (int)lv : Lin;
+    if (t0 >= Lin) return;                        // a tile wholly past the utterance: nobody reads its outputs
+  }
   const int pitch = cin + 8;
   cl_stage<NT>(xs, pitch, P.x[0] + (int64_t)b * P.x_bstride, P.x[1] ? P.x[1] + (int64_t)b * P.x_bstride : nullptr,
                P.x[2] ? P.x[2] + (int64_t)b * P.x_bstride : nullptr, P.nsrc, P.in_scale, P.pre_lrelu != 0, P.slope,
-               t0 - P.pad_left, BT + (k - 1) * dil, cin, P.Lin, tid);
+               t0 - P.pad_left, BT + (k - 1) * dil, cin, Lin, tid);
   __syncthreads();
   const bool active = mt0 * 32 < P.cout_pad;      // waves beyond this problem's channels still join the epilogue barriers
 
@@ -375,6 +381,11 @@ __global__ void __launch_bounds__(CP_TS) conv_post_cl_kernel(const ConvPostClArg
   float* ms = cps + C * k;
   const int mp = C + 1;
   const int b = blockIdx.y, t0 = blockIdx.x * CP_TS, tid = threadIdx.x;
+  int Lv = A.L;
+  if (A.lens) {
+    const int64_t lv = A.lens[b] * A.len_mul;
+    Lv = lv < Lv ? (int)lv : Lv;
+  }
   for (int i = tid; i < C * k; i += CP_TS) ws[i] = A.w[i];
   const int rows = CP_TS + k - 1, ppr = C >> 3;
   for (int p = tid; p < rows * ppr; p += CP_TS) {
@@ -383,7 +394,7 @@ __global__ void __launch_bounds__(CP_TS) conv_post_cl_kernel(const ConvPostClArg
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (t >= 0 && t < A.L) {
+    if (t >= 0 && t < Lv) {
       const int64_t off = ((int64_t)b * A.L + t) * C + cb * 8;
       for (int s = 0; s < A.nsrc; ++s) {
         const u32x4 u = *reinterpret_cast<const u32x4*>(A.x[s] + off);

@@ -20,13 +20,18 @@ __global__ void __launch_bounds__(256) conv_post_kernel(const ConvPostArgs A) {
   const int b = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= A.L) return;
+  int Lv = A.L;
+  if (A.lens) {
+    const int64_t lv = A.lens[b] * A.len_mul;
+    Lv = lv < Lv ? (int)lv : Lv;
+  }
   const int pad = (A.k - 1) / 2;
   float acc = 0.f;
   for (int c = 0; c < A.C; ++c) {
     const int64_t roff = (int64_t)b * A.x_bstride + (int64_t)c * A.x_rstride;
     for (int j = 0; j < A.k; ++j) {
       const int tt = t - pad + j;
-      if (tt < 0 || tt >= A.L) continue;
+      if (tt < 0 || tt >= Lv) continue;
       float v = A.x[0][roff + tt];
       if (A.nsrc > 1) v += A.x[1][roff + tt];
       if (A.nsrc > 2) v += A.x[2][roff + tt];
@@ -392,6 +397,54 @@ int launch_wn_res_skip(hipStream_t stream, const float* rs, float* x, float* out
                        int last, int first) {
   hipLaunchKernelGGL(wn_res_skip_kernel, dim3((T + 255) / 256, H, B), dim3(256), 0, stream, rs, x, outacc, mask, H, T,
                      last, first);
+  return BV2_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16-bit PCM (what the reference's callers do on the host after .cpu(): gradio convert_to_16_bit_wav, webui.py:86,
+// hiyoriUI.py:343): per utterance  pcm = int16( wave / max|wave| * 32767 )  (truncation, as numpy astype), over the valid
+// samples [0, y_length*hop); samples past the utterance are 0.  peak[] holds the bit pattern of max|wave| (non-negative
+// floats order like unsigned integers) and must be zero on entry (the launcher clears it on the stream).
+__global__ void __launch_bounds__(256) pcm_peak_kernel(const float* wave, int64_t bstride, const int64_t* y_lengths, int hop,
+                                                       int64_t S, unsigned* peak) {
+  const int b = blockIdx.y;
+  int64_t n = y_lengths[b] * hop;
+  n = n < S ? n : S;
+  const float* w = wave + (int64_t)b * bstride;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(w + i) & 15) == 0)) {
+      const float4 v = *reinterpret_cast<const float4*>(w + i);
+      m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    } else {
+      for (int e = 0; e < 4 && i + e < n; ++e) m = fmaxf(m, fabsf(w[i + e]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(peak + b, __float_as_uint(m));
+}
+__global__ void __launch_bounds__(256) pcm_convert_kernel(const float* wave, int64_t bstride, const int64_t* y_lengths, int hop,
+                                                          int64_t S, const unsigned* peak, int16_t* pcm, int64_t pstride) {
+  const int b = blockIdx.y;
+  int64_t n = y_lengths[b] * hop;
+  n = n < S ? n : S;
+  const float pk = __uint_as_float(peak[b]);
+  const float* w = wave + (int64_t)b * bstride;
+  int16_t* o = pcm + (int64_t)b * pstride;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += (int64_t)gridDim.x * 256) {
+    // numpy: (x / peak) * 32767 in fp32, then astype(int16) truncates toward zero
+    o[i] = (i < n && pk > 0.f) ? (int16_t)(int)((w[i] / pk) * 32767.f) : (int16_t)0;
+  }
+}
+int launch_pcm16(hipStream_t stream, const float* wave, int64_t bstride, const int64_t* y_lengths, int hop, int B, int64_t S,
+                 int16_t* pcm, int64_t pstride, unsigned* peak) {
+  if (B < 1 || S < 1 || hop < 1) return -1;
+  if (hipMemsetAsync(peak, 0, sizeof(unsigned) * (size_t)B, stream) != hipSuccess) return -1;
+  int gx = (int)((S + 4095) / 4096);
+  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+  hipLaunchKernelGGL(pcm_peak_kernel, dim3(gx, B), dim3(256), 0, stream, wave, bstride, y_lengths, hop, S, peak);
+  hipLaunchKernelGGL(pcm_convert_kernel, dim3(gx, B), dim3(256), 0, stream, wave, bstride, y_lengths, hop, S, peak, pcm, pstride);
   return BV2_CHECK_LAUNCH();
 }
 

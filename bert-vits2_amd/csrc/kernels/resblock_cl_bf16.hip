@@ -96,12 +96,18 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
   if (t0 >= L.L) return;                          // branches with a smaller halo need fewer tiles
   const int b = blockIdx.y;
   const int tb = t0 - P.halo;                     // time step of tile row 0
-  const int Lseq = L.L, k = P.k, nd = L.nd;
+  const int Lrow = L.L, k = P.k, nd = L.nd;      // Lrow: rows per batch item in HBM; Lseq: valid rows of THIS item
+  int Lseq = Lrow;
+  if (L.lens) {
+    const int64_t lv = L.lens[b] * L.len_mul;
+    Lseq = lv < Lrow ? (int)lv : Lrow;
+    if (t0 >= Lseq) return;                       // a tile wholly past the utterance: nobody reads its outputs
+  }
   const float slope = L.slope;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const uint16_t* xg = P.x + (int64_t)b * Lseq * C;
+  const uint16_t* xg = P.x + (int64_t)b * Lrow * C;
 
   // weight ring: primed once, never drained between the convs
   Ring ring;
@@ -159,7 +165,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
 
   const int U = (C / 16) * k, Upad = (U + RBCL_PD - 1) / RBCL_PD * RBCL_PD;
   const int half = (k - 1) / 2;
-  uint16_t* outg = P.out + (int64_t)b * Lseq * C;
+  uint16_t* outg = P.out + (int64_t)b * Lrow * C;
   const int row0 = wid * NI * 32 + l31;           // this lane's row in block ni: row0 + 32*ni
 
   for (int d = 0; d < nd; ++d) {

@@ -81,6 +81,12 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * RF_BN;
   const int C = F.C, L = F.L, k = P.k, dil = P.dil;
+  int Lv = L;                                     // valid length of this batch item (exact lengths), L stays the row stride
+  if (F.lens) {
+    const int64_t lv = F.lens[b] * F.len_mul;
+    Lv = lv < L ? (int)lv : L;
+    if (t0 >= Lv) return;
+  }
   const int groups = (C + 7) / 8;
   const int h1 = ((k - 1) / 2) * dil, h2 = (k - 1) / 2;
   const float slope = F.slope;
@@ -97,8 +103,8 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
 #pragma unroll
     for (int s = 0; s < RF_XS; ++s) {
       const int t = tb + lane + 64 * s;
-      ok[s] = (lane + 64 * s < XW) && t >= 0 && t < L;
-      tc[s] = 4u * (unsigned)(t < 0 ? 0 : (t >= L ? L - 1 : t));
+      ok[s] = (lane + 64 * s < XW) && t >= 0 && t < Lv;
+      tc[s] = 4u * (unsigned)(t < 0 ? 0 : (t >= Lv ? Lv - 1 : t));
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -125,7 +131,7 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     rf_gemm(acc, P.w1, w_lane, groups, k, Xs, RF_XP, 32 * wid + l31, dil, lh);
     const int t = t0 - RF_LEAD + 32 * wid + l31;
-    const bool tin = t >= 0 && t < L;
+    const bool tin = t >= 0 && t < Lv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;

@@ -56,7 +56,7 @@ class DecodeIn(C.Structure):
         ("B", C.c_int32), ("T", C.c_int32), ("Ty", C.c_int32), ("max_len", C.c_int32),
         ("m_p", C.c_void_p), ("logs_p", C.c_void_p), ("x_mask", C.c_void_p), ("w_ceil", C.c_void_p),
         ("y_lengths", C.c_void_p), ("g", C.c_void_p), ("noise_z", C.c_void_p),
-        ("nz_bstride", C.c_int64), ("nz_cstride", C.c_int64), ("noise_scale", C.c_float),
+        ("nz_bstride", C.c_int64), ("nz_cstride", C.c_int64), ("noise_scale", C.c_float), ("exact_lengths", C.c_int32),
     ]
 
 
@@ -89,6 +89,7 @@ SYMBOLS = [
     ("bv2_stage_generator", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
     ("bv2_infer", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.c_int64, C.c_float,
                             C.c_int32, C.c_int32, C.POINTER(DecodeOut), C.POINTER(C.c_int32), _P, C.c_int64]),
+    ("bv2_pcm16", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int64, _P]),
     ("bv2_graph_capture_encode", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.POINTER(_P)]),
     ("bv2_graph_capture_decode", C.c_int, [_P, _P, C.POINTER(DecodeIn), C.POINTER(DecodeOut), _P, C.c_int64, C.POINTER(_P)]),
     ("bv2_graph_launch", C.c_int, [_P, _P]),

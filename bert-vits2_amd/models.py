@@ -307,7 +307,7 @@ class SynthesizerTrn(nn.Module):
 
     @torch.no_grad()
     def decode(self, enc: Dict[str, torch.Tensor], noise_z: torch.Tensor, Ty: int, noise_scale=0.667, max_len=None,
-               want_attn: bool = True) -> Dict[str, torch.Tensor]:
+               want_attn: bool = True, exact_lengths: bool = False) -> Dict[str, torch.Tensor]:
         """Phase B = reference models.py:1058-1073.  ``noise_z`` [B,inter,>=Ty] replaces randn_like at :1071."""
         dev = self.device
         hp = self.hp
@@ -329,14 +329,14 @@ class SynthesizerTrn(nn.Module):
                 sin["noise_z"] = torch.empty(B, Ci, Ty, dtype=torch.float32, device=dev)
                 sout = mk_out()
                 din = L.DecodeIn(B, T, int(Ty), int(L_dec), *[_ptr(sin[k]) for k in ikeys], _ptr(sin["noise_z"]),
-                                 sin["noise_z"].stride(0), sin["noise_z"].stride(1), float(noise_scale))
+                                 sin["noise_z"].stride(0), sin["noise_z"].stride(1), float(noise_scale), int(exact_lengths))
                 dout = L.DecodeOut(*[_ptr(sout[k]) for k in okeys])
                 with torch.cuda.device(dev):
                     g = self._capture(self._lib.bv2_graph_capture_decode, C.byref(din), C.byref(dout),
                                       C.c_void_p(ws.data_ptr()), ws.numel())
                 return dict(graph=g, sin=sin, sout=sout)
 
-            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale)), build)
+            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale), bool(exact_lengths)), build)
             for k in ikeys:
                 ent["sin"][k].copy_(enc[k])
             ent["sin"]["noise_z"].copy_(noise_z[:, :, :Ty])
@@ -347,7 +347,7 @@ class SynthesizerTrn(nn.Module):
         out = mk_out()
         din = L.DecodeIn(B, T, int(Ty), int(L_dec), _ptr(enc["m_p"]), _ptr(enc["logs_p"]), _ptr(enc["x_mask"]),
                          _ptr(enc["w_ceil"]), _ptr(enc["y_lengths"]), _ptr(enc["g"]), _ptr(noise_z),
-                         noise_z.stride(0), noise_z.stride(1), float(noise_scale))
+                         noise_z.stride(0), noise_z.stride(1), float(noise_scale), int(exact_lengths))
         dout = L.DecodeOut(*[_ptr(out[k]) for k in okeys])
         ws = self._workspace(B, T, Ty)
         with torch.cuda.device(dev):
@@ -360,10 +360,12 @@ class SynthesizerTrn(nn.Module):
     @torch.no_grad()
     def infer(self, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_scale=0.667, length_scale=1,
               noise_scale_w=0.8, max_len=None, sdp_ratio=0, y=None, *, noise_w=None, noise_z=None, w_ceil=None,
-              want_attn=True):
+              want_attn=True, exact_lengths=False):
         """reference models.py:1026-1074.  Keyword-only extras (not in the reference): ``noise_w`` [B,2,T] and
         ``noise_z`` [B,inter,>=T_y] inject the two N(0,1) draws (parity tests; the reference's ONNX export externalises
-        them the same way), ``w_ceil`` substitutes the durations, ``want_attn=False`` skips materialising the path."""
+        them the same way), ``w_ceil`` substitutes the durations, ``want_attn=False`` skips materialising the path,
+        ``exact_lengths=True`` makes every utterance of a ragged batch come out exactly as if it had been run alone (the
+        reference's unmasked decoder lets the padding bleed into an utterance's last ~40 ms; bv2.h ``exact_lengths``)."""
         if self.device.type != "cuda":
             raise RuntimeError("bert_vits2_amd.SynthesizerTrn.infer needs a GPU: no CPU fallback exists by design")
         dev = self.device
@@ -383,7 +385,8 @@ class SynthesizerTrn(nn.Module):
             noise_z = noise_z.to(dev, torch.float32)
             if noise_z.stride(2) != 1:
                 noise_z = noise_z.contiguous()
-        dec = self.decode(enc, noise_z, Ty, noise_scale=noise_scale, max_len=max_len, want_attn=want_attn)
+        dec = self.decode(enc, noise_z, Ty, noise_scale=noise_scale, max_len=max_len, want_attn=want_attn,
+                          exact_lengths=exact_lengths)
         self.last_encode = enc
         return dec["o"], dec["attn"], dec["y_mask"], (dec["z"], dec["z_p"], dec["m_p"], dec["logs_p"])
 

@@ -145,6 +145,12 @@ typedef struct bv2_decode_in {
   const float* noise_z;      /* N(0,1) for models.py:1071; element (b,c,j) at noise_z[b*nz_bstride + c*nz_cstride + j] */
   int64_t nz_bstride, nz_cstride;
   float noise_scale;
+  int32_t exact_lengths;     /* 0: the reference's batch semantics — dec is unmasked, so in a padded batch the activations
+                                past an utterance's end bleed into its last ~40 ms (models.py:1073 masks only z).
+                                1: every Generator conv treats positions >= y_lengths[b]*(samples per frame at its stage) as
+                                zero padding, i.e. each utterance of a ragged batch gets exactly the audio it gets when run
+                                alone (what the reference produces, since it only ever infers at batch 1); tiles past an
+                                utterance's end are skipped. */
 } bv2_decode_in;
 
 typedef struct bv2_decode_out {   /* all DEVICE, caller-allocated; any pointer except o may be NULL */
@@ -175,6 +181,14 @@ int bv2_stage_generator(bv2_handle* h, bv2_stream stream, int B, int Ty, int L, 
 int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* enc_out,
               const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, float noise_scale, int32_t max_len,
               int32_t Ty_cap, const bv2_decode_out* dec_out, int32_t* Ty_out, void* workspace, int64_t workspace_bytes);
+
+/* ---- 16-bit PCM (serving glue; replaces the host-side gradio convert_to_16_bit_wav the reference's callers run after
+ * .cpu(): webui.py:86,129, hiyoriUI.py:343) -------------------------------------------------------------------- */
+/* pcm[b][i] = (int16) trunc( wave[b][i] / max_j |wave[b][j]| * 32767 ) over the valid samples i, j < y_lengths[b]*hop
+ * (capped at S); samples past the utterance are 0; an all-zero utterance stays 0.  wave [B][wave_bstride >= S] fp32,
+ * pcm [B][pcm_bstride >= S] int16, peak_scratch [B] uint32 — all DEVICE.  Asynchronous on `stream`, graph-capturable. */
+int bv2_pcm16(bv2_stream stream, const float* wave, int64_t wave_bstride, const int64_t* y_lengths, int32_t hop, int32_t B,
+              int64_t S, int16_t* pcm, int64_t pcm_bstride, uint32_t* peak_scratch);
 
 /* ---- hipGraph capture (BASELINE config 3: "hipGraph-captured decode") ----------------------------------------- */
 /* Both phases are fixed launch sequences on the caller's stream with no allocation, host sync or device->host copy,
