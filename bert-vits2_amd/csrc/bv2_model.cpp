@@ -426,6 +426,7 @@ int pack_all(Model& m, Packer& P) {
   P.emit_bf16 = false;
   m.post_c = ch;
   m.conv_post = P.vec("dec.conv_post.weight", {1, ch, m.post_k});
+  P.alloc(2048);                                  // slack: weight prefetch rings run up to 4 units (4 KB) past a stream's end
   m.total_floats = P.cursor;
   return 0;
 }

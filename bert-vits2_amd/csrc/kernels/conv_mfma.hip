@@ -94,13 +94,19 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   f32x4* Ws = reinterpret_cast<f32x4*>(smem);     // [2][GR][2][BM] float4
   float* Xs = smem + 2 * W4 * 4;                  // [nchunks > 1 ? 2 : 1][CK][XP]
 
-  f32x16 acc[MI][NI];
+  // A wave with ONE output tile would chain every MFMA on the previous one's accumulator; with anything issued between two
+  // dependent MFMAs the pipe inserts a ~43-cycle bubble (MI355X_MICROARCH.md, per-instruction constants).  Two accumulators
+  // taking alternate K steps (summed in the epilogue) double the dependency distance.
+  constexpr int NA = (MI * NI == 1) ? 2 : 1;
+  f32x16 acc[NA][MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][mi][ni][r] = 0.f;
 
   f32x4 wreg[NW4];
   float xr[RPW][XS];
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
           const float a = q == 0 ? a4[mi].x : (q == 1 ? a4[mi].y : (q == 2 ? a4[mi].z : a4[mi].w));
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[ni], acc[mi][ni], 0, 0, 0);
+            acc[q % NA][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[ni], acc[q % NA][mi][ni], 0, 0, 0);
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bb[ni] = bbn[ni];
@@ -274,6 +280,251 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (MI * 32) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= P.cout) continue;
+        float v = NA == 2 ? acc[0][mi][ni][r] + acc[NA - 1][mi][ni][r] : acc[0][mi][ni][r];
+        if (P.bias) v += P.bias[row];
+        if (P.bias2) v += P.bias2[(int64_t)b * P.bias2_bstride + row];
+        if (P.act == ACT_RELU) v = fmaxf(v, 0.f);
+        if (P.mask_pre) v *= om;
+        const int64_t oidx = (int64_t)row * P.out_rstride + (int64_t)col * P.out_tstride + P.out_toff;
+        if (P.res_mode == RES_ADD) v += P.res[(int64_t)b * P.res_bstride + oidx];
+        else if (P.res_mode == RES_RSUB) v = P.res[(int64_t)b * P.res_bstride + oidx] - v;
+        if (P.mask_post) v *= om;
+        P.out[(int64_t)b * P.out_bstride + oidx] = v;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv1d_mfma2_kernel — same tiling and epilogue as conv1d_mfma_kernel, different operand plumbing:
+//   * weights never touch LDS: every wave streams the A fragments of its own MI m-tiles global -> registers through a ring of
+//     GR (group, tap) units (1 KB each, the packed stream of one m-tile is contiguous over (group, tap), so the ring just
+//     walks it and is never drained between chunks);
+//   * the X chunk [CK][BN + halo] is the only LDS tenant (double buffered, register-prefetched one chunk ahead), and the
+//     workgroup synchronises ONCE PER CHUNK (GR*k units = 16*k MFMAs per wave) instead of once per (chunk, tap) step.
+// v1 spends a barrier + a weight-tile LDS round trip every 16 MFMAs; at batch 1, where a CU holds 1-3 workgroups, those
+// bubbles are not covered by other waves (profiles/r01_h_pmc_summary.md: 0.52 MFMA utilisation).
+template <int WM, int WN, int MI, int NI, int CK, int XS>
+__global__ void __launch_bounds__(256) conv1d_mfma2_kernel(const ConvLaunch L, const int mtiles, const int per_xcd) {
+  constexpr int BM = WM * MI * 32;
+  constexpr int BN = WN * NI * 32;
+  constexpr int XP = XS * 64;
+  constexpr int RPW = CK / 4;
+  constexpr int GR = CK / 8;                      // channel groups per chunk = ring depth (GR*k units per chunk: whole rings)
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const ConvProb& P = L.p[blockIdx.z];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int b = blockIdx.y / mtiles;
+  const int m0 = (blockIdx.y - b * mtiles) * BM;
+  const int vt = per_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const int t0 = vt * BN;
+  if (t0 >= L.L) return;
+  if (m0 >= P.cout_pad) return;
+
+  const int k = P.k, dil = P.dil, cin = P.cin, nsrc = P.nsrc;
+  int Lin = P.Lin;
+  if (L.lens) {
+    const int64_t lv = L.lens[b] * L.len_mul;
+    Lin = lv < Lin ? (int)lv : Lin;
+    if (t0 >= Lin) return;
+  }
+  const float in_scale = P.in_scale, slope = P.slope;
+  const bool lrelu = P.pre_act == PRE_LRELU;
+  const float* const x0p = P.x[0] + (int64_t)b * P.x_bstride;
+  const float* const x1p = P.x[1] ? P.x[1] + (int64_t)b * P.x_bstride : nullptr;
+  const float* const x2p = P.x[2] ? P.x[2] + (int64_t)b * P.x_bstride : nullptr;
+  const float* const maskp = P.in_mask ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
+  const int x_rstride = P.x_rstride;
+  const int XW = BN + (k - 1) * dil;
+  const int nchunks = P.cin_pad / CK;
+  const int groups = P.cin_pad / 8;
+  float* Xs = smem;                               // [nchunks > 1 ? 2 : 1][CK][XP]
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // ---- weight ring: unit (group g, tap j) of m-tile mt lives at byte offset (((mt*groups + g)*k + j)*64 + lh*32 + l31)*16
+  f32x4 ar[GR][MI];
+  // ring slot g always holds group g of the current chunk: unit (g, j) is followed in the slot by (g, j+1), and after the
+  // last tap by (g, 0) of the next chunk.  One wave-uniform pointer per (slot, m-tile) + the per-lane offset.
+  const float* wq[GR][MI];
+  const unsigned wlane = 16u * (unsigned)(lh * 32 + l31);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int mt = (m0 >> 5) + wm * MI + mi;
+    mt = mt * 32 < P.w_ld ? mt : (m0 >> 5);       // rows beyond the allocation: any valid tile (results are dropped)
+#pragma unroll
+    for (int g = 0; g < GR; ++g) wq[g][mi] = P.w + ((int64_t)mt * groups + g) * k * 256;
+  }
+  auto load_unit = [&](int slot, int step_floats) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ar[slot][mi] = ld_off4(wq[slot][mi], wlane);
+      wq[slot][mi] += step_floats;
+    }
+  };
+
+  // ---- X prefetch (identical to v1)
+  float xr[RPW][XS];
+  float xm[XS];
+  const int tbase = t0 - P.pad_left;
+  unsigned tc[XS];
+  float colsc[XS];
+#pragma unroll
+  for (int s = 0; s < XS; ++s) {
+    const int t = tbase + lane + 64 * s;
+    const bool tok = (lane + 64 * s < XW) && t >= 0 && t < Lin;
+    colsc[s] = tok ? in_scale : 0.f;
+    tc[s] = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
+  }
+  auto issue_x = [&](int c) __attribute__((always_inline)) {
+    unsigned roff[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      int cg = c * CK + wid * RPW + r;
+      cg = cg < cin ? cg : cin - 1;
+      roff[r] = 4u * (unsigned)cg * (unsigned)x_rstride;
+    }
+    if (maskp) {
+#pragma unroll
+      for (int s = 0; s < XS; ++s) xm[s] = ld_off(maskp, tc[s]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < XS; ++s) xm[s] = 1.f;
+    }
+#pragma unroll
+    for (int s = 0; s < XS; ++s)
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) xr[r][s] = ld_off(x0p, roff[r] + tc[s]);
+    if (nsrc > 1) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) xr[r][s] += ld_off(x1p, roff[r] + tc[s]);
+      if (nsrc > 2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < XS; ++s)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) xr[r][s] += ld_off(x2p, roff[r] + tc[s]);
+      }
+    }
+  };
+  auto store_x = [&](int c, int buf) __attribute__((always_inline)) {
+    float* dst = Xs + buf * (CK * XP) + (wid * RPW) * XP + lane;
+    const int rows_ok = cin - (c * CK + wid * RPW);
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      const float sc = colsc[s] * xm[s];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        float v = xr[r][s];
+        const float vn = v * slope;
+        v = (lrelu && v < 0.f) ? vn : v;
+        v *= sc;
+        dst[r * XP + 64 * s] = r < rows_ok ? v : 0.f;
+      }
+    }
+  };
+
+  // prologue: X chunk 0 first (its latency is the long one), then prime the ring
+  issue_x(0);
+#pragma unroll
+  for (int i = 0; i < GR; ++i) { load_unit(i, k == 1 ? (nchunks > 1 ? GR * 256 : 0) : 256); __builtin_amdgcn_sched_barrier(0); }
+  store_x(0, 0);
+  __syncthreads();
+
+  // Unit order inside a chunk: tap-major — for every tap j the GR groups in turn (ring slot = group, a compile-time index;
+  // rows 8g of the X chunk are immediate offsets, the tap's column shift is one VGPR add per tap).  Operands of the next
+  // unit are read from LDS while the current unit's MFMAs run.
+  const unsigned xlane = 4u * (unsigned)(lh * XP + wn * (NI * 32) + l31);
+  const unsigned tap_step = 4u * (unsigned)dil;
+  const char* const xs_bytes = reinterpret_cast<const char*>(Xs);
+  const int last_step = ((GR - 1) * k + 1) * 256;                   // floats from (g, k-1) to (g, 0) of the next chunk
+  for (int c = 0; c < nchunks; ++c) {
+    const bool next_chunk = (c + 1) < nchunks;
+    if (next_chunk) issue_x(c + 1);               // in flight under this chunk's MFMAs
+    unsigned xcol = xlane + (unsigned)(c & 1) * (unsigned)(CK * XP * 4);
+    // the units loaded during the LAST chunk's last tap have no successor: wrap the pointer back to the tile's first chunk
+    // (valid memory, values unused) instead of branching around the load
+    const int jump = next_chunk ? last_step : -(((nchunks - 1) * GR * k + (k - 1)) * 256);
+    float bb[2][4][NI];
+    {
+      const char* xb = xs_bytes + xcol;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bb[0][q][ni] = *reinterpret_cast<const float*>(xb + 4 * ((2 * q) * XP + ni * 32));
+    }
+    for (int j = 0; j < k; ++j) {
+      const unsigned xnext = (j + 1 < k) ? xcol + tap_step : xcol;   // the chunk's last unit re-reads itself (unused)
+      // after consuming (g, j) the slot is refilled with (g, j+1); the unit loaded while j == k-1 is (g, 0) of the next chunk
+      // and the one loaded while j == k-2 is (g, k-1): the pointer must jump AFTER that one
+      const int step_after = (j + 2 == k || k == 1) ? jump : 256;
+#pragma unroll
+      for (int g = 0; g < GR; ++g) {
+        {
+          const char* xb = xs_bytes + (g + 1 < GR ? xcol : xnext);
+          const int grow = g + 1 < GR ? 8 * (g + 1) : 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              bb[(g & 1) ^ 1][q][ni] = *reinterpret_cast<const float*>(xb + 4 * ((grow + 2 * q) * XP + ni * 32));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const float a = q == 0 ? ar[g][mi].x : (q == 1 ? ar[g][mi].y : (q == 2 ? ar[g][mi].z : ar[g][mi].w));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[g & 1][q][ni], acc[mi][ni], 0, 0, 0);
+          }
+        load_unit(g, step_after);
+        // pin the emitted order: next unit's LDS reads FIRST (they land under this unit's MFMAs; left alone the scheduler
+        // sinks them below the MFMAs and every unit then starts with an exposed LDS round trip), MFMAs, ring load
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NI, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI * NI, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
+        __builtin_amdgcn_sched_barrier(0);        // keep program order: the ring's vmcnt distances stay GR - 1 units
+      }
+      xcol = xnext;
+    }
+    if (next_chunk) {
+      store_x(c + 1, (c + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue (identical to v1)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
+      if (col >= L.L) continue;
+      const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (MI * 32) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= P.cout) continue;
         float v = acc[mi][ni][r];
         if (P.bias) v += P.bias[row];
         if (P.bias2) v += P.bias2[(int64_t)b * P.bias2_bstride + row];
@@ -293,9 +544,6 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 // split-K kernel for small-N problems
 constexpr int SK_PD = 8;          // prefetch ring depth (units of 4 MFMAs)
 
-__device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
-  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
 
 template <bool MASK, int NWV>    // NWV waves per workgroup split K inside the workgroup
 __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunch L, const int mtiles, const int ntiles,
@@ -341,9 +589,9 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const int g0 = (int)(((int64_t)groups * sl) / nsl), g1 = (int)(((int64_t)groups * (sl + 1)) / nsl);
   const int U = (g1 - g0) * k;                   // units of (group, tap) = 4 MFMAs each
 
-  f32x16 acc;
+  f32x16 acc, acc2;                               // two accumulators on alternate K steps: see conv1d_mfma_kernel
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 
   const int tcol = t0 + l31 - P.pad_left;
   f32x4 ar[SK_PD];
@@ -399,9 +647,9 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
           bq[q] = x * cs;
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].x, bq[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].y, bq[1], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].y, bq[1], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].z, bq[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].w, bq[3], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].w, bq[3], acc2, 0, 0, 0);
       }
       load_unit(i);
       __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay SK_PD - 1 units
@@ -410,7 +658,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
 
   // reduce the waves' partial tiles through LDS
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r];
+  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r] + acc2[r];
   __syncthreads();
   const int col = t0 + (tid & 31);
   if (col >= L.L) return;
@@ -462,6 +710,21 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int m
   const int per_xcd = (ntx % 8 == 0 || ntx >= 64) ? (ntx + 7) / 8 : 0;      // contiguous per-XCD ranges only if they balance
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, mtiles * L.B, L.nprob);
   const int nxbuf = max_chunks > 1 ? 2 : 1;     // a single-chunk problem never re-stages its X tile
+  static const bool use_v1 = getenv("BV2_CONV_V1") != nullptr;
+  if (!use_v1) {
+    // v2: weights global -> registers, LDS holds only the (double-buffered) X chunk
+    if (ck == 32) {
+      const size_t lds = sizeof(float) * (size_t)(nxbuf * 32 * XS * 64);
+      auto kern = conv1d_mfma2_kernel<WM, WN, MI, NI, 32, XS>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
+    } else {
+      const size_t lds = sizeof(float) * (size_t)(nxbuf * 16 * XS * 64);
+      auto kern = conv1d_mfma2_kernel<WM, WN, MI, NI, 16, XS>;
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (ck == 32) {
     const size_t lds = sizeof(float) * (size_t)(2 * 8 * BM * 4 + 2 * 32 * XS * 64);
     const size_t lds1 = sizeof(float) * (size_t)(2 * 8 * BM * 4 + nxbuf * 32 * XS * 64);
