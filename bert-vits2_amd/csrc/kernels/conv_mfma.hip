@@ -6,15 +6,13 @@
 // Packed weight ("fragment order", written once by bv2_model.cpp):
 //      Wp[m-tile = co/32][group g = ci/8][tap j][lh = ci&1][co%32][q = (ci%8)/2]
 //   -> the four floats a lane needs as MFMA A operand (A[m = l&31][kk = l>>5]) for four consecutive K steps of one
-//      8-channel group are ONE aligned float4, both in HBM and in LDS (conflict-free ds_read_b128, 1 read per 4 MFMAs),
+//      8-channel group are ONE aligned float4 (one 16-byte global load per lane per 4 MFMAs, 1 KB per wave = one "unit"),
 //      and the weight stream of one 32-row output tile is contiguous (sequential reads: no L2-channel camping).
 //
 // Two kernels:
 //  * conv1d_mfma_kernel  — LDS-tiled, for problems with enough columns to fill the chip (the Generator, and every conv at
-//    large batch).  Per (C_in chunk, tap) step: weights global -> registers -> LDS (double buffered, loads in flight under
-//    the MFMAs); the activation tile Xs[CK][BN + (k-1)*dil] is prefetched into registers one chunk ahead, the
-//    pre-activation / 3-way branch mean / input mask are applied once per element while it is written to the other LDS
-//    buffer, and it is re-used by all k taps.  ONE barrier per step.
+//    large batch): weights global -> register ring, X chunk in LDS re-used by all k taps, one barrier per C_in chunk
+//    (details at the kernel).
 //  * conv1d_splitk_kernel — for the small-N problems of the text encoder / flow / duration predictors at small batch
 //    (N = T or T_y columns, a few hundred): 32x32 output tile per workgroup, the 4 waves split K (channel groups) and
 //    reduce through LDS; optionally K is also split ACROSS workgroups into `ksplit` partial slabs that the consumer
@@ -38,278 +36,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP
 __device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
-
-
-template <int WM, int WN, int MI, int NI, int CK, int XS>
-__global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles, const int per_xcd) {
-  constexpr int BM = WM * MI * 32;
-  constexpr int BN = WN * NI * 32;
-  constexpr int XP = XS * 64;                     // X tile row pitch (floats)
-  constexpr int RPW = CK / 4;                     // X rows staged per wave
-  constexpr int GR = CK / 8;                      // channel groups per chunk
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  constexpr int W4 = GR * 2 * BM;                 // float4 per weight tile
-  constexpr int NW4 = (W4 + 255) / 256;           // float4 per thread
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const ConvProb& P = L.p[blockIdx.z];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int wm = wid / WN, wn = wid % WN;
-  const int b = blockIdx.y / mtiles;
-  const int m0 = (blockIdx.y - b * mtiles) * BM;
-  // XCD-aware placement: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), gridDim.x is a multiple
-  // of 8, so XCD = blockIdx.x % 8 for every (y, z).  Give each XCD a CONTIGUOUS range of time tiles: neighbouring tiles
-  // share (k-1)*dil halo columns (up to 50 of 64) and the C_out/BM sibling tiles share the whole X tile — in one L2 those
-  // re-reads are hits instead of a second fetch from HBM.
-  // (per_xcd == 0: too few time tiles to split them over the XCDs evenly — plain mapping.)
-  const int vt = per_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-  const int t0 = vt * BN;
-  if (t0 >= L.L) return;
-  if (m0 >= P.cout_pad) return;                   // problems in one launch may have different C_out
-
-  // problem fields used in the main loop, hoisted into registers (P lives in the kernarg segment; re-reading it costs
-  // an s_load + lgkmcnt wait at every use)
-  const int k = P.k, dil = P.dil, cin = P.cin, nsrc = P.nsrc;
-  int Lin = P.Lin;
-  if (L.lens) {                                   // exact lengths: this batch item's input ends at lens[b]*len_mul
-    const int64_t lv = L.lens[b] * L.len_mul;
-    Lin = lv < Lin ? (int)lv : Lin;
-    if (t0 >= Lin) return;                        // a tile wholly past the utterance: nobody reads its outputs
-  }
-  const float in_scale = P.in_scale, slope = P.slope;
-  const bool lrelu = P.pre_act == PRE_LRELU;
-  // per-batch base pointers (wave-uniform -> SGPR pairs); element offsets inside one batch item fit 32 bits
-  const float* const x0p = P.x[0] + (int64_t)b * P.x_bstride;
-  const float* const x1p = P.x[1] ? P.x[1] + (int64_t)b * P.x_bstride : nullptr;
-  const float* const x2p = P.x[2] ? P.x[2] + (int64_t)b * P.x_bstride : nullptr;
-  const float* const maskp = P.in_mask ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
-  const int x_rstride = P.x_rstride;
-  const int XW = BN + (k - 1) * dil;
-  const int nchunks = P.cin_pad / CK;
-  const int groups = P.cin_pad / 8;
-  const int nsteps = nchunks * k;
-  f32x4* Ws = reinterpret_cast<f32x4*>(smem);     // [2][GR][2][BM] float4
-  float* Xs = smem + 2 * W4 * 4;                  // [nchunks > 1 ? 2 : 1][CK][XP]
-
-  // A wave with ONE output tile would chain every MFMA on the previous one's accumulator; with anything issued between two
-  // dependent MFMAs the pipe inserts a ~43-cycle bubble (MI355X_MICROARCH.md, per-instruction constants).  Two accumulators
-  // taking alternate K steps (summed in the epilogue) double the dependency distance.
-  constexpr int NA = (MI * NI == 1) ? 2 : 1;
-  f32x16 acc[NA][MI][NI];
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][mi][ni][r] = 0.f;
-
-  f32x4 wreg[NW4];
-  float xr[RPW][XS];
-  float xm[XS];
-  const f32x4* wg = reinterpret_cast<const f32x4*>(P.w);
-  const int mt0 = m0 >> 5;
-
-  // weight tile of step (chunk c, tap j): for each of the BM/32 m-tiles, GR pieces of [lh][32 rows] float4 (1 KB each)
-  auto issue_w = [&](int c, int j) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < NW4; ++q) {
-      const int idx = tid + q * 256;
-      if (W4 % 256 == 0 || idx < W4) {
-        const int r = idx & 63, gl = (idx >> 6) % GR, mtl = idx / (64 * GR);           // r = lh*32 + row
-        wreg[q] = wg[((int64_t)((mt0 + mtl) * groups + c * GR + gl) * k + j) * 64 + r];
-      }
-    }
-  };
-  auto store_w = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < NW4; ++q) {
-      const int idx = tid + q * 256;
-      if (W4 % 256 == 0 || idx < W4) {
-        const int r = idx & 63, gl = (idx >> 6) % GR, mtl = idx / (64 * GR);
-        Ws[buf * W4 + (gl * 2 + (r >> 5)) * BM + mtl * 32 + (r & 31)] = wreg[q];     // LDS: [gl][lh][BM]
-      }
-    }
-  };
-  // X prefetch: branch-free, unconditional loads from CLAMPED addresses (so nothing waits on a load before the MFMAs);
-  // zero padding / the channel tail / the input mask are applied when the registers are written to LDS.
-  const int tbase = t0 - P.pad_left;
-  unsigned tc[XS];
-  float colsc[XS];                                // in_scale for real columns, 0 for padding / beyond the tile
-#pragma unroll
-  for (int s = 0; s < XS; ++s) {
-    const int t = tbase + lane + 64 * s;
-    const bool tok = (lane + 64 * s < XW) && t >= 0 && t < Lin;
-    colsc[s] = tok ? in_scale : 0.f;
-    tc[s] = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));   // byte offset
-  }
-  auto issue_x = [&](int c) __attribute__((always_inline)) {
-    unsigned roff[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      int cg = c * CK + wid * RPW + r;
-      cg = cg < cin ? cg : cin - 1;
-      roff[r] = 4u * (unsigned)cg * (unsigned)x_rstride;
-    }
-    if (maskp) {
-#pragma unroll
-      for (int s = 0; s < XS; ++s) xm[s] = ld_off(maskp, tc[s]);
-    } else {
-#pragma unroll
-      for (int s = 0; s < XS; ++s) xm[s] = 1.f;
-    }
-    if (nsrc == 1) {
-#pragma unroll
-      for (int s = 0; s < XS; ++s)
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) xr[r][s] = ld_off(x0p, roff[r] + tc[s]);
-    } else {
-      // mean of the ResBlock branches (Generator ups inputs): one source per pass, passes fenced so that the register
-      // footprint stays one tile + one pass of temporaries instead of nsrc tiles
-#pragma unroll
-      for (int s = 0; s < XS; ++s)
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) xr[r][s] = ld_off(x0p, roff[r] + tc[s]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < XS; ++s)
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) xr[r][s] += ld_off(x1p, roff[r] + tc[s]);
-      if (nsrc > 2) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < XS; ++s)
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) xr[r][s] += ld_off(x2p, roff[r] + tc[s]);
-      }
-    }
-  };
-  auto store_x = [&](int c, int buf) __attribute__((always_inline)) {
-    float* dst = Xs + buf * (CK * XP) + (wid * RPW) * XP + lane;
-    const int rows_ok = cin - (c * CK + wid * RPW);                // rows r < rows_ok are real channels
-#pragma unroll
-    for (int s = 0; s < XS; ++s) {
-      const float sc = colsc[s] * xm[s];
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        float v = xr[r][s];
-        const float vn = v * slope;
-        v = (lrelu && v < 0.f) ? vn : v;
-        v *= sc;
-        dst[r * XP + 64 * s] = r < rows_ok ? v : 0.f;
-      }
-    }
-  };
-
-  // prologue
-  issue_w(0, 0);
-  issue_x(0);
-  store_w(0);
-  store_x(0, 0);
-  __syncthreads();
-
-  int c = 0, j = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    const bool more = (step + 1) < nsteps;
-    const bool last_tap = (j == k - 1);
-    const bool next_chunk = (c + 1) < nchunks;
-    if (more) issue_w(last_tap ? c + 1 : c, last_tap ? 0 : j + 1);   // global loads stay in flight under the MFMAs
-    if (j == 0 && next_chunk) issue_x(c + 1);
-
-    const f32x4* wsb = Ws + buf * W4 + lh * BM + wm * (MI * 32) + l31;
-    const float* xsb = Xs + (c & 1) * (CK * XP) + lh * XP + wn * (NI * 32) + l31 + j * dil;
-    // software-pipelined operand reads: the LDS reads of K-step u+1 are issued before the MFMAs of step u
-    f32x4 a4[MI], a4n[MI];
-    float bb[NI], bbn[NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a4[mi] = wsb[mi * 32];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bb[ni] = xsb[ni * 32];
-#pragma unroll
-    for (int g = 0; g < GR; ++g) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < 3) {
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bbn[ni] = xsb[(8 * g + 2 * (q + 1)) * XP + ni * 32];
-        } else if (g + 1 < GR) {
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bbn[ni] = xsb[(8 * (g + 1)) * XP + ni * 32];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) a4n[mi] = wsb[(g + 1) * 2 * BM + mi * 32];
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const float a = q == 0 ? a4[mi].x : (q == 1 ? a4[mi].y : (q == 2 ? a4[mi].z : a4[mi].w));
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[q % NA][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[ni], acc[q % NA][mi][ni], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bb[ni] = bbn[ni];
-        if (q == 3) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) a4[mi] = a4n[mi];
-        }
-        // pin the emitted order: next step's LDS reads first, then this step's MFMAs (reads land under the MFMAs)
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
-      }
-    }
-
-    if (more) store_w(buf ^ 1);
-    if (last_tap && next_chunk) store_x(c + 1, (c + 1) & 1);
-    __syncthreads();
-    if (last_tap) { j = 0; ++c; } else ++j;
-  }
-
-  // epilogue
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
-      if (col >= L.L) continue;
-      const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (MI * 32) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= P.cout) continue;
-        float v = NA == 2 ? acc[0][mi][ni][r] + acc[NA - 1][mi][ni][r] : acc[0][mi][ni][r];
-        if (P.bias) v += P.bias[row];
-        if (P.bias2) v += P.bias2[(int64_t)b * P.bias2_bstride + row];
-        if (P.act == ACT_RELU) v = fmaxf(v, 0.f);
-        if (P.mask_pre) v *= om;
-        const int64_t oidx = (int64_t)row * P.out_rstride + (int64_t)col * P.out_tstride + P.out_toff;
-        if (P.res_mode == RES_ADD) v += P.res[(int64_t)b * P.res_bstride + oidx];
-        else if (P.res_mode == RES_RSUB) v = P.res[(int64_t)b * P.res_bstride + oidx] - v;
-        if (P.mask_post) v *= om;
-        P.out[(int64_t)b * P.out_bstride + oidx] = v;
-      }
-    }
-  }
-}
-
 __device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// conv1d_mfma2_kernel — same tiling and epilogue as conv1d_mfma_kernel, different operand plumbing:
-//   * weights never touch LDS: every wave streams the A fragments of its own MI m-tiles global -> registers through a ring of
-//     GR (group, tap) units (1 KB each, the packed stream of one m-tile is contiguous over (group, tap), so the ring just
-//     walks it and is never drained between chunks);
-//   * the X chunk [CK][BN + halo] is the only LDS tenant (double buffered, register-prefetched one chunk ahead), and the
-//     workgroup synchronises ONCE PER CHUNK (GR*k units = 16*k MFMAs per wave) instead of once per (chunk, tap) step.
-// v1 spends a barrier + a weight-tile LDS round trip every 16 MFMAs; at batch 1, where a CU holds 1-3 workgroups, those
-// bubbles are not covered by other waves (profiles/r01_h_pmc_summary.md: 0.52 MFMA utilisation).
+// conv1d_mfma_kernel — LDS-tiled implicit-GEMM conv for problems with enough columns to fill the chip (the Generator, and
+// every conv at large batch).  Workgroup = 4 waves = WM x WN, wave tile = MI x NI blocks of 32x32, BM x BN outputs.
+//   * weights never touch LDS: every wave streams the A fragments of its own MI m-tiles global -> registers through a ring
+//     with one slot per channel group of the chunk (slot g: unit (g, tap j) is followed by (g, j+1), after the last tap by
+//     (g, 0) of the next chunk — the ring is never drained);
+//   * the X chunk [CK][BN + halo] is the only LDS tenant (double buffered, register-prefetched one chunk ahead; the
+//     pre-activation / 3-way branch mean / input mask are applied once per element while it is written), re-used by all k
+//     taps, and the workgroup synchronises ONCE PER CHUNK (GR*k units = 16*k MFMAs per wave);
+//   * inside a chunk the units run tap-major (all groups of tap j, then tap j+1): LDS rows are immediate offsets, a tap is
+//     one VGPR add, and the next unit's B operands are read while the current unit's MFMAs run (order pinned with
+//     sched_group_barrier: 63 instructions per 16 MFMAs).
+// (An earlier form staged the weights through LDS with a barrier every 16 MFMAs: 113 instructions per 16 MFMAs, 92 TF where
+// this one reaches 103 TF on the C=128 stage at batch 1; tools/probe/mfma_probe.hip shows why — every VALU / LDS-dependent
+// instruction between MFMAs costs issue slots the 64-cycle fp32 MFMA cannot hide at 1-3 waves per SIMD.)
 template <int WM, int WN, int MI, int NI, int CK, int XS>
-__global__ void __launch_bounds__(256) conv1d_mfma2_kernel(const ConvLaunch L, const int mtiles, const int per_xcd) {
+__global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles, const int per_xcd) {
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
   constexpr int XP = XS * 64;
@@ -710,33 +457,16 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int m
   const int per_xcd = (ntx % 8 == 0 || ntx >= 64) ? (ntx + 7) / 8 : 0;      // contiguous per-XCD ranges only if they balance
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, mtiles * L.B, L.nprob);
   const int nxbuf = max_chunks > 1 ? 2 : 1;     // a single-chunk problem never re-stages its X tile
-  static const bool use_v1 = getenv("BV2_CONV_V1") != nullptr;
-  if (!use_v1) {
-    // v2: weights global -> registers, LDS holds only the (double-buffered) X chunk
-    if (ck == 32) {
-      const size_t lds = sizeof(float) * (size_t)(nxbuf * 32 * XS * 64);
-      auto kern = conv1d_mfma2_kernel<WM, WN, MI, NI, 32, XS>;
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
-    } else {
-      const size_t lds = sizeof(float) * (size_t)(nxbuf * 16 * XS * 64);
-      auto kern = conv1d_mfma2_kernel<WM, WN, MI, NI, 16, XS>;
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
-    }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-  }
+  // weights go global -> registers; LDS holds only the (double-buffered) X chunk
   if (ck == 32) {
-    const size_t lds = sizeof(float) * (size_t)(2 * 8 * BM * 4 + 2 * 32 * XS * 64);
-    const size_t lds1 = sizeof(float) * (size_t)(2 * 8 * BM * 4 + nxbuf * 32 * XS * 64);
+    const size_t lds = sizeof(float) * (size_t)(nxbuf * 32 * XS * 64);
     auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 32, XS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles, per_xcd);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
   } else {
-    const size_t lds = sizeof(float) * (size_t)(2 * 4 * BM * 4 + 2 * 16 * XS * 64);
-    const size_t lds1 = sizeof(float) * (size_t)(2 * 4 * BM * 4 + nxbuf * 16 * XS * 64);
+    const size_t lds = sizeof(float) * (size_t)(nxbuf * 16 * XS * 64);
     auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 16, XS>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds1, stream, L, mtiles, per_xcd);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -74,6 +74,9 @@ __device__ __forceinline__ void hc_gemm(f32x16 (&acc)[NI], const uint16_t* wp, i
         j = jn; s = sn;
       }
       load_unit(i);
+      __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);   // next unit's LDS reads first, then the MFMAs, then the ring load
+      __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay HC_PD - 1 units
     }
   }

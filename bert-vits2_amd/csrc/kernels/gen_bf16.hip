@@ -130,6 +130,10 @@ __device__ __forceinline__ void cl_gemm(f32x16 (&acc)[MI][NI], const uint16_t* w
         j = jn; s = sn;
       }
       load_unit(i);
+      // pin the emitted order: next unit's LDS reads first (they land under this unit's MFMAs), MFMAs, ring loads
+      __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
       __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay PD - 1 units
     }
   }

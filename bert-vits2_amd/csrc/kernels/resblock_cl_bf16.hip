@@ -77,6 +77,9 @@ __device__ __forceinline__ void rb_gemm(f32x16 (&acc)[NI], Ring& ring, int U, in
         j = jn; s = sn;
       }
       ring.load(i);
+      __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);   // next unit's LDS reads first, then the MFMAs, then the ring load
+      __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_barrier(0);          // keep program order: the ring's vmcnt distances stay RBCL_PD - 1 units
     }
   }

@@ -56,20 +56,32 @@ __device__ __forceinline__ void rf_gemm(f32x16& acc, const float* wp, unsigned w
   };
 #pragma unroll
   for (int i = 0; i < RF_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  // operands of unit u+1 are read from LDS before unit u's MFMAs are issued (software pipeline, order pinned below)
   int g = 0, j = 0;
+  float bq[2][4];
+  {
+    const float* b = bs + lh * bp + col0;
+    bq[0][0] = b[0]; bq[0][1] = b[2 * bp]; bq[0][2] = b[4 * bp]; bq[0][3] = b[6 * bp];
+  }
   for (int u0 = 0; u0 < U; u0 += RF_PD) {
 #pragma unroll
     for (int i = 0; i < RF_PD; ++i) {
       if (u0 + i < U) {
-        const float* b = bs + (8 * g + lh) * bp + col0 + j * tstep;
-        const float b0 = b[0], b1 = b[2 * bp], b2 = b[4 * bp], b3 = b[6 * bp];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].x, b0, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].y, b1, acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].z, b2, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].w, b3, acc2, 0, 0, 0);
-        if (++j == k) { j = 0; ++g; }
+        int jn = j + 1, gn = g;
+        if (jn == k) { jn = 0; ++gn; }
+        const bool more = u0 + i + 1 < U;
+        const float* b = bs + (8 * (more ? gn : g) + lh) * bp + col0 + (more ? jn : j) * tstep;
+        bq[(i & 1) ^ 1][0] = b[0]; bq[(i & 1) ^ 1][1] = b[2 * bp]; bq[(i & 1) ^ 1][2] = b[4 * bp]; bq[(i & 1) ^ 1][3] = b[6 * bp];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].x, bq[i & 1][0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].y, bq[i & 1][1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].z, bq[i & 1][2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].w, bq[i & 1][3], acc2, 0, 0, 0);
+        j = jn; g = gn;
       }
       load_unit(i);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
