@@ -576,7 +576,14 @@ int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i,
 int bv2_test_attention(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,
                        int B, int H, int D, int T, int W) {
   AttnArgs a;
-  a.qkv = qkv; a.ld = ld; a.mask = mask; a.erv = erv; a.out = out; a.B = B; a.H = H; a.D = D; a.T = T; a.W = W;
+  a.qkv = qkv; a.ld = ld; a.mask = mask; a.erv = erv; a.out = out; a.B = B; a.H = H; a.D = D; a.T = T; a.W = W; a.f16 = 0;
+  return launch_attention(static_cast<hipStream_t>(stream), a);
+}
+
+int bv2_test_attention_f16(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,
+                           int B, int H, int D, int T, int W) {
+  AttnArgs a;
+  a.qkv = qkv; a.ld = ld; a.mask = mask; a.erv = erv; a.out = out; a.B = B; a.H = H; a.D = D; a.T = T; a.W = W; a.f16 = 1;
   return launch_attention(static_cast<hipStream_t>(stream), a);
 }
 

@@ -171,7 +171,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     }
     AttnArgs a;
     a.qkv = b.qkv; a.ld = ld; a.mask = mask; a.erv = c.W(L.erv.off); a.out = b.att;
-    a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow;
+    a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow; a.f16 = f16 ? 1 : 0;
     if (!c.rc) {
       const int pi = c.prof_begin("attention");
       const int r = launch_attention(c.s, a);

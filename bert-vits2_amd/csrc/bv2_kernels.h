@@ -241,6 +241,7 @@ struct AttnArgs {
   const float* erv;         // [2W+1][D]
   float* out;               // [B][H*D][T]
   int B, H, D, T, W;
+  int f16;                  // 1: QK^T and PV on the fp16 matrix core (operands rounded in registers, everything else fp32)
 };
 int launch_attention(hipStream_t stream, const AttnArgs& a);
 double attention_flops(const AttnArgs& a);

@@ -25,6 +25,7 @@ namespace bv2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // wave-uniform base (SGPR pair) + 32-bit per-lane BYTE offset: one VGPR per address instead of a 64-bit pair
 __device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
@@ -39,7 +40,16 @@ constexpr int AK = 32;          // keys per tile
 constexpr int AMAXW = 8;        // max window
 constexpr int ANS = 4;          // merge slots
 
-template <int DT, int NW>       // D = 32*DT head channels, NW waves
+// F16 = true (bv2_set_flow_dtype(BV2_F16)): the two matrix products run on v_mfma_f32_32x32x16_f16 — 12 MFMAs per key tile
+// instead of 96 fp32 ones.  Nothing else changes: K / V / Q are still read as fp32 and rounded to fp16 in registers, the
+// logits, softmax, running max / sum, output accumulators and the merge stay fp32.  The operand fragments need no data
+// movement: an fp16 MFMA takes 8 K-indices per lane, and any K-index <-> channel (or key) assignment works as long as both
+// operands use the same one, so
+//   S^T step t (16 channels): A = the lane's kreg[8t .. 8t+7] (channels 2(8t+e)+lh), B = the same channels of Q, which the
+//                             staging loop stores in LDS as fp16 in exactly that order (one ds_read_b128 per step);
+//   O^T step s (16 keys):     B = the lane's S registers 8s .. 8s+7 (its own D-layout rows), A = vreg[m][2s], vreg[m][2s+1]
+//                             (the float4s that hold exactly those keys).
+template <int DT, int NW, bool F16>       // D = 32*DT head channels, NW waves
 __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   constexpr int D = 32 * DT;
   constexpr int NT = 64 * NW;
@@ -95,9 +105,17 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   }
   const float mi = iok ? mp[iq] : 0.f;
   // query tile and Ev -> LDS (all threads)
+  constexpr int QP = D + 8;                         // fp16 row pitch of the transposed query tile (odd multiple of 16 B)
+  _Float16* Qh = reinterpret_cast<_Float16*>(Qs);   // F16: [AQ][QP], row i holds Q[2(8t+e)+lh][i] at t*16 + lh*8 + e
   for (int e = tid; e < D * AQ; e += NT) {
     const int c = e >> 5, i = e & 31;
-    Qs[e] = qp[c * ld + i0 + i];                    // columns beyond T: finite-or-not garbage, dead columns below
+    const float qv = qp[c * ld + i0 + i];           // columns beyond T: finite-or-not garbage, dead columns below
+    if (F16) {
+      const int h2 = c & 1, u = c >> 1;             // c = 2u + lh, u = 8t + e
+      Qh[i * QP + (u >> 3) * 16 + h2 * 8 + (u & 7)] = (_Float16)((i0 + i < T) ? qv : 0.f);
+    } else {
+      Qs[e] = qv;
+    }
   }
   for (int e = tid; e < NR * D; e += NT) Ev[e] = A.erv[e];
   __syncthreads();
@@ -117,6 +135,16 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     f32x16 S;
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    if (F16) {
+#pragma unroll
+      for (int t = 0; t < D / 16; ++t) {
+        f16x8 ka;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ka[e] = (_Float16)kreg[8 * t + e];
+        const f16x8 qf = *reinterpret_cast<const f16x8*>(Qh + l31 * QP + t * 16 + lh * 8);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf, S, 0, 0, 0);
+      }
+    } else {
     // the Q operand streams from LDS a few K-steps ahead of the MFMAs (pinned: hoisting all D/2 reads costs registers)
     float qb[4];
 #pragma unroll
@@ -128,6 +156,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       S = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qcur, S, 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);             // keep the V loads BEHIND the S MFMAs (K registers are free again)
     issue_v(j0);                                   // in flight under the softmax
@@ -175,6 +204,29 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
         for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
     }
     // ---- O^T += V P^T, K-steps in D-layout row order
+    if (F16) {
+      f16x8 pf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[s2][e] = (_Float16)S[8 * s2 + e];
+#pragma unroll
+      for (int m = 0; m < DT; ++m) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          f32x4 va = vreg[m][2 * s2], vb = vreg[m][2 * s2 + 1];
+          const int ja = j0 + 16 * s2 + 4 * lh, jb2 = ja + 8;
+          if (jb2 + 3 >= T) {                                 // tile tail: keys that do not exist contribute exactly 0
+            va.x = ja + 0 < T ? va.x : 0.f; va.y = ja + 1 < T ? va.y : 0.f; va.z = ja + 2 < T ? va.z : 0.f; va.w = ja + 3 < T ? va.w : 0.f;
+            vb.x = jb2 + 0 < T ? vb.x : 0.f; vb.y = jb2 + 1 < T ? vb.y : 0.f; vb.z = jb2 + 2 < T ? vb.z : 0.f; vb.w = jb2 + 3 < T ? vb.w : 0.f;
+          }
+          f16x8 vf;
+          vf[0] = (_Float16)va.x; vf[1] = (_Float16)va.y; vf[2] = (_Float16)va.z; vf[3] = (_Float16)va.w;
+          vf[4] = (_Float16)vb.x; vf[5] = (_Float16)vb.y; vf[6] = (_Float16)vb.z; vf[7] = (_Float16)vb.w;
+          O[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], O[m], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < DT; ++m) {
 #pragma unroll
@@ -190,6 +242,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
         O[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.z, S[4 * g4 + 2], O[m], 0, 0, 0);
         O[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.w, S[4 * g4 + 3], O[m], 0, 0, 0);
       }
+    }
     }
   }
 
@@ -258,13 +311,18 @@ static size_t attn_lds_bytes(int D, int NW) {
   return sizeof(float) * (size_t)(ANS * D * AQ + D * AQ + (2 * AMAXW + 1) * D + (2 * AMAXW + 1) * AQ + 2 * NW * AQ);
 }
 
-template <int DT, int NW>
-static int launch_attn_variant(hipStream_t stream, const AttnArgs& a, dim3 grid) {
+template <int DT, int NW, bool F16>
+static int launch_attn_variant2(hipStream_t stream, const AttnArgs& a, dim3 grid) {
   const size_t lds = attn_lds_bytes(32 * DT, NW);
-  auto kern = attention_kernel<DT, NW>;
+  auto kern = attention_kernel<DT, NW, F16>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int DT, int NW>
+static int launch_attn_variant(hipStream_t stream, const AttnArgs& a, dim3 grid) {
+  return a.f16 ? launch_attn_variant2<DT, NW, true>(stream, a, grid) : launch_attn_variant2<DT, NW, false>(stream, a, grid);
 }
 
 template <int DT>

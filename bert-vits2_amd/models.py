@@ -179,8 +179,9 @@ class SynthesizerTrn(nn.Module):
     def set_flow_dtype(self, dtype) -> None:
         """Arithmetic of the transformer flow's Encoder convolutions (fused q/k/v, conv_o, FFN): ``torch.float32``
         (default) or ``torch.float16`` (fp16 weights / conv inputs / FFN hidden, fp32 accumulate — BASELINE config 5
-        "fp16 flow + fp32 spline"; the reference's counterpart is ``flow`` under ``torch.autocast(float16)``).  LayerNorm,
-        the attention core, the residual stream and everything before the flow stay fp32: durations are unchanged."""
+        "fp16 flow + fp32 spline"; the reference's counterpart is ``flow`` under ``torch.autocast(float16)``); the attention
+        core's QK^T / PV products take fp16 operands too.  LayerNorm, softmax, the residual stream and everything before the
+        flow stay fp32: durations are unchanged."""
         lib = self._ensure_handle()
         code = {torch.float32: L.F32, "fp32": L.F32, "f32": L.F32, torch.float16: L.F16, "fp16": L.F16, "f16": L.F16}.get(dtype)
         if code is None:

@@ -90,9 +90,10 @@ int bv2_set_generator_dtype(bv2_handle* h, int dtype);
 /* Arithmetic of the transformer flow's Encoder convolutions (BASELINE config 5 "fp16 flow + fp32 spline"): the fused
  * q/k/v projection, conv_o and the FFN conv_1/conv_2 of TransformerCouplingLayer.enc (reference modules.py:561-580,
  * attentions.py:103-120, 263-266, 438-446) — 95 % of the flow's FLOPs.  BV2_F32 (default) or BV2_F16
- * (v_mfma_f32_32x32x16_f16: fp16 weights and conv inputs, fp32 accumulation; the FFN hidden activation is stored fp16).
- * LayerNorm, softmax / attention core, the residual stream, pre/post and everything before the flow (text encoder,
- * durations, spline) stay fp32, so durations and the alignment path are unchanged.  The reference's counterpart is running
+ * (v_mfma_f32_32x32x16_f16: fp16 weights and conv inputs, fp32 accumulation; the FFN hidden activation is stored fp16;
+ * the attention core's two matrix products QK^T and PV take their operands rounded to fp16 in registers).
+ * LayerNorm, logits / softmax / running statistics, the residual stream, pre/post and everything before the flow (text
+ * encoder, durations, spline) stay fp32, so durations and the alignment path are unchanged.  The reference's counterpart is running
  * flow under torch.autocast(float16).  Only the transformer flow has an fp16 form (returns -2 otherwise). */
 int bv2_set_flow_dtype(bv2_handle* h, int dtype);
 

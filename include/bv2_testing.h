@@ -57,6 +57,9 @@ int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i,
  * rows are the relative-key logits q_i·Ek[r]/sqrt(D)), ld % 32 == 0, mask [B][T], erv [2W+1][D], out [B][H*D][T] (all DEVICE) */
 int bv2_test_attention(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,
                        int B, int H, int D, int T, int W);
+/* the same with QK^T / PV on the fp16 matrix core (bv2_set_flow_dtype(BV2_F16)) */
+int bv2_test_attention_f16(void* stream, const float* qkv, int ld, const float* mask, const float* erv, float* out,
+                       int B, int H, int D, int T, int W);
 
 /* channel LayerNorm family (see bv2_kernels.h LnArgs); all DEVICE pointers, nullable where optional */
 int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode, const float* dww, const float* dwb, int dil,
