@@ -139,9 +139,67 @@ __device__ __forceinline__ void cl_gemm(f32x16 (&acc)[MI][NI], const uint16_t* w
   }
 }
 
+// Tap-major form of the same product for C_in = 16*G known at compile time (G = 4 / 8 / 16: the ResBlock convs of the wide
+// stages).  The generic loop above spends ~9 scalar / vector instructions per MFMA on unit bookkeeping (tap wrap, LDS
+// address arithmetic with runtime pitch, end-of-stream clamps, a branch per unit) — more than a 32-cycle bf16 MFMA hides
+// from one wave.  Here the ring has one slot per 16-channel group (slot s: unit (s, tap j) is followed by (s, j+1)), the
+// groups of a tap are a fully unrolled inner loop, every LDS offset is an immediate (pitch = 16*G + 8 is a constant) and
+// a tap costs one pointer add: NI ds_read_b128 + NI MFMAs + 1 global load + 2 scalar adds per unit.
+// explicit global address space: pointers kept in an array and advanced in a loop defeat the address-space inference, and a
+// FLAT load counts on lgkmcnt as well — every LDS wait would then also wait for the weight ring
+typedef __attribute__((address_space(1))) bf16x8 GlobalFrag;
+template <int MI, int NI, int G>
+__device__ __forceinline__ void cl_gemm_tm(f32x16 (&acc)[MI][NI], const uint16_t* wbase, int64_t mstride, unsigned wlane_bytes,
+                                           int k, const unsigned short* xb, int tstep) {   // wbase: wave-uniform stream start
+  constexpr int PITCH = 16 * G + 8;
+  static_assert(G % 2 == 0, "the B double buffer alternates with the group index");
+  bf16x8 ar[G][MI];
+  const uint16_t* wq[G][MI];
+  const int first_step = k > 1 ? 512 : 0;
+#pragma unroll
+  for (int s = 0; s < G; ++s) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      wq[s][mi] = wbase + mi * mstride + (int64_t)s * k * 512;
+      ar[s][mi] = *(const GlobalFrag*)(reinterpret_cast<const char*>(wq[s][mi]) + wlane_bytes);
+      wq[s][mi] += first_step;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16x8 bb[2][NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bb[0][ni] = *reinterpret_cast<const bf16x8*>(xb + ni * 32 * PITCH);
+  const unsigned short* xrow = xb;
+  for (int j = 0; j < k; ++j) {
+    const unsigned short* xnext = (j + 1 < k) ? xrow + tstep * PITCH : xrow;   // after the last tap: re-read (unused)
+    const int step = (j + 2 < k) ? 512 : 0;       // slot s is refilled with (s, j+1); the last tap's unit is not followed
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const unsigned short* xn = (s + 1 < G) ? xrow + (s + 1) * 16 : xnext;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bb[(s & 1) ^ 1][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * PITCH);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[s][mi], bb[s & 1][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        ar[s][mi] = *(const GlobalFrag*)(reinterpret_cast<const char*>(wq[s][mi]) + wlane_bytes);
+        wq[s][mi] += step;
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    xrow = xnext;
+  }
+}
+
 // workgroup = WN x WM waves; wave (wn, wm) owns MI 32-channel output tiles starting at 32*MI*(cg*WN + wn) and NI 32-step
 // time tiles starting at t0 + 32*NI*wm
-template <int WN, int WM, int MI, int NI>
+template <int WN, int WM, int MI, int NI, int G>   // G > 0: C_in = 16*G for every problem of the launch (tap-major GEMM)
 __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
   constexpr int NT = 64 * WN * WM;
   constexpr int WT = 32 * NI;
@@ -182,9 +240,14 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
   const int U = (cin >> 4) * k;
   // a wave whose second m-tile lies beyond cout_pad streams the first one twice (results of the copy are dropped)
   const int64_t mstride = (MI > 1 && (mt0 + 1) * 32 < P.cout_pad) ? (int64_t)U * 512 : 0;
-  if (active)
-    cl_gemm<MI, NI, PD>(acc, P.w + (int64_t)mt0 * U * 512 + lane * 8, mstride, U, k, xs + (wm * WT + l31) * pitch + lh * 8,
-                        pitch, dil);
+  if (active) {
+    if constexpr (G > 0)
+      cl_gemm_tm<MI, NI, G>(acc, P.w + (int64_t)mt0 * U * 512, mstride, 16u * (unsigned)lane, k,
+                            xs + (wm * WT + l31) * pitch + lh * 8, dil);
+    else
+      cl_gemm<MI, NI, PD>(acc, P.w + (int64_t)mt0 * U * 512 + lane * 8, mstride, U, k, xs + (wm * WT + l31) * pitch + lh * 8,
+                          pitch, dil);
+  }
 
   // ---- epilogue through LDS.  In the D fragment a lane holds 4 consecutive channels of ONE time step, i.e. 8-byte pieces
   // 2*C bytes apart in HBM: stored (and, for the residual, loaded) directly, every wave instruction touches 32 different
@@ -254,7 +317,7 @@ bool conv_cl_bf16_supported(int cin, int cout, int k, int dil) {
   return (int64_t)(128 + (k - 1) * dil) * (cin + 8) * 2 <= 160 * 1024;
 }
 
-template <int WN, int WM, int MI, int NI>
+template <int WN, int WM, int MI, int NI, int G = 0>
 static int launch_cl_variant(hipStream_t stream, const ClLaunch& L, int nt, size_t lds_rows_extra, int cin) {
   constexpr int BT = WM * 32 * NI;
   const size_t lds_in = (size_t)(BT + lds_rows_extra) * (size_t)(cin + 8) * 2;
@@ -263,7 +326,7 @@ static int launch_cl_variant(hipStream_t stream, const ClLaunch& L, int nt, size
   if (lds > 160 * 1024) return -2;
   const int ngrp = (nt + WN * MI - 1) / (WN * MI);
   dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
-  auto kern = conv_cl_bf16_kernel<WN, WM, MI, NI>;
+  auto kern = conv_cl_bf16_kernel<WN, WM, MI, NI, G>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN * WM), lds, stream, L, ngrp);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -299,23 +362,37 @@ int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** vari
   // variant ids: 0 = 8x1 (8 waves x [32 ch x 128 t]), 1 = 4x1, 2 = 2x2, 3 = 1x4, then the 2 x NI register-blocked forms
   // 4 = 4x1 MI2 NI4 (4 waves x [64 ch x 128 t]), 5 = 2x2 MI2 NI4, 6 = 2x4 MI2 NI2, 7 = 1x4 MI2 NI4, 8 = 4x2 MI2 NI2, 9 = 1x8 MI2 NI2
   int v = forced_variant(nt);
-  if (v < 0) v = nt >= 8 ? 0 : (nt >= 3 ? 1 : (nt == 2 ? 2 : 3));
+  // measured at B=32 (profiles/r01_j_*): C=64 is fastest as 8 waves x [64 ch x 64 t] (2x2 register blocking: every B fragment
+  // feeds two MFMAs), C >= 128 as one 32-channel tile per wave x 128 t (the 2 x NI forms lose more to fewer resident waves
+  // than they gain in LDS traffic)
+  if (v < 0) v = nt >= 8 ? 0 : (nt >= 3 ? 1 : (nt == 2 ? (cin == 64 ? 9 : 2) : 3));
   static const char* names[] = {"conv_cl_bf16<8x1>", "conv_cl_bf16<4x1>", "conv_cl_bf16<2x2>", "conv_cl_bf16<1x4>",
                                 "conv_cl_bf16<4x1,2x4>", "conv_cl_bf16<2x2,2x4>", "conv_cl_bf16<2x4,2x2>", "conv_cl_bf16<1x4,2x4>",
                                 "conv_cl_bf16<4x2,2x2>", "conv_cl_bf16<1x8,2x2>"};
+  static const bool generic = getenv("BV2_CL_GENERIC") != nullptr;
   int r = -1;
   for (int attempt = 0; attempt < 2; ++attempt) {
     switch (v) {
-      case 0: r = launch_cl_variant<8, 1, 1, 4>(stream, L, nt, extra, cin); break;
-      case 1: r = launch_cl_variant<4, 1, 1, 4>(stream, L, nt, extra, cin); break;
-      case 2: r = launch_cl_variant<2, 2, 1, 4>(stream, L, nt, extra, cin); break;
+      // C_in known at compile time for the ResBlock widths: tap-major GEMM (BV2_CL_GENERIC forces the generic loop)
+      case 0: r = (cin == 256 && !generic) ? launch_cl_variant<8, 1, 1, 4, 16>(stream, L, nt, extra, cin)
+                                           : launch_cl_variant<8, 1, 1, 4>(stream, L, nt, extra, cin); break;
+      case 1: r = (cin == 128 && !generic) ? launch_cl_variant<4, 1, 1, 4, 8>(stream, L, nt, extra, cin)
+                                           : launch_cl_variant<4, 1, 1, 4>(stream, L, nt, extra, cin); break;
+      case 2: r = (cin == 64 && !generic) ? launch_cl_variant<2, 2, 1, 4, 4>(stream, L, nt, extra, cin)
+                                          : launch_cl_variant<2, 2, 1, 4>(stream, L, nt, extra, cin); break;
       case 3: r = launch_cl_variant<1, 4, 1, 4>(stream, L, nt, extra, cin); break;
-      case 4: r = launch_cl_variant<4, 1, 2, 4>(stream, L, nt, extra, cin); break;
-      case 5: r = launch_cl_variant<2, 2, 2, 4>(stream, L, nt, extra, cin); break;
-      case 6: r = launch_cl_variant<2, 4, 2, 2>(stream, L, nt, extra, cin); break;
-      case 7: r = launch_cl_variant<1, 4, 2, 4>(stream, L, nt, extra, cin); break;
-      case 8: r = launch_cl_variant<4, 2, 2, 2>(stream, L, nt, extra, cin); break;
-      case 9: r = launch_cl_variant<1, 8, 2, 2>(stream, L, nt, extra, cin); break;
+      case 4: r = (cin == 256 && !generic) ? launch_cl_variant<4, 1, 2, 4, 16>(stream, L, nt, extra, cin)
+                                           : launch_cl_variant<4, 1, 2, 4>(stream, L, nt, extra, cin); break;
+      case 5: r = (cin == 128 && !generic) ? launch_cl_variant<2, 2, 2, 4, 8>(stream, L, nt, extra, cin)
+                                           : launch_cl_variant<2, 2, 2, 4>(stream, L, nt, extra, cin); break;
+      case 6: r = (cin == 128 && !generic) ? launch_cl_variant<2, 4, 2, 2, 8>(stream, L, nt, extra, cin)
+                                           : launch_cl_variant<2, 4, 2, 2>(stream, L, nt, extra, cin); break;
+      case 7: r = (cin == 64 && !generic) ? launch_cl_variant<1, 4, 2, 4, 4>(stream, L, nt, extra, cin)
+                                          : launch_cl_variant<1, 4, 2, 4>(stream, L, nt, extra, cin); break;
+      case 8: r = (cin == 256 && !generic) ? launch_cl_variant<4, 2, 2, 2, 16>(stream, L, nt, extra, cin)
+                                           : launch_cl_variant<4, 2, 2, 2>(stream, L, nt, extra, cin); break;
+      case 9: r = (cin == 64 && !generic) ? launch_cl_variant<1, 8, 2, 2, 4>(stream, L, nt, extra, cin)
+                                          : launch_cl_variant<1, 8, 2, 2>(stream, L, nt, extra, cin); break;
       default: return -1;
     }
     if (variant_name) *variant_name = names[v];
