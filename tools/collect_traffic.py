@@ -24,8 +24,8 @@ def family(kname):
     if "conv1d_splitk_kernel" in kname:
         return "conv1d_splitk<32x32>"
     if "conv_cl_bf16_kernel" in kname:
-        for k, v in {"<8, 1, 1, 4>": "conv_cl_bf16<8x1>", "<4, 1, 1, 4>": "conv_cl_bf16<4x1>", "<2, 2, 1, 4>": "conv_cl_bf16<2x2>",
-                     "<1, 4, 1, 4>": "conv_cl_bf16<1x4>"}.items():
+        for k, v in {"<8, 1, 1, 4,": "conv_cl_bf16<8x1>", "<4, 1, 1, 4,": "conv_cl_bf16<4x1>", "<2, 2, 1, 4,": "conv_cl_bf16<2x2>",
+                     "<1, 4, 1, 4,": "conv_cl_bf16<1x4>", "<1, 8, 2, 2,": "conv_cl_bf16<1x8,2x2>"}.items():
             if "conv_cl_bf16_kernel" + k in kname:
                 return v
     if "resblock_cl_bf16_kernel" in kname:
