@@ -40,7 +40,9 @@ def _digest() -> str:
     for rel in SOURCES + HEADERS:
         p = rel if os.path.isabs(rel) else os.path.join(CSRC, rel)
         with open(p, "rb") as f:
-            h.update(rel.encode())
+            # name relative to the repo root: the digest must not depend on where the tree is checked out (the GPU box
+            # runs a copy under another path and must not rebuild what travelled with it)
+            h.update(os.path.relpath(p, ROOT).encode())
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()

@@ -119,7 +119,15 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     # touch torch's memory (hipMemcpy -> invalid value).
     import torch  # noqa: F401
     if build_if_missing and _build.needs_build():
-        _build.build(verbose=False)
+        try:
+            _build.build(verbose=False)
+        except RuntimeError as e:
+            # no compiler on this box: a library that travelled with the tree is still usable (its ABI version and every
+            # symbol are checked below); without one there is nothing to fall back to
+            if "hipcc not found" not in str(e) or not os.path.exists(_build.LIB):
+                raise
+            import warnings
+            warnings.warn("libbv2.so could not be rebuilt (no hipcc here); loading the library that is in the tree")
     if not os.path.exists(_build.LIB):
         raise RuntimeError(f"{_build.LIB} is missing: the HIP extension must be built (python -m bert_vits2_amd.build); "
                            "there is no CPU fallback")
