@@ -142,8 +142,9 @@ double conv_cl_bytes(const ClLaunch& L);
 
 // a whole ResBlock1 (nd (dilated conv, conv) pairs with residuals) of a narrow Generator stage in one launch, bf16
 // channels-last, intermediates in LDS (kernels/resblock_cl_bf16.hip).  x / out: [B][L][C], C = 16 or 32, out != x.
-//   w    : ONE contiguous bf16 fragment stream [d][conv e][unit u < Upad][lane][8]  (unit = cl_w_index order of m-tile 0,
-//          Upad = resblock_cl_bf16_units(C, k) = (C/16)*k rounded up to RBCL_PD, padding units zero) + RBCL_PD tail units
+//   w    : ONE contiguous bf16 fragment stream [d][conv e][unit u < Upad][lane][8]  (units of m-tile 0 in TAP-MAJOR order
+//          u = tap*(C/16) + group, each unit laid out as in cl_w_index; Upad = resblock_cl_bf16_units(C, k) = (C/16)*k
+//          rounded up to RBCL_PD, padding units zero) + RBCL_PD tail units
 //   bias : fp32 [2*nd][32]  (row 2d+e = bias of conv e of pair d, zero padded to 32)
 #define BV2_RBCL_MAX_D 4
 constexpr int RBCL_PD = 8;        // weight ring depth = unit padding of the stream

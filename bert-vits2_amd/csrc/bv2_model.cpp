@@ -415,8 +415,15 @@ int pack_all(Model& m, Packer& P) {
           for (int d = 0; d < m.n_rbd; ++d)
             for (int e = 0; e < 2; ++e) {
               const ConvW& cw = m.rb[i][j][d][e];
-              std::memcpy(dst + (int64_t)(2 * d + e) * Upad * 512, reinterpret_cast<const uint16_t*>(P.blob + cw.wb_off),
-                          sizeof(uint16_t) * (size_t)U * 512);
+              // TAP-MAJOR unit order (tap j outer, 16-channel group s inner): the kernel's LDS walk then needs one pointer add
+              // per tap and immediate offsets for the groups; the per-conv stream is group-major (unit = s*k + j)
+              const uint16_t* src = reinterpret_cast<const uint16_t*>(P.blob + cw.wb_off);
+              const int G = ch / 16;
+              for (int j2 = 0; j2 < k; ++j2)
+                for (int s2 = 0; s2 < G; ++s2)
+                  std::memcpy(dst + ((int64_t)(2 * d + e) * Upad + (int64_t)j2 * G + s2) * 512, src + ((int64_t)s2 * k + j2) * 512,
+                              sizeof(uint16_t) * 512);
+              (void)U;
               std::memcpy(P.blob + m.rbcl_b_off[i][j] + (2 * d + e) * 32, P.blob + cw.b_off, sizeof(float) * (size_t)ch);
             }
         }

@@ -16,7 +16,7 @@
 // Rows outside [0, L) are forced to zero after every conv (they are the NEXT conv's zero padding, not conv outputs).
 // Rounding points are exactly those of the layer-wise bf16 path / oracle generator_bf16 (every tensor that was stored to
 // HBM there is rounded to bf16 here at the same place), so both paths agree up to fp32 summation order.
-// Weights: ONE contiguous bf16 fragment stream per (stage, branch) [d][conv][unit padded to 8][lane][8] (+8 tail units),
+// Weights: ONE contiguous bf16 fragment stream per (stage, branch) [d][conv][tap-major unit, padded to 8][lane][8] (+8 tail units),
 // streamed global -> registers through an 8-deep ring that is never drained between the 6 convs.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
@@ -52,29 +52,36 @@ struct Ring {
   }
 };
 
-// acc[ni] += sum_{u < U} W(u) x B(u, ni); the ring already holds this conv's first RBCL_PD units and is refilled from
-// the contiguous stream (which continues into the next conv's units) as it is consumed.  Upad = U rounded up to RBCL_PD.
-template <int NI>
-__device__ __forceinline__ void rb_gemm(f32x16 (&acc)[NI], Ring& ring, int U, int Upad, int k, const unsigned short* xb,
-                                        int pitch, int tstep) {
+// acc[ni] += sum_{u < U} W(u) x B(u, ni), units in TAP-MAJOR order u = j*G + s (tap j, 16-channel group s; the packer writes
+// the stream in this order): the group index of ring slot i is the compile-time i % G, a tap is one pointer add, every LDS
+// offset is an immediate.  The ring already holds this conv's first RBCL_PD units and is refilled from the contiguous stream
+// (which continues into the next conv's units) as it is consumed; Upad = U rounded up to RBCL_PD.  (The first form of this
+// loop recomputed (group, tap) and the LDS address per unit: 9.6 instructions per MFMA, which two waves per SIMD cannot
+// issue under 32-cycle MFMAs.)
+template <int NI, int G, int PITCH>
+__device__ __forceinline__ void rb_gemm(f32x16 (&acc)[NI], Ring& ring, int U, int Upad, const unsigned short* xb, int tstep) {
+  static_assert(RBCL_PD % G == 0, "ring slots map to fixed groups");
   bf16x8 bb[2][NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) bb[0][ni] = *reinterpret_cast<const bf16x8*>(xb + ni * 32 * pitch);
-  int s = 0, j = 0;
+  for (int ni = 0; ni < NI; ++ni) bb[0][ni] = *reinterpret_cast<const bf16x8*>(xb + ni * 32 * PITCH);
+  const unsigned short* xrow = xb;                // row of the current tap
+  const int tap_step = tstep * PITCH;
   for (int u0 = 0; u0 < Upad; u0 += RBCL_PD) {
+    const bool full = u0 + RBCL_PD <= U;          // wave-uniform: whole ring rounds run without per-unit guards
 #pragma unroll
     for (int i = 0; i < RBCL_PD; ++i) {
-      if (u0 + i < U) {
-        int jn = j + 1, sn = s;
-        if (jn == k) { jn = 0; ++sn; }
-        const bool more = u0 + i + 1 < U;
-        const unsigned short* xn = xb + (more ? jn : j) * tstep * pitch + (more ? sn : s) * 16;
+      constexpr int dummy = 0; (void)dummy;
+      const int s = i % G;
+      const bool last_of_tap = s == G - 1;
+      if (full || u0 + i < U) {
+        // next unit: next group of this tap, or group 0 of the next tap (one tap past the end reads guard rows: unused)
+        const unsigned short* xn = last_of_tap ? xrow + tap_step : xrow + (s + 1) * 16;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bb[(i & 1) ^ 1][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * pitch);
+        for (int ni = 0; ni < NI; ++ni) bb[(i & 1) ^ 1][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * PITCH);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.ar[i], bb[i & 1][ni], acc[ni], 0, 0, 0);
-        j = jn; s = sn;
+        if (last_of_tap) xrow += tap_step;
       }
       ring.load(i);
       __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);   // next unit's LDS reads first, then the MFMAs, then the ring load
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-    rb_gemm<NI>(acc, ring, U, Upad, k, XA + (RB_G + row0 - half * dil) * PITCH + lh * 8, PITCH, dil);
+    rb_gemm<NI, C / 16, PITCH>(acc, ring, U, Upad, XA + (RB_G + row0 - half * dil) * PITCH + lh * 8, dil);
     {
       const float* bias = P.bias + (2 * d) * 32;
 #pragma unroll
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-    rb_gemm<NI>(acc, ring, U, Upad, k, TA + (RB_G + row0 - half) * PITCH + lh * 8, PITCH, 1);
+    rb_gemm<NI, C / 16, PITCH>(acc, ring, U, Upad, TA + (RB_G + row0 - half) * PITCH + lh * 8, 1);
     {
       const float* bias = P.bias + (2 * d + 1) * 32;
       const bool last = d + 1 == nd;
