@@ -16,6 +16,7 @@ MAX_RBK = 4
 MAX_RBD = 4
 
 F32, F16, BF16 = 0, 1, 2
+ABI_VERSION = 2      # include/bv2.h BV2_ABI_VERSION
 
 
 class Config(C.Structure):
@@ -136,7 +137,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)         # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.bv2_abi_version() != 1:
+    if lib.bv2_abi_version() != ABI_VERSION:
         raise RuntimeError("libbv2.so ABI version mismatch")
     _lib = lib
     return lib

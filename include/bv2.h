@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BV2_ABI_VERSION 1
+#define BV2_ABI_VERSION 2   /* 2: bv2_decode_in.exact_lengths, fp16 / tap-major weight streams in the blob */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
 #define BV2_MAX_RESBLOCK_DILATIONS 4
