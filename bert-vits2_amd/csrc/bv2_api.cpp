@@ -554,17 +554,47 @@ int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i,
       w = &m.rb[i][j][d][e];
       pad_left = ((w->k - 1) / 2) * (e == 0 ? m.cfg.resblock_dilation_sizes[j][d] : 1);
     }
-    if (!w || w->wb_off < 0) return -2;
+    // kind 3: fp16 stream of a transformer-flow Encoder conv — coupling i (application order), layer j, d = 0 qkv / 1 o /
+    //         2 ffn conv_1 / 3 ffn conv_2.   kind 4: resblock conv rb[i][j][d][e] read back from the TAP-MAJOR whole-ResBlock
+    //         stream (must equal kind 2).
+    bool half = false, tapmajor = false;
+    if (kind == 3 && i >= 0 && i < m.n_coupling && m.cfg.use_transformer_flow && j >= 0 && j < m.coupling[i].enc.n_layers &&
+        d >= 0 && d < 4) {
+      const EncLayerW& L = m.coupling[i].enc.layer[j];
+      w = d == 0 ? &L.qkv : (d == 1 ? &L.o : (d == 2 ? &L.ffn1 : &L.ffn2));
+      pad_left = (w->k - 1) / 2;
+      half = true;
+      if (w->wh_off < 0) return -2;
+    } else if (kind == 4 && i >= 0 && i < m.n_ups && j >= 0 && j < m.n_rbk && d >= 0 && d < m.n_rbd && (e == 0 || e == 1)) {
+      w = &m.rb[i][j][d][e];
+      pad_left = ((w->k - 1) / 2) * (e == 0 ? m.cfg.resblock_dilation_sizes[j][d] : 1);
+      tapmajor = true;
+      if (m.rbcl_w_off[i][j] < 0) return -2;
+    }
+    if (!w || (!half && w->wb_off < 0)) return -2;
     dims[0] = w->cin; dims[1] = w->cout; dims[2] = w->k; dims[3] = pad_left;
     const float* blob = static_cast<const float*>(host_blob);
-    const uint16_t* wb = reinterpret_cast<const uint16_t*>(blob + w->wb_off);
+    const uint16_t* wb = reinterpret_cast<const uint16_t*>(blob + (half ? w->wh_off : w->wb_off));
+    if (tapmajor) wb = reinterpret_cast<const uint16_t*>(blob + m.rbcl_w_off[i][j]) +
+                       (int64_t)(2 * d + e) * resblock_cl_bf16_units(w->cin, w->k) * 512;
     if (w_out)
       for (int co = 0; co < w->cout; ++co)
         for (int ci = 0; ci < w->cin; ++ci)
           for (int jj = 0; jj < w->k; ++jj) {
-            const uint32_t u = (uint32_t)wb[cl_w_index(jj, ci, co, w->cin, w->k)] << 16;
+            int64_t idx = cl_w_index(jj, ci, co, w->cin, w->k);
+            if (tapmajor) {                           // unit (group s, tap jj) sits at jj*G + s instead of s*k + jj
+              const int G = w->cin / 16, sg = ci / 16;
+              idx = ((int64_t)jj * G + sg) * 512 + idx % 512;
+            }
             float f;
-            std::memcpy(&f, &u, 4);
+            if (half) {
+              _Float16 hv;
+              std::memcpy(&hv, &wb[idx], 2);
+              f = (float)hv;
+            } else {
+              const uint32_t u = (uint32_t)wb[idx] << 16;
+              std::memcpy(&f, &u, 4);
+            }
             w_out[((size_t)co * w->cin + ci) * w->k + jj] = f;
           }
     if (bias_out)

@@ -48,7 +48,9 @@ int bv2_test_conv_f16(void* stream, const void* x, int in_ct, const float* in_ma
 
 /* Decode one Generator conv of a packed HOST blob back to dense form (checks the bf16 packer on a CPU-only box):
  * kind 0 = dec.conv_pre, 1 = dec.ups[i] in its channels-last single-conv form (C_out' = u*C_out), 2 = resblock conv
- * rb[i][j][d][e].  dims = {cin, cout, k, pad_left}; w_out [cout][cin][k] (bf16 values widened to fp32) and bias_out [cout]
+ * rb[i][j][d][e], 3 = fp16 stream of a transformer-flow Encoder conv (coupling i in application order, layer j, d = 0 fused
+ * q/k/v(+relative-key rows) / 1 conv_o / 2 FFN conv_1 / 3 FFN conv_2), 4 = rb[i][j][d][e] read back from the tap-major
+ * whole-ResBlock stream (must equal kind 2).  dims = {cin, cout, k, pad_left}; w_out [cout][cin][k] (bf16 values widened to fp32) and bias_out [cout]
  * may be NULL to query dims only.  Returns 0, or a negative status. */
 int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i, int j, int d, int e, int32_t* dims,
                           float* w_out, float* bias_out);

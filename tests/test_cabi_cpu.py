@@ -192,3 +192,50 @@ def test_bf16_oracle_generator_close_to_fp32():
         b = O.generator_bf16(sd, hp, z, gg)
     rel = ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
     assert 1e-5 < rel < 5e-2, rel
+
+
+def test_fp16_flow_streams_and_tap_major_resblock_streams():
+    """The fp16 weight streams of the transformer flow's Encoder convs decode to fp16(reference weight) — for the fused q/k/v
+    projection: q rows pre-scaled by 1/sqrt(d), k, v rows as is, then per head the 2W+1 relative-key rows E_k·W_q/sqrt(d)
+    (attentions.py:264-266, 280, 286-288) — and the tap-major whole-ResBlock streams hold the same bf16 weights as the
+    per-conv streams."""
+    import math
+    hp = H.default_v23()
+    sd = cached_state_dict(hp, 0)
+    m = models.from_hparams(hp)
+    m.load_state_dict(sd, strict=False)
+    blob = m.pack_host_blob()
+    lib = L.load()
+    lib.bv2_test_dump_cl_conv.restype = C.c_int
+    h = m._handle
+    h16 = lambda t: t.to(torch.float16).to(torch.float32)
+    nf = hp.n_flow_layer
+    for a in (0, nf - 1):                                   # application order a <-> reference flows.{2*(nf-1-a)}
+        p = f"flow.flows.{2 * (nf - 1 - a)}.enc"
+        for lyr in (0, hp.n_layers_trans_flow - 1):
+            w, b, _ = _dump_cl(lib, h, blob, 3, a, lyr, 1)
+            assert torch.equal(w, h16(sd[f"{p}.attn_layers.{lyr}.conv_o.weight"])) and torch.equal(b, sd[f"{p}.attn_layers.{lyr}.conv_o.bias"])
+            w, b, pl = _dump_cl(lib, h, blob, 3, a, lyr, 2)
+            assert pl == 2 and torch.equal(w, h16(sd[f"{p}.ffn_layers.{lyr}.conv_1.weight"]))
+            w, b, _ = _dump_cl(lib, h, blob, 3, a, lyr, 3)
+            assert torch.equal(w, h16(sd[f"{p}.ffn_layers.{lyr}.conv_2.weight"])) and torch.equal(b, sd[f"{p}.ffn_layers.{lyr}.conv_2.bias"])
+            w, b, _ = _dump_cl(lib, h, blob, 3, a, lyr, 0)
+            Hc, dk, nr = hp.hidden_channels, hp.hidden_channels // hp.n_heads, 9
+            assert w.shape == (3 * Hc + hp.n_heads * nr, Hc, 1)
+            wq = sd[f"{p}.attn_layers.{lyr}.conv_q.weight"][:, :, 0].double()
+            isq = 1.0 / math.sqrt(dk)
+            assert torch.equal(w[:Hc, :, 0], h16((wq * isq).float()))
+            assert torch.equal(w[Hc:2 * Hc], h16(sd[f"{p}.attn_layers.{lyr}.conv_k.weight"]))
+            assert torch.equal(w[2 * Hc:3 * Hc], h16(sd[f"{p}.attn_layers.{lyr}.conv_v.weight"]))
+            ek = sd[f"{p}.attn_layers.{lyr}.emb_rel_k"][0].double()
+            rel = torch.cat([ek @ wq[hh * dk:(hh + 1) * dk] for hh in range(hp.n_heads)]) * isq
+            assert (w[3 * Hc:, :, 0].double() - rel).abs().max() <= 2.0 ** -10 * rel.abs().max()   # one fp16 rounding
+    for i in (3, 4):                                        # the narrow stages carry a whole-ResBlock stream
+        for j in range(len(hp.resblock_kernel_sizes)):
+            for d in range(3):
+                for e in (0, 1):
+                    w2, b2, pl2 = _dump_cl(lib, h, blob, 2, i, j, d, e)
+                    w4, b4, pl4 = _dump_cl(lib, h, blob, 4, i, j, d, e)
+                    assert pl2 == pl4 and torch.equal(w2, w4) and torch.equal(b2, b4)
+    dims = (C.c_int32 * 4)()
+    assert lib.bv2_test_dump_cl_conv(h, C.c_void_p(blob.data_ptr()), 4, 0, 0, 0, 0, dims, None, None) == -2   # wide stage: none
