@@ -432,6 +432,10 @@ class SynthesizerTrn(nn.Module):
         self._check(self._lib.bv2_profile_enable(self._handle, int(on)), "bv2_profile_enable")
         self._lib.bv2_profile_reset(self._handle)
 
+    def profile_pause(self):
+        """Stop recording events but keep what was recorded (the pool holds 8192 launches)."""
+        self._check(self._lib.bv2_profile_enable(self._handle, 0), "bv2_profile_enable")
+
     def profile_report(self):
         rows = (L.ProfileRow * 256)()
         n = self._lib.bv2_profile_report(self._handle, rows, 256)
