@@ -75,10 +75,18 @@ def adapt_state_dict(saved: Dict[str, torch.Tensor], want: Dict[str, torch.Tenso
     return new, missing
 
 
-def load_checkpoint(checkpoint_path, model, optimizer=None, skip_optimizer=False):
-    """reference utils.py:65-120: returns ``(model, optimizer, learning_rate, iteration)``."""
+def load_checkpoint(checkpoint_path, model, optimizer=None, skip_optimizer=False, *, trust_pickle: bool = False):
+    """reference utils.py:65-120: returns ``(model, optimizer, learning_rate, iteration)``.
+
+    Checkpoints of this model family hold tensors, dicts and scalars only (utils.py:123-139), so the file is read with
+    ``weights_only=True`` — a third-party ``.pth`` cannot run code at load time.  ``trust_pickle=True`` (or the environment
+    variable ``BV2_TRUST_PICKLE=1``) opts in to the unrestricted unpickler for legacy files that embed other objects."""
     assert os.path.isfile(checkpoint_path)
-    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    if trust_pickle or os.environ.get("BV2_TRUST_PICKLE") == "1":
+        logger.warning("loading %s with the unrestricted unpickler (trust_pickle): only do this for files you trust", checkpoint_path)
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    else:
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     iteration = ckpt.get("iteration", 0)
     learning_rate = ckpt.get("learning_rate", 0.0)
     if optimizer is not None and not skip_optimizer and ckpt.get("optimizer") is not None:

@@ -1,4 +1,5 @@
 // bv2_api.cpp — the extern "C" surface declared in include/bv2.h.
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -123,9 +124,19 @@ int bv2_attach_weights(bv2_handle* h, const void* dev_blob, int64_t bytes) {
     h->err = "bv2_attach_weights: blob header does not match this handle's config (not packed, or packed for another model)";
     return -7;
   }
+  if (hdr[3] != BV2_PACK_LAYOUT) {
+    h->err = "bv2_attach_weights: blob was packed with another pack layout (a cache written by an older library build): repack";
+    return -7;
+  }
   h->blob = static_cast<const float*>(dev_blob);
   return 0;
   BV2_CATCH(h)
+}
+
+int bv2_detach_weights(bv2_handle* h) {
+  if (!h) return -1;
+  h->blob = nullptr;
+  return 0;
 }
 
 int bv2_set_generator_dtype(bv2_handle* h, int dtype) {
@@ -202,12 +213,54 @@ int bv2_decode(bv2_handle* h, bv2_stream stream, const bv2_decode_in* in, const 
   BV2_CATCH(h)
 }
 
-int bv2_stage_flow(bv2_handle* h, bv2_stream stream, int B, int Ty, const float* z_p, const int64_t* y_lengths,
-                   const float* g, float* z, void* ws, int64_t wsb) {
+int bv2_stage_emb_g(bv2_handle* h, bv2_stream stream, int B, const int64_t* sid, float* g) {
+  if (!h) return -1;
+  if (!h->blob) { h->err = "no weights attached (call bv2_pack_weights + bv2_attach_weights first)"; return -8; }
+  BV2_TRY
+  if (B < 1 || !sid || !g) { h->err = "bv2_stage_emb_g: bad argument"; return -1; }
+  return run_stage_emb_g(h, static_cast<hipStream_t>(stream), B, sid, g);
+  BV2_CATCH(h)
+}
+
+int bv2_stage_enc_p(bv2_handle* h, bv2_stream stream, int B, int T, const int64_t* x, const int64_t* t, const int64_t* language,
+                    const float* bert_0, const float* bert_1, const float* bert_2, const float* g, const int64_t* x_lengths,
+                    float* xout, float* m_p, float* logs_p, float* x_mask, void* ws, int64_t wsb) {
   if (int rc = ready(h, ws)) return rc;
   BV2_TRY
-  if (B < 1 || Ty < 1 || !z_p || !y_lengths || !g || !z) { h->err = "bv2_stage_flow: bad argument"; return -1; }
-  return run_flow(h, static_cast<hipStream_t>(stream), B, Ty, z_p, y_lengths, g, z, ws, wsb);
+  if (B < 1 || T < 1 || !x || !t || !language || !bert_0 || !bert_1 || !bert_2 || !g || !xout || !m_p || !logs_p || !x_mask) {
+    h->err = "bv2_stage_enc_p: bad argument"; return -1;
+  }
+  return run_stage_enc_p(h, static_cast<hipStream_t>(stream), B, T, x, t, language, bert_0, bert_1, bert_2, g, x_lengths, xout,
+                         m_p, logs_p, x_mask, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_stage_sdp(bv2_handle* h, bv2_stream stream, int B, int T, const float* x, const float* x_mask, const float* zin,
+                  const float* g, float* logw, void* ws, int64_t wsb) {
+  if (int rc = ready(h, ws)) return rc;
+  BV2_TRY
+  if (B < 1 || T < 1 || !x || !x_mask || !zin || !g || !logw) { h->err = "bv2_stage_sdp: bad argument"; return -1; }
+  return run_stage_sdp(h, static_cast<hipStream_t>(stream), B, T, x, x_mask, zin, g, logw, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_stage_dp(bv2_handle* h, bv2_stream stream, int B, int T, const float* x, const float* x_mask, const float* g,
+                 float* logw, void* ws, int64_t wsb) {
+  if (int rc = ready(h, ws)) return rc;
+  BV2_TRY
+  if (B < 1 || T < 1 || !x || !x_mask || !g || !logw) { h->err = "bv2_stage_dp: bad argument"; return -1; }
+  return run_stage_dp(h, static_cast<hipStream_t>(stream), B, T, x, x_mask, g, logw, ws, wsb);
+  BV2_CATCH(h)
+}
+
+int bv2_stage_flow(bv2_handle* h, bv2_stream stream, int B, int Ty, const float* z_p, const int64_t* y_lengths,
+                   const float* y_mask, const float* g, float* z, void* ws, int64_t wsb) {
+  if (int rc = ready(h, ws)) return rc;
+  BV2_TRY
+  if (B < 1 || Ty < 1 || !z_p || !g || !z || ((y_lengths != nullptr) == (y_mask != nullptr))) {
+    h->err = "bv2_stage_flow: bad argument (exactly one of y_lengths / y_mask)"; return -1;
+  }
+  return run_flow(h, static_cast<hipStream_t>(stream), B, Ty, z_p, y_lengths, y_mask, g, z, ws, wsb);
   BV2_CATCH(h)
 }
 
@@ -215,13 +268,13 @@ int bv2_stage_generator(bv2_handle* h, bv2_stream stream, int B, int Ty, int L, 
                         const float* g, float* o, void* ws, int64_t wsb) {
   if (int rc = ready(h, ws)) return rc;
   BV2_TRY
-  if (B < 1 || Ty < 1 || !z || !y_lengths || !g || !o) { h->err = "bv2_stage_generator: bad argument"; return -1; }
+  if (B < 1 || Ty < 1 || !z || !g || !o) { h->err = "bv2_stage_generator: bad argument"; return -1; }
   return run_generator(h, static_cast<hipStream_t>(stream), B, Ty, L, z, y_lengths, g, o, ws, wsb);
   BV2_CATCH(h)
 }
 
 int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* enc_out,
-              const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, float noise_scale, int32_t max_len,
+              const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, int64_t nz_tstride, float noise_scale, int32_t max_len,
               int32_t Ty_cap, const bv2_decode_out* dec_out, int32_t* Ty_out, void* ws, int64_t wsb) {
   if (int rc = bv2_encode_durations(h, stream, in, enc_out, ws, wsb)) return rc;
   BV2_TRY
@@ -239,7 +292,7 @@ int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const b
   d.B = in->B; d.T = in->T; d.Ty = (int32_t)Ty; d.max_len = max_len;
   d.m_p = enc_out->m_p; d.logs_p = enc_out->logs_p; d.x_mask = enc_out->x_mask; d.w_ceil = enc_out->w_ceil;
   d.y_lengths = enc_out->y_lengths; d.g = enc_out->g;
-  d.noise_z = noise_z; d.nz_bstride = nz_bstride; d.nz_cstride = nz_cstride; d.noise_scale = noise_scale;
+  d.noise_z = noise_z; d.nz_bstride = nz_bstride; d.nz_cstride = nz_cstride; d.nz_tstride = nz_tstride; d.noise_scale = noise_scale;
   return bv2_decode(h, stream, &d, dec_out, ws, wsb);
   BV2_CATCH(h)
 }
@@ -318,6 +371,17 @@ void bv2_graph_destroy(bv2_graph* g) {
   if (!g) return;
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   delete g;
+}
+
+int bv2_set_option(bv2_handle* h, const char* key, int value) {
+  if (!h) return -1;
+  BV2_TRY
+  const std::string k = key ? key : "";
+  if (k == "fused_resblock") h->no_fused_resblock = value == 0;
+  else if (k == "fused_dds") h->no_fused_dds = value == 0;
+  else { h->err = "bv2_set_option: unknown key '" + k + "'"; return -1; }
+  return 0;
+  BV2_CATCH(h)
 }
 
 int bv2_set_tap(bv2_handle* h, const char* name, float* dev_dst, int64_t cap) {
@@ -626,6 +690,54 @@ int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode,
   l.gamma = gamma; l.beta = beta; l.eps = 1e-5f; l.post_gelu = post_gelu; l.res = res; l.vec = vec; l.vec_bstride = C;
   l.mask = mask; l.out = out; l.B = B; l.C = C; l.T = T;
   return launch_layernorm(static_cast<hipStream_t>(stream), l);
+}
+
+void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target) { conv_set_tuning(splitk_waves, force_ck, tile_target); }
+
+int64_t bv2_test_dds_pack_floats(int C) {
+  // [dww 3C][dwb C][g1 C][b1 C][g2 C][b2 C][pre_w C][pre_b C] + conv pack (1x1 C->C) + post conv pack (1x1 C->C rows max)
+  return 10 * (int64_t)C + 2 * bv2_test_conv_pack_floats(C, C, 1);
+}
+
+int bv2_test_dds_layer(void* stream, const float* x, const float* pre_w_host, const float* pre_b_host, const float* z, int z_src,
+                       const float* g, const float* mask, const float* dww_host, const float* dwb_host, const float* g1_host,
+                       const float* b1_host, const float* g2_host, const float* b2_host, const float* w_host,
+                       const float* bias_host, float* out, int dil, int last_mask, const float* post_w_host,
+                       const float* post_b_host, int post_cout, float* post_out, float* zio, int z_dst, float* wpack_dev,
+                       int B, int C, int T) {
+  try {
+    const int64_t one = bv2_test_conv_pack_floats(C, C, 1);
+    std::vector<float> pk((size_t)bv2_test_dds_pack_floats(C), 0.f);
+    size_t o = 0;
+    auto put = [&](const float* src, size_t n) { size_t at = o; if (src) std::memcpy(&pk[o], src, n * sizeof(float)); o += n; return at; };
+    const size_t o_dww = put(dww_host, 3 * (size_t)C), o_dwb = put(dwb_host, C), o_g1 = put(g1_host, C), o_b1 = put(b1_host, C),
+                 o_g2 = put(g2_host, C), o_b2 = put(b2_host, C), o_pw = put(pre_w_host, C), o_pb = put(pre_b_host, C);
+    const int cin_pad = t_round_up(C, 16), ld = t_round_up(C, 128);
+    const size_t o_w = o, boff = (size_t)cin_pad * ld;
+    for (int ci = 0; ci < C; ++ci)
+      for (int co = 0; co < C; ++co) pk[o_w + (size_t)conv_w_index(0, ci, co, cin_pad, 1)] = w_host[(size_t)co * C + ci];
+    for (int co = 0; co < C; ++co) pk[o_w + boff + co] = bias_host[co];
+    const size_t o_p = o_w + (size_t)one;
+    if (post_w_host) {
+      for (int ci = 0; ci < C; ++ci)
+        for (int co = 0; co < post_cout; ++co) pk[o_p + (size_t)conv_w_index(0, ci, co, cin_pad, 1)] = post_w_host[(size_t)co * C + ci];
+      if (post_b_host) for (int co = 0; co < post_cout; ++co) pk[o_p + boff + co] = post_b_host[co];
+    }
+    if (hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
+    DdsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = x;
+    if (pre_w_host) { a.pre_w = wpack_dev + o_pw; a.pre_b = wpack_dev + o_pb; a.z = z; a.z_src = z_src; a.g = g; a.x = nullptr; }
+    a.mask = mask; a.dww = wpack_dev + o_dww; a.dwb = wpack_dev + o_dwb; a.g1 = wpack_dev + o_g1; a.b1 = wpack_dev + o_b1;
+    a.g2 = wpack_dev + o_g2; a.b2 = wpack_dev + o_b2; a.w = wpack_dev + o_w; a.bias = wpack_dev + o_w + boff;
+    a.out = out; a.dil = dil; a.last_mask = last_mask; a.eps = 1e-5f;
+    if (post_w_host) {
+      a.post_w = wpack_dev + o_p; a.post_b = wpack_dev + o_p + boff; a.post_cout = post_cout; a.post_cout_pad = t_round_up(post_cout, 32);
+      a.post_out = post_out; a.zio = zio; a.z_src = z_src; a.z_dst = z_dst; a.sqrt_fc = std::sqrt((float)C); a.tail = 5.0f;
+    }
+    a.B = B; a.C = C; a.T = T;
+    return launch_dds_layer(static_cast<hipStream_t>(stream), a);
+  } catch (...) { return -100; }
 }
 
 int bv2_test_spline(void* stream, float* z, int src, int dst, const float* params, int prow, const float* mask,

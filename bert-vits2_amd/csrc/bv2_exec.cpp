@@ -155,7 +155,8 @@ inline int attn_ld(int T) { return (T + 31) / 32 * 32; }
 inline int qkv_rows(const EncoderW& e) { return 3 * e.hidden + e.heads * (2 * kAttnWindow + 1); }
 
 void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask, const float* spk, int spk_bstride,
-                 int B, int T, const char* tapname, bool f16 = false) {
+                 int B, int T, const char* tapname, bool f16 = false, float* out2 = nullptr, const float* vec2 = nullptr,
+                 int vec2_bstride = 0) {
   const int H = e.hidden, ld = attn_ld(T), R = qkv_rows(e);
   // cond_layer_idx == 2 > 0: the speaker add always rides on the previous layer's LN2 epilogue
   for (int i = 0; i < e.n_layers; ++i) {
@@ -212,7 +213,10 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     }
     l.a = b.s; l.nslab = ns; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off);
     if (i + 1 == kCondLayer && i + 1 < e.n_layers) { l.vec = spk; l.vec_bstride = spk_bstride; l.mask = mask; }
-    if (i + 1 == e.n_layers) l.mask = mask;
+    if (i + 1 == e.n_layers) {
+      l.mask = mask;
+      if (out2) { l.out2 = out2; l.vec2 = vec2; l.vec2_bstride = vec2_bstride; }   // (x + vec2) * mask beside x * mask
+    }
     c.ln(l, "enc.ln2");
     if (tapname) {
       const std::string tn = std::string(tapname) + ".layer." + std::to_string(i);
@@ -221,7 +225,46 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
   }
 }
 
-// modules.DDSConv.forward (reference modules.py:118-130), 3 launches per layer:
+// modules.DDSConv.forward (reference modules.py:118-130).  Fused form (kernels/dds_fused.hip): ONE launch per layer, the
+// layers ping-pong between `ha` and `hb` (a tile reads its neighbours' input columns, so a layer never updates in place), the
+// first layer can take ConvFlow.pre as its input transform and the last one applies the projection that follows the DDSConv.
+struct DdsPost {                      // what follows the DDSConv
+  const ConvW* proj = nullptr;        // sdp.proj (post_out) or ConvFlow.proj (+ spline on z)
+  float* post_out = nullptr;
+  float* zio = nullptr; int z_src = 0, z_dst = 0;
+};
+struct DdsPre { const float* w = nullptr; const float* b = nullptr; const float* z = nullptr; int z_src = 0; const float* g = nullptr; };
+
+void run_dds_fused(Ctx& c, const DDSW& d, const float* x_in, const DdsPre& pre, float* ha, float* hb, const float* mask,
+                   const DdsPost& post, int B, int C, int T, float sqrt_fc) {
+  const float* cur = x_in;
+  for (int i = 0; i < kSdpLayers; ++i) {
+    const DDSLayerW& L = d.l[i];
+    const bool last = i + 1 == kSdpLayers;
+    DdsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    if (i == 0 && pre.w) { a.pre_w = pre.w; a.pre_b = pre.b; a.z = pre.z; a.z_src = pre.z_src; a.g = pre.g; }
+    else a.x = cur;
+    a.mask = mask;
+    a.dww = c.W(L.dww.off); a.dwb = c.W(L.dwb.off); a.g1 = c.W(L.g1.off); a.b1 = c.W(L.b1.off);
+    a.g2 = c.W(L.g2.off); a.b2 = c.W(L.b2.off);
+    a.w = c.W(L.c1x1.w_off); a.bias = c.W(L.c1x1.b_off);
+    float* out = (cur == ha) ? hb : ha;
+    a.out = out; a.dil = L.dil; a.last_mask = last ? 1 : 0; a.eps = 1e-5f;
+    a.B = B; a.C = C; a.T = T;
+    if (last && post.proj) {
+      a.post_w = c.W(post.proj->w_off); a.post_b = c.W(post.proj->b_off);
+      a.post_cout = post.proj->cout; a.post_cout_pad = post.proj->cout_pad;
+      a.post_out = post.post_out; a.zio = post.zio; a.z_src = post.z_src; a.z_dst = post.z_dst;
+      a.sqrt_fc = sqrt_fc; a.tail = 5.0f;
+      a.out = nullptr;                                         // only the projection's result is consumed
+    }
+    if (!c.rc) { if (int r = launch_dds_layer(c.s, a)) c.fail("dds.layer", r); }
+    cur = out;
+  }
+}
+
+// Unfused form (3 launches per layer), for channel counts the fused kernel does not cover:
 //   y1 = gelu(LN1(dwconv_k3,dil(x*mask)))   y2 = W_1x1 y1 (MFMA)   x = x + gelu(LN2(y2))   [*mask after the last]
 void run_dds(Ctx& c, const DDSW& d, float* x, float* y1, float* y2, int64_t slab, const float* mask, int B, int C, int T) {
   for (int i = 0; i < kSdpLayers; ++i) {
@@ -337,37 +380,34 @@ int64_t workspace_bytes(const Model& m, int B, int T, int Ty) {
 }
 
 // ===============================================================================================================
-// phase A: emb_g, enc_p, sdp, dp, durations
-int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_encode_out& out, void* ws, int64_t wsb) {
-  const Model& m = h->model;
-  const bv2_config& cf = m.cfg;
-  const int B = in.B, T = in.T, H = cf.hidden_channels, C = cf.inter_channels;
-  Arena A(ws, wsb);
-  PlanA P = plan_a(A, m, B, T);
-  if (!A.ok()) { h->err = "workspace too small for bv2_encode_durations"; return -5; }
-  P.enc.x = out.x;
-  Ctx c{h, s, m, h->blob};
-  const float* mask = out.x_mask;
+// phase A pieces (each is also one of the reference's ONNX stages, include/bv2.h "single stages")
 
-  // g = emb_g(sid); x_mask; every g-conditioned vector of this phase in ONE GEMV launch
-  c.chk(launch_gather_rows(s, c.W(m.emb_g.off), in.sid, out.g, B, cf.gin_channels, cf.n_speakers), "emb_g");
-  c.chk(launch_seq_mask(s, in.x_lengths, out.x_mask, B, T), "x_mask");
-  float *spk = P.gv, *sdp_c = P.gv + H, *dp_c = P.gv + 2 * H;
-  {
-    GemvLaunch G;
-    std::memset(&G, 0, sizeof(G));
-    const GemvW* gw[3] = {&m.enc.spk, &m.sdp_cond, &m.dp_cond};
-    float* go[3] = {spk, sdp_c, dp_c};
-    for (int i = 0; i < 3; ++i) {
-      G.p[i].w = c.W(gw[i]->w_off); G.p[i].bias = c.W(gw[i]->b_off); G.p[i].out = go[i];
-      G.p[i].cout = gw[i]->cout; G.p[i].cin = gw[i]->cin; G.p[i].out_bstride = 3 * H;
-    }
-    G.nprob = 3; G.B = B; G.g = out.g; G.g_bstride = cf.gin_channels;
-    c.chk(launch_gemv(s, G), "gemv.A");
+// the front launch: emb_g lookup (or a given g), the speaker-conditioning GEMVs, x_mask and the scaled SDP noise
+static void run_front(Ctx& c, const int64_t* sid, const float* g_in, float* g_out, const GemvW* const* gw, float* const* go,
+                      int n, int out_stride, const int64_t* x_lengths, float* x_mask, int B, int T, const float* noise,
+                      float* z, float noise_scale) {
+  const bv2_config& cf = c.m.cfg;
+  FrontArgs F;
+  std::memset(&F, 0, sizeof(F));
+  for (int i = 0; i < n; ++i) {
+    F.p[i].w = c.W(gw[i]->w_off); F.p[i].bias = c.W(gw[i]->b_off); F.p[i].out = go[i];
+    F.p[i].cout = gw[i]->cout; F.p[i].cin = gw[i]->cin; F.p[i].out_bstride = out_stride;
   }
+  F.nprob = n; F.B = B; F.g = g_in; F.g_bstride = cf.gin_channels; F.gin = cf.gin_channels;
+  if (sid) { F.table = c.W(c.m.emb_g.off); F.sid = sid; F.nrows = cf.n_speakers; F.g_out = g_out; }
+  F.lengths = x_lengths; F.mask = x_mask; F.T = T;
+  F.noise = noise; F.z = z; F.noise_scale = noise_scale; F.nz = z ? (int64_t)B * 2 * T : 0;
+  c.chk(launch_front(c.s, F), "front");
+}
 
-  // ---- TextEncoder (reference models.py:377-400)
-  const float* berts[3] = {in.bert, in.ja_bert, in.en_bert};
+// TextEncoder (reference models.py:377-400).  dp0/dp_c: the DurationPredictor's `x + cond(g)` input rides on the last LayerNorm.
+static void enc_p_core(Ctx& c, PlanA& P, const int64_t* x, const int64_t* tone, const int64_t* lang, const float* const* berts,
+                       const float* mask, const float* spk, int spk_stride, int B, int T, float* out_x, float* out_m,
+                       float* out_logs, float* dp0, const float* dp_c) {
+  const Model& m = c.m;
+  const bv2_config& cf = m.cfg;
+  const int H = cf.hidden_channels;
+  P.enc.x = out_x;
   int bert_slabs;
   {
     // the three 1024 -> hidden projections in ONE launch; each writes its own partial slab(s), the embed kernel sums them
@@ -383,83 +423,187 @@ int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_
   }
   {
     EmbedArgs e;
-    e.x = in.x; e.tone = in.tone; e.lang = in.language;
+    e.x = x; e.tone = tone; e.lang = lang;
     e.emb = c.W(m.emb.off); e.tone_emb = c.W(m.tone_emb.off); e.lang_emb = c.W(m.lang_emb.off);
     e.n_vocab = cf.n_vocab; e.n_tones = cf.n_tones; e.n_langs = cf.n_languages;
     e.bsum = P.bsum; e.nslab = bert_slabs; e.slab_stride = P.slab;
-    e.mask = mask; e.out = out.x; e.scale = (float)std::sqrt((double)H); e.B = B; e.C = H; e.T = T;
-    c.chk(launch_embed(s, e), "embed");
+    e.mask = mask; e.out = out_x; e.scale = (float)std::sqrt((double)H); e.B = B; e.C = H; e.T = T;
+    c.chk(launch_embed(c.s, e), "embed");
   }
-  c.tap("enc.x0", out.x, (int64_t)B * H * T);
-  run_encoder(c, m.enc, P.enc, mask, spk, 3 * H, B, T, "enc");
+  c.tap("enc.x0", out_x, (int64_t)B * H * T);
+  run_encoder(c, m.enc, P.enc, mask, spk, spk_stride, B, T, "enc", false, dp0, dp_c, spk_stride);
   {
     ConvLaunch cl;
     cl.nprob = 2; cl.B = B; cl.L = T;
-    cl.p[0] = c.prob(m.proj_m, out.x, out.m_p, T);
-    cl.p[1] = c.prob(m.proj_logs, out.x, out.logs_p, T);
+    cl.p[0] = c.prob(m.proj_m, out_x, out_m, T);
+    cl.p[1] = c.prob(m.proj_logs, out_x, out_logs, T);
     for (int i = 0; i < 2; ++i) { cl.p[i].out_mask = mask; cl.p[i].mask_post = 1; }
     c.conv(cl, "enc_p.proj");
   }
+}
 
-  // ---- DurationPredictor (reference models.py:285-299)
-  c.chk(launch_add_vec_mask(s, out.x, dp_c, 3 * H, nullptr, P.dp0, B, H, T), "dp.cond");
-  {
-    ConvProb p = c.prob(m.dp_c1, P.dp0, P.dp1, T);
-    p.in_mask = mask; p.act = ACT_RELU;
-    c.conv1(p, B, T, "dp.conv_1");
-    LnArgs l;
-    std::memset(&l, 0, sizeof(l));
-    l.a = P.dp1; l.gamma = c.W(m.dp_g1.off); l.beta = c.W(m.dp_b1.off); l.eps = 1e-5f; l.out = P.dp1;
-    l.B = B; l.C = kDpFilter; l.T = T;
-    c.ln(l, "dp.norm_1");
-    p = c.prob(m.dp_c2, P.dp1, P.dp2, T);
-    p.in_mask = mask; p.act = ACT_RELU;
-    c.conv1(p, B, T, "dp.conv_2");
-    l.a = P.dp2; l.gamma = c.W(m.dp_g2.off); l.beta = c.W(m.dp_b2.off); l.out = P.dp2;
-    c.ln(l, "dp.norm_2");
-    p = c.prob(m.dp_proj, P.dp2, P.logw_dp, T);
-    p.in_mask = mask; p.out_mask = mask; p.mask_post = 1;
-    c.conv1(p, B, T, "dp.proj");
-  }
+// DurationPredictor (reference models.py:285-299); dp0 = (x + cond(g)) [* mask is applied by conv_1's input mask]
+static void dp_core(Ctx& c, PlanA& P, const float* dp0, const float* mask, int B, int T, float* logw_dp) {
+  const Model& m = c.m;
+  ConvProb p = c.prob(m.dp_c1, dp0, P.dp1, T);
+  p.in_mask = mask; p.act = ACT_RELU;
+  c.conv1(p, B, T, "dp.conv_1");
+  LnArgs l;
+  std::memset(&l, 0, sizeof(l));
+  l.a = P.dp1; l.gamma = c.W(m.dp_g1.off); l.beta = c.W(m.dp_b1.off); l.eps = 1e-5f; l.out = P.dp1;
+  l.B = B; l.C = kDpFilter; l.T = T;
+  c.ln(l, "dp.norm_1");
+  p = c.prob(m.dp_c2, P.dp1, P.dp2, T);
+  p.in_mask = mask; p.act = ACT_RELU;
+  c.conv1(p, B, T, "dp.conv_2");
+  l.a = P.dp2; l.gamma = c.W(m.dp_g2.off); l.beta = c.W(m.dp_b2.off); l.out = P.dp2;
+  c.ln(l, "dp.norm_2");
+  p = c.prob(m.dp_proj, P.dp2, logw_dp, T);
+  p.in_mask = mask; p.out_mask = mask; p.mask_post = 1;
+  c.conv1(p, B, T, "dp.proj");
+}
 
-  // ---- StochasticDurationPredictor, reverse (reference models.py:197-204, 245-256)
-  {
-    ConvProb p = c.prob(m.sdp_pre, out.x, P.sdp_h, T);
-    p.bias2 = sdp_c; p.bias2_bstride = 3 * H;                 // x = pre(x) + cond(g)
-    c.conv1(p, B, T, "sdp.pre");
+// StochasticDurationPredictor, reverse (reference models.py:197-204, 245-256) up to the last ConvFlow: on return P.z [B,2,T]
+// holds the flow state whose channel 0 the ElementwiseAffine inverse (durations kernel) turns into logw.  P.z must already hold
+// the SCALED noise (randn * noise_scale_w).
+static void sdp_core(Ctx& c, PlanA& P, const float* x, const float* mask, const float* sdp_c, int sdp_c_stride, int B, int T) {
+  const Model& m = c.m;
+  const int H = m.cfg.hidden_channels;
+  const float sqrt_fc = (float)std::sqrt((double)H);
+  ConvProb p = c.prob(m.sdp_pre, x, P.sdp_h, T);
+  p.bias2 = sdp_c; p.bias2_bstride = sdp_c_stride;              // x = pre(x) + cond(g)
+  c.conv1(p, B, T, "sdp.pre");
+  const bool fused = dds_fused_supported(H) && !c.h->no_fused_dds;
+  if (fused) {
+    DdsPost post;
+    post.proj = &m.sdp_proj; post.post_out = P.sdp_x;             // x = proj(convs(x)) * mask: the ConvFlows' conditioning
+    run_dds_fused(c, m.sdp_convs, P.sdp_h, DdsPre(), P.y1, P.y2, mask, post, B, H, T, sqrt_fc);
+  } else {
     run_dds(c, m.sdp_convs, P.sdp_h, P.y1, P.y2, P.slab, mask, B, H, T);
     p = c.prob(m.sdp_proj, P.sdp_h, P.sdp_x, T);
     p.out_mask = mask; p.mask_post = 1;
     c.conv1(p, B, T, "sdp.proj");
-    c.tap("sdp.x", P.sdp_x, (int64_t)B * H * T);
-    c.chk(launch_scale(s, in.noise_w, P.z, in.noise_scale_w, (int64_t)B * 2 * T), "sdp.noise");
-    // Flip, CF, Flip, CF, Flip, CF, Flip, EA: the 2-channel flips are index swaps (src/dst), never data movement
-    for (int i = 0; i < kSdpFlowsUsed; ++i) {
-      const int src = (i % 2 == 0) ? 1 : 0, dst = 1 - src;
-      const ConvFlowW& F = m.cf[i];
-      c.chk(launch_convflow_pre(s, P.z, src, c.W(F.pre_w.off), c.W(F.pre_b.off), P.sdp_x, P.sdp_h, B, H, T), "cf.pre");
+  }
+  c.tap("sdp.x", P.sdp_x, (int64_t)B * H * T);
+  // Flip, CF, Flip, CF, Flip, CF, Flip, EA: the 2-channel flips are index swaps (src/dst), never data movement
+  for (int i = 0; i < kSdpFlowsUsed; ++i) {
+    const int src = (i % 2 == 0) ? 1 : 0, dst = 1 - src;
+    const ConvFlowW& F = m.cf[i];
+    if (fused) {
+      DdsPre pre;
+      pre.w = c.W(F.pre_w.off); pre.b = c.W(F.pre_b.off); pre.z = P.z; pre.z_src = src; pre.g = P.sdp_x;
+      DdsPost post;
+      post.proj = &F.proj; post.zio = P.z; post.z_src = src; post.z_dst = dst;
+      run_dds_fused(c, F.convs, nullptr, pre, P.sdp_h, P.y1, mask, post, B, H, T, sqrt_fc);
+    } else {
+      c.chk(launch_convflow_pre(c.s, P.z, src, c.W(F.pre_w.off), c.W(F.pre_b.off), P.sdp_x, P.sdp_h, B, H, T), "cf.pre");
       run_dds(c, F.convs, P.sdp_h, P.y1, P.y2, P.slab, mask, B, H, T);
       p = c.prob(F.proj, P.sdp_h, P.params, T);
       p.out_bstride = (int64_t)32 * T;
       p.out_mask = mask; p.mask_post = 1;
       c.conv1(p, B, T, "cf.proj");
-      c.chk(launch_spline(s, P.z, src, dst, P.params, 32, mask, (float)std::sqrt((double)H), 5.0f, B, T), "cf.spline");
-      const std::string tn = "sdp.z." + std::to_string(i);
-      c.tap(tn.c_str(), P.z, (int64_t)B * 2 * T);
+      c.chk(launch_spline(c.s, P.z, src, dst, P.params, 32, mask, sqrt_fc, 5.0f, B, T), "cf.spline");
     }
+    const std::string tn = "sdp.z." + std::to_string(i);
+    c.tap(tn.c_str(), P.z, (int64_t)B * 2 * T);
   }
+}
+
+static void run_durations(Ctx& c, const PlanA& P, const float* logw_dp, const float* mask, float sdp_ratio, float length_scale,
+                          float* logw_sdp, float* logw, float* w_ceil, int64_t* y_lengths, int B, int T) {
+  const Model& m = c.m;
+  DurArgs d;
+  d.z = P.z; d.ea_m = c.W(m.ea_m.off); d.ea_logs = c.W(m.ea_logs.off);
+  d.logw_dp = logw_dp; d.mask = mask;
+  d.sdp_ratio = sdp_ratio; d.one_minus_ratio = (float)(1.0 - (double)sdp_ratio); d.length_scale = length_scale;
+  d.logw_sdp = logw_sdp; d.logw = logw; d.w_ceil = w_ceil; d.y_lengths = y_lengths;
+  d.B = B; d.T = T;
+  c.chk(launch_durations(c.s, d), "durations");
+}
+
+// ===============================================================================================================
+// phase A: emb_g, enc_p, sdp, dp, durations
+int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_encode_out& out, void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  const bv2_config& cf = m.cfg;
+  const int B = in.B, T = in.T, H = cf.hidden_channels;
+  Arena A(ws, wsb);
+  PlanA P = plan_a(A, m, B, T);
+  if (!A.ok()) { h->err = "workspace too small for bv2_encode_durations"; return -5; }
+  Ctx c{h, s, m, h->blob};
+  const float* mask = out.x_mask;
+
+  // ONE front launch: g = emb_g(sid), x_mask, every g-conditioned vector of this phase, and the scaled SDP noise
+  float *spk = P.gv, *sdp_c = P.gv + H, *dp_c = P.gv + 2 * H;
   {
-    DurArgs d;
-    d.z = P.z; d.ea_m = c.W(m.ea_m.off); d.ea_logs = c.W(m.ea_logs.off);
-    d.logw_dp = P.logw_dp; d.mask = mask;
-    d.sdp_ratio = in.sdp_ratio; d.one_minus_ratio = (float)(1.0 - (double)in.sdp_ratio); d.length_scale = in.length_scale;
-    d.logw_sdp = out.logw_sdp ? out.logw_sdp : P.logw_sdp; d.logw = out.logw; d.w_ceil = out.w_ceil; d.y_lengths = out.y_lengths;
-    d.B = B; d.T = T;
-    c.chk(launch_durations(s, d), "durations");
+    const GemvW* gw[3] = {&m.enc.spk, &m.sdp_cond, &m.dp_cond};
+    float* go[3] = {spk, sdp_c, dp_c};
+    run_front(c, in.sid, nullptr, out.g, gw, go, 3, 3 * H, in.x_lengths, out.x_mask, B, T, in.noise_w, P.z, in.noise_scale_w);
   }
-  if (out.logw_dp && !c.rc)
-    (void)hipMemcpyAsync(out.logw_dp, P.logw_dp, sizeof(float) * (size_t)B * T, hipMemcpyDeviceToDevice, s);
-  (void)C;
+  const float* berts[3] = {in.bert, in.ja_bert, in.en_bert};
+  enc_p_core(c, P, in.x, in.tone, in.language, berts, mask, spk, 3 * H, B, T, out.x, out.m_p, out.logs_p, P.dp0, dp_c);
+  float* logw_dp = out.logw_dp ? out.logw_dp : P.logw_dp;
+  dp_core(c, P, P.dp0, mask, B, T, logw_dp);
+  sdp_core(c, P, out.x, mask, sdp_c, 3 * H, B, T);
+  run_durations(c, P, logw_dp, mask, in.sdp_ratio, in.length_scale, out.logw_sdp ? out.logw_sdp : P.logw_sdp, out.logw,
+                out.w_ceil, out.y_lengths, B, T);
+  return c.rc;
+}
+
+// ---- the reference's ONNX stages of phase A (include/bv2.h) --------------------------------------------------------
+int run_stage_emb_g(bv2_handle* h, hipStream_t s, int B, const int64_t* sid, float* g) {
+  const Model& m = h->model;
+  Ctx c{h, s, m, h->blob};
+  c.chk(launch_gather_rows(s, c.W(m.emb_g.off), sid, g, B, m.cfg.gin_channels, m.cfg.n_speakers), "emb_g");
+  return c.rc;
+}
+
+int run_stage_enc_p(bv2_handle* h, hipStream_t s, int B, int T, const int64_t* x, const int64_t* tone, const int64_t* lang,
+                    const float* b0, const float* b1, const float* b2, const float* g, const int64_t* x_lengths, float* xout,
+                    float* m_p, float* logs_p, float* x_mask, void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  const int H = m.cfg.hidden_channels;
+  Arena A(ws, wsb);
+  PlanA P = plan_a(A, m, B, T);
+  if (!A.ok()) { h->err = "workspace too small for bv2_stage_enc_p"; return -5; }
+  Ctx c{h, s, m, h->blob};
+  const GemvW* gw[1] = {&m.enc.spk};
+  float* go[1] = {P.gv};
+  run_front(c, nullptr, g, nullptr, gw, go, 1, 3 * H, x_lengths, x_mask, B, T, nullptr, nullptr, 0.f);
+  const float* berts[3] = {b0, b1, b2};
+  enc_p_core(c, P, x, tone, lang, berts, x_mask, P.gv, 3 * H, B, T, xout, m_p, logs_p, nullptr, nullptr);
+  return c.rc;
+}
+
+int run_stage_sdp(bv2_handle* h, hipStream_t s, int B, int T, const float* x, const float* x_mask, const float* zin,
+                  const float* g, float* logw, void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  const int H = m.cfg.hidden_channels;
+  Arena A(ws, wsb);
+  PlanA P = plan_a(A, m, B, T);
+  if (!A.ok()) { h->err = "workspace too small for bv2_stage_sdp"; return -5; }
+  Ctx c{h, s, m, h->blob};
+  const GemvW* gw[1] = {&m.sdp_cond};
+  float* go[1] = {P.gv + H};
+  run_front(c, nullptr, g, nullptr, gw, go, 1, 3 * H, nullptr, nullptr, B, T, zin, P.z, 1.0f);   // zin is already scaled
+  sdp_core(c, P, x, x_mask, P.gv + H, 3 * H, B, T);
+  run_durations(c, P, nullptr, x_mask, 1.f, 1.f, logw, nullptr, nullptr, nullptr, B, T);
+  return c.rc;
+}
+
+int run_stage_dp(bv2_handle* h, hipStream_t s, int B, int T, const float* x, const float* x_mask, const float* g, float* logw,
+                 void* ws, int64_t wsb) {
+  const Model& m = h->model;
+  const int H = m.cfg.hidden_channels;
+  Arena A(ws, wsb);
+  PlanA P = plan_a(A, m, B, T);
+  if (!A.ok()) { h->err = "workspace too small for bv2_stage_dp"; return -5; }
+  Ctx c{h, s, m, h->blob};
+  const GemvW* gw[1] = {&m.dp_cond};
+  float* go[1] = {P.gv + 2 * H};
+  run_front(c, nullptr, g, nullptr, gw, go, 1, 3 * H, nullptr, nullptr, B, T, nullptr, nullptr, 0.f);
+  c.chk(launch_add_vec_mask(s, x, P.gv + 2 * H, 3 * H, nullptr, P.dp0, B, H, T), "dp.cond");
+  dp_core(c, P, P.dp0, x_mask, B, T, logw);
   return c.rc;
 }
 
@@ -554,7 +698,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     }
     // the n_rbk ResBlock1 branches run side by side
     const int nb = m.n_rbk;
-    bool fused = U.cout <= 32 && nb <= 3 && !getenv("BV2_NO_FUSED_RESBLOCK");
+    bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock;
     for (int j = 0; j < nb && fused; ++j)
       for (int d = 0; d < m.n_rbd; ++d)
         fused = fused && resblock_fused_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
@@ -712,7 +856,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     }
     tap_cl("dec.ups." + std::to_string(i), x, U.cout, Lo);
     const int nb = m.n_rbk;
-    bool whole = nb <= 3 && !getenv("BV2_NO_FUSED_RESBLOCK");
+    bool whole = nb <= 3 && !c.h->no_fused_resblock;
     for (int j = 0; j < nb && whole; ++j) whole = m.rbcl_w_off[i][j] >= 0;
     if (whole) {
       // narrow stages: every branch's whole ResBlock (all dilation pairs) in ONE launch, intermediates in LDS
@@ -807,12 +951,12 @@ int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_
   ExpandArgs e;
   std::memset(&e, 0, sizeof(e));
   e.w_ceil = in.w_ceil; e.x_mask = in.x_mask; e.y_lengths = in.y_lengths; e.m_p = in.m_p; e.logs_p = in.logs_p;
-  e.noise = in.noise_z; e.nz_bstride = in.nz_bstride; e.nz_cstride = in.nz_cstride; e.noise_scale = in.noise_scale;
+  e.noise = in.noise_z; e.nz_bstride = in.nz_bstride; e.nz_cstride = in.nz_cstride; e.nz_tstride = in.nz_tstride;
+  e.noise_scale = in.noise_scale;
   e.frame_idx = P.fidx; e.attn = out.attn; e.y_mask = ymask; e.z_p = z; e.m_e = out.m_p; e.logs_e = out.logs_p;
+  e.z_p2 = out.z_p;                                  // the flow updates z in place: z_p is kept as a second store
   e.B = B; e.C = C; e.T = T; e.Ty = Ty;
   c.chk(launch_expand(s, e), "expand");
-  if (out.z_p && !c.rc)
-    (void)hipMemcpyAsync(out.z_p, z, sizeof(float) * (size_t)B * C * Ty, hipMemcpyDeviceToDevice, s);
   phase_b_gemv(c, P, in.g, B);
   flow_core(c, P, z, ymask, in.g, B, Ty);
   const int L = (in.max_len > 0 && in.max_len < Ty) ? in.max_len : Ty;
@@ -822,15 +966,18 @@ int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_
   return c.rc;
 }
 
-int run_flow(bv2_handle* h, hipStream_t s, int B, int Ty, const float* z_p, const int64_t* y_lengths, const float* g,
-             float* z, void* ws, int64_t wsb) {
+int run_flow(bv2_handle* h, hipStream_t s, int B, int Ty, const float* z_p, const int64_t* y_lengths, const float* y_mask,
+             const float* g, float* z, void* ws, int64_t wsb) {
   const Model& m = h->model;
   Arena A(ws, wsb);
   PlanB P = plan_b(A, m, B, Ty);
   if (!A.ok()) { h->err = "workspace too small for bv2_stage_flow"; return -5; }
   Ctx c{h, s, m, h->blob};
-  float* ymask = P.ymask;
-  c.chk(launch_seq_mask(s, y_lengths, ymask, B, Ty), "y_mask");
+  const float* ymask = y_mask;
+  if (!ymask) {
+    c.chk(launch_seq_mask(s, y_lengths, P.ymask, B, Ty), "y_mask");
+    ymask = P.ymask;
+  }
   if (z != z_p)
     (void)hipMemcpyAsync(z, z_p, sizeof(float) * (size_t)B * m.cfg.inter_channels * Ty, hipMemcpyDeviceToDevice, s);
   phase_b_gemv(c, P, g, B);
@@ -846,8 +993,11 @@ int run_generator(bv2_handle* h, hipStream_t s, int B, int Ty, int L, const floa
   PlanB P = plan_b(A, m, B, Ty);
   if (!A.ok()) { h->err = "workspace too small for bv2_stage_generator"; return -5; }
   Ctx c{h, s, m, h->blob};
-  float* ymask = P.ymask;
-  c.chk(launch_seq_mask(s, y_lengths, ymask, B, Ty), "y_mask");
+  const float* ymask = nullptr;                    // y_lengths == null: z_in is taken as it is (the exported dec graph)
+  if (y_lengths) {
+    c.chk(launch_seq_mask(s, y_lengths, P.ymask, B, Ty), "y_mask");
+    ymask = P.ymask;
+  }
   phase_b_gemv(c, P, g, B);
   if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, o, nullptr);
   else gen_core(c, P, z, Ty, ymask, B, L, o, nullptr);

@@ -120,6 +120,9 @@ struct bv2_handle {
   std::map<std::string, bv2::Tap> taps;
   int gen_dtype = BV2_F32;           // Generator arithmetic: BV2_F32 (conv_mfma.hip) or BV2_BF16 (gen_bf16.hip)
   int flow_dtype = BV2_F32;          // transformer-flow Encoder convs: BV2_F32 (conv_mfma.hip) or BV2_F16 (enc_f16.hip)
+  // bv2_set_option switches (tests compare the fused kernels with the layer-wise ones)
+  bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
+  bool no_fused_dds = false;         // "fused_dds" = 0: DDSConv layers as 3 launches each
   // profiling
   bool prof_on = false;
   int prof_mode = 1;                 // 1: every MFMA kernel launch, 2: Generator (dec.*) launches only
@@ -139,8 +142,16 @@ bool key_in_schema(const Model& m, const std::string& key);
 int64_t workspace_bytes(const Model& m, int B, int T, int Ty);
 int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_encode_out& out, void* ws, int64_t wsb);
 int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_decode_out& out, void* ws, int64_t wsb);
-int run_flow(bv2_handle* h, hipStream_t s, int B, int Ty, const float* z_p, const int64_t* y_lengths, const float* g,
-             float* z, void* ws, int64_t wsb);
+int run_flow(bv2_handle* h, hipStream_t s, int B, int Ty, const float* z_p, const int64_t* y_lengths, const float* y_mask,
+             const float* g, float* z, void* ws, int64_t wsb);
+int run_stage_emb_g(bv2_handle* h, hipStream_t s, int B, const int64_t* sid, float* g);
+int run_stage_enc_p(bv2_handle* h, hipStream_t s, int B, int T, const int64_t* x, const int64_t* tone, const int64_t* lang,
+                    const float* b0, const float* b1, const float* b2, const float* g, const int64_t* x_lengths, float* xout,
+                    float* m_p, float* logs_p, float* x_mask, void* ws, int64_t wsb);
+int run_stage_sdp(bv2_handle* h, hipStream_t s, int B, int T, const float* x, const float* x_mask, const float* zin,
+                  const float* g, float* logw, void* ws, int64_t wsb);
+int run_stage_dp(bv2_handle* h, hipStream_t s, int B, int T, const float* x, const float* x_mask, const float* g, float* logw,
+                 void* ws, int64_t wsb);
 int run_generator(bv2_handle* h, hipStream_t s, int B, int Ty, int L, const float* z, const int64_t* y_lengths,
                   const float* g, float* o, void* ws, int64_t wsb);
 

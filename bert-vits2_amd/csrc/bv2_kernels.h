@@ -81,6 +81,8 @@ int conv_pick_ksplit(const ConvLaunch& L, int max_split);
 inline int64_t conv_w_index(int j, int ci, int co, int cin_pad, int k) {
   return ((((((int64_t)(co >> 5) * (cin_pad / 8) + ci / 8) * k + j) * 2 + (ci & 1)) * 32) + (co & 31)) * 4 + (ci % 8) / 2;
 }
+// tuning experiments only (tools/kbench.py through bv2_test_set_tuning): 0 = shipped heuristics
+void conv_set_tuning(int splitk_waves, int force_ck, long tile_target);
 double conv_flops(const ConvLaunch& L);
 double conv_bytes(const ConvLaunch& L);
 
@@ -218,6 +220,8 @@ int launch_conv_post(hipStream_t stream, const ConvPostArgs& a);
 //             = dwb[c] + sum_j dww[c][j] * a[b][c][t+(j-1)*dil]*in_mask[b][.]   mode 1 (depthwise k=3, DDSConv)
 //   y         = (v - mean_c) * rsqrt(var_c + eps) * gamma[c] + beta[c];  y = gelu(y) if post_gelu
 //   out       = ((res ? res : 0) + y + (vec ? vec[b][c] : 0)) * (mask ? mask[b][t] : 1)
+//   out2      = ((res ? res : 0) + y + (vec ? vec[b][c] : 0) + vec2[b][c]) * mask     (optional second output: the
+//               DurationPredictor's `x + cond(g)` rides on the text encoder's last LayerNorm, models.py:288-289)
 struct LnArgs {
   const float* a; const float* add;
   int nslab; int64_t slab_stride;     // nslab <= 1: a is a plain tensor
@@ -227,6 +231,7 @@ struct LnArgs {
   const float* res; const float* vec; int vec_bstride; const float* mask;
   float* out;
   int B, C, T;
+  float* out2; const float* vec2; int vec2_bstride;
 };
 int launch_layernorm(hipStream_t stream, const LnArgs& a);
 
@@ -252,6 +257,18 @@ double attention_flops(const AttnArgs& a);
 struct GemvProb { const float* w; const float* bias; float* out; int cout, cin; int out_bstride; };  // w [cout][cin]
 struct GemvLaunch { GemvProb p[16]; int nprob; int B; const float* g; int g_bstride; };
 int launch_gemv(hipStream_t stream, const GemvLaunch& L);            // out[b][co] = bias[co] + w[co][:]·g[b][:]
+
+// phase-A front (one launch): the speaker-conditioning GEMVs with g either given or looked up (g[b] = table[sid[b]], also
+// written to g_out — emb_g, models.py:1046), x_mask = sequence_mask(x_lengths) (commons.py:119-123; lengths null = all ones)
+// and z = noise * noise_scale_w (models.py:248-251).  Every part is optional.
+struct FrontArgs {
+  GemvProb p[16]; int nprob; int B;
+  const float* g; int g_bstride;
+  const float* table; const int64_t* sid; int nrows; float* g_out; int gin;
+  const int64_t* lengths; float* mask; int T;
+  const float* noise; float* z; float noise_scale; int64_t nz;
+};
+int launch_front(hipStream_t stream, const FrontArgs& a);
 
 int launch_gather_rows(hipStream_t stream, const float* table, const int64_t* idx, float* out, int B, int C, int nrows);
 int launch_seq_mask(hipStream_t stream, const int64_t* lengths, float* mask, int B, int T);
@@ -290,13 +307,40 @@ struct DurArgs {
 };
 int launch_durations(hipStream_t stream, const DurArgs& a);
 
+// --- one whole DDSConv layer per launch (kernels/dds_fused.hip; reference modules.py:121-129) -----------------------
+//   xin = x                      or   pre_w[c]*z[b][z_src][t] + pre_b[c] + g[b][c][t]   (ConvFlow.pre + the `x + g`, modules.py:488-489,119-120)
+//   y   = gelu(LN1(dwb + dwconv_k3,dil(xin*mask)));  y = W y + bias (1x1, MFMA);  y = gelu(LN2(y));  out = xin + y  [* mask if last_mask]
+// optional post 1x1 GEMM on the (masked) layer output, for the layer that ends a DDSConv:
+//   post_out != null : post_out[b][r][t] = (Wp out + bp)[r][t] * mask                        (sdp.proj, models.py:203-204)
+//   zio      != null : params = (Wp out + bp) * mask (29 rows); z[b][z_dst] = mask * rq_spline_inverse(z[b][z_dst]; params);
+//                      z[b][z_src] *= mask                                                   (ConvFlow.proj + spline, modules.py:491-516)
+// A workgroup owns 16 time steps x all C channels (C/16 waves); both channel LayerNorms reduce with wave shuffles + one LDS
+// exchange; the 1x1 convs run on v_mfma_f32_16x16x4_f32 with weights in the conv_w_index fragment order (k = 1).
+// out must not alias x (tiles read their neighbours' columns).  C in {128, 192, 256}.
+struct DdsArgs {
+  const float* x; const float* pre_w; const float* pre_b; const float* z; int z_src; const float* g;
+  const float* mask;
+  const float* dww; const float* dwb; const float* g1; const float* b1; const float* g2; const float* b2;
+  const float* w; const float* bias;
+  float* out;                           // [B][C][T] or null (when only the post GEMM's result is needed)
+  int dil, last_mask; float eps;
+  const float* post_w; const float* post_b; int post_cout, post_cout_pad;
+  float* post_out;
+  float* zio; int z_dst; float sqrt_fc, tail;
+  float cst, wscale;                    // filled by launch_dds_layer
+  int B, C, T;
+};
+bool dds_fused_supported(int C);
+int launch_dds_layer(hipStream_t stream, const DdsArgs& a);
+
 // --- length regulation (reference models.py:1058-1071, commons.py:126-140) ---
 struct ExpandArgs {
   const float* w_ceil; const float* x_mask; const int64_t* y_lengths;
   const float* m_p; const float* logs_p;             // [B][C][T]
-  const float* noise; int64_t nz_bstride, nz_cstride; float noise_scale;
+  const float* noise; int64_t nz_bstride, nz_cstride, nz_tstride; float noise_scale;
   int* frame_idx;                                     // [B][Ty] scratch
   float* attn; float* y_mask; float* z_p; float* m_e; float* logs_e;   // outputs (attn/y_mask/m_e/logs_e may be null)
+  float* z_p2;                                        // optional second copy of z_p (the flow updates z_p in place)
   int B, C, T, Ty;
 };
 int launch_expand(hipStream_t stream, const ExpandArgs& a);

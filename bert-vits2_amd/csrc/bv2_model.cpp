@@ -490,7 +490,7 @@ int pack_blob(const Model& m_in, const std::map<std::string, HostTensor>& t, flo
   }
   if (m.total_floats != m_in.total_floats) { err = "internal: layout drift between passes"; return -4; }
   uint32_t* hdr = reinterpret_cast<uint32_t*>(blob);
-  hdr[0] = kBlobMagic; hdr[1] = BV2_ABI_VERSION; hdr[2] = m_in.cfg_hash; hdr[3] = 0;
+  hdr[0] = kBlobMagic; hdr[1] = BV2_ABI_VERSION; hdr[2] = m_in.cfg_hash; hdr[3] = BV2_PACK_LAYOUT;
   int64_t tf = m.total_floats;
   std::memcpy(hdr + 4, &tf, sizeof(tf));
   return 0;

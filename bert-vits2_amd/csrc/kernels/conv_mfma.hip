@@ -23,7 +23,6 @@
 // (models.py:539-545), attentions.FFN (attentions.py:438-446), q/k/v/o and all 1x1 projections, DurationPredictor
 // convs (models.py:285-299), WN in/res_skip layers (modules.py:192-210).
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "../bv2_kernels.h"
 
 namespace bv2 {
@@ -485,11 +484,15 @@ static int splitk_units(const ConvLaunch& L) {
   return units;
 }
 
+// tuning experiments (tools/kbench.py drive these through bv2_test_set_tuning; 0 = the shipped heuristics)
+static int g_tune_splitk_waves = 0, g_tune_force_ck = 0;
+static long g_tune_tile_target = 0;
+void conv_set_tuning(int splitk_waves, int force_ck, long tile_target) {
+  g_tune_splitk_waves = splitk_waves; g_tune_force_ck = force_ck; g_tune_tile_target = tile_target;
+}
+
 static int splitk_waves(const ConvLaunch& L) {
-  if (const char* e = getenv("BV2_SPLITK_WAVES")) {               // tuning experiments (tools/kbench.py)
-    const int w = atoi(e);
-    if (w == 4 || w == 8 || w == 16) return w;
-  }
+  if (g_tune_splitk_waves == 4 || g_tune_splitk_waves == 8 || g_tune_splitk_waves == 16) return g_tune_splitk_waves;
   const int slices = (splitk_units(L) + SK_UNITS_PER_WAVE - 1) / SK_UNITS_PER_WAVE;   // K slices wanted in total
   const int per_wg = (slices + L.ksplit - 1) / L.ksplit;
   return per_wg > 4 ? 8 : 4;
@@ -564,8 +567,7 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     if ((p.k - 1) * p.dil > max_extra) max_extra = (p.k - 1) * p.dil;
     if (p.cin_pad % 32) ck = 16;
   }
-  static const int force_ck = [] { const char* e = getenv("BV2_FORCE_CK"); return e ? atoi(e) : 0; }();
-  if (force_ck == 16) ck = 16;
+  if (g_tune_force_ck == 16) ck = 16;
   for (int i = 0; i < L.nprob; ++i)
     if (L.p[i].cin_pad / ck > max_chunks) max_chunks = L.p[i].cin_pad / ck;
   if (tile == TILE_AUTO && conv_use_splitk(L)) tile = TILE_SPLITK;
@@ -578,8 +580,8 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     // largest tile that still yields >= ~6 workgroups per CU (256 CUs; measured optimum, profiles/r01_c_*): the problems
     // of one launch differ in cost (k = 3 / 7 / 11 branches) and only 2-3 workgroups are resident per CU, so the
     // dispatcher balances them only if there are several times more workgroups than slots; per-tile prologue/epilogue
-    // latency is also hidden by the co-resident workgroups.  BV2_TILE_TARGET overrides (tuning experiments).
-    static const long target = [] { const char* e = getenv("BV2_TILE_TARGET"); return e ? atol(e) : 1536L; }();
+    // latency is also hidden by the co-resident workgroups.  conv_set_tuning overrides (tuning experiments).
+    const long target = g_tune_tile_target > 0 ? g_tune_tile_target : 1536L;
     tile = TILE_32x128;
     double best_score = -1.0;
     bool reached = false;

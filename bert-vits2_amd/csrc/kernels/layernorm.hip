@@ -8,7 +8,10 @@
 // Latency-first layout (at batch 1 the tensor is ~300 KB): a workgroup owns only 8 consecutive time steps x all C
 // channels; thread (tx = t, ty = channel group of 32) keeps its C/32 values in registers.  All loads are unconditional
 // (clamped addresses) and the slab / channel counts are template parameters, so every load of a thread is in flight
-// at once: ONE memory round trip, then a two-pass (mean, centred sum of squares) reduction through LDS.
+// at once: ONE memory round trip.  The channel reduction is wavefront-level: a wave holds 8 time steps x 8 channel groups
+// (lane = tx + 8*cg), so each of the two passes (mean, then the centred sum of squares — the exact two-pass variance) is
+// three `__shfl_xor` butterflies (lane ^ 8, ^ 16, ^ 32) plus ONE 4-entry exchange between the workgroup's four waves
+// through LDS: two barriers per kernel, no serial sums.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
 
@@ -19,8 +22,7 @@ constexpr int LN_G = 32;       // channel groups (threads along C)
 
 template <int CPT, int NSLAB, int MODE, bool GUARD>   // CPT channels per thread; GUARD: C < CPT*LN_G allowed
 __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
-  __shared__ float red[LN_G][LN_TT + 1];
-  __shared__ float stat[LN_TT];
+  __shared__ float red[2][4][LN_TT];               // [pass][wave][time step]
   const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 3;
   const int b = blockIdx.y;
   const int t = blockIdx.x * LN_TT + tx;
@@ -72,20 +74,18 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
       v[i] = x;
     }
   }
+  // ---- wave-level reduction over the channel groups (lanes tx + 8*cg), then across the 4 waves
+  const int wv = threadIdx.x >> 6;
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i)
     if (!GUARD || ty + i * LN_G < C) s += v[i];
-  red[ty][tx] = s;
+  s += __shfl_xor(s, 8);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if ((threadIdx.x & 63) < LN_TT) red[0][wv][tx] = s;
   __syncthreads();
-  if (ty == 0) {
-    float m = 0.f;
-#pragma unroll
-    for (int g = 0; g < LN_G; ++g) m += red[g][tx];
-    stat[tx] = m / (float)C;
-  }
-  __syncthreads();
-  const float mean = stat[tx];
+  const float mean = ((red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx])) / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i)
@@ -93,17 +93,12 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
       const float d = v[i] - mean;
       q += d * d;
     }
+  q += __shfl_xor(q, 8);
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  if ((threadIdx.x & 63) < LN_TT) red[1][wv][tx] = q;
   __syncthreads();
-  red[ty][tx] = q;
-  __syncthreads();
-  if (ty == 0) {
-    float m = 0.f;
-#pragma unroll
-    for (int g = 0; g < LN_G; ++g) m += red[g][tx];
-    stat[tx] = 1.0f / sqrtf(m / (float)C + A.eps);
-  }
-  __syncthreads();
-  const float rstd = stat[tx];
+  const float rstd = 1.0f / sqrtf(((red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx])) / (float)C + A.eps);
   if (!tok) return;
   const float mk = A.mask ? A.mask[(int64_t)b * T + t] : 1.f;
   float rr[CPT];
@@ -122,6 +117,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
       y += rr[i];
       if (A.vec) y += A.vec[(int64_t)b * A.vec_bstride + c];
       A.out[base + c * T + t] = y * mk;
+      if (A.out2) A.out2[base + c * T + t] = (y + A.vec2[(int64_t)b * A.vec2_bstride + c]) * mk;
     }
   }
 }

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <cmath>
 #include "../bv2_kernels.h"
+#include "spline.h"
 
 namespace bv2 {
 
@@ -75,6 +76,60 @@ int launch_gemv(hipStream_t stream, const GemvLaunch& L) {
   for (int i = 0; i < L.nprob; ++i) maxc = L.p[i].cout > maxc ? L.p[i].cout : maxc;
   dim3 grid((maxc + 3) / 4, L.nprob);
   hipLaunchKernelGGL(gemv_kernel, grid, dim3(256), 0, stream, L);
+  return BV2_CHECK_LAUNCH();
+}
+
+// phase-A front: the GEMVs above with g optionally looked up through sid (emb_g, models.py:1046), plus — in the extra block row —
+// g_out, x_mask = sequence_mask(x_lengths) (commons.py:119-123) and z = noise * noise_scale_w (models.py:248-251).
+__global__ void __launch_bounds__(256) front_kernel(const FrontArgs A) {
+  if ((int)blockIdx.y < A.nprob) {
+    const GemvProb& P = A.p[blockIdx.y];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= P.cout) return;
+    const float* w = P.w + (int64_t)row * P.cin;
+    for (int b = 0; b < A.B; ++b) {
+      const float* g;
+      if (A.sid) {
+        int64_t r = A.sid[b];
+        r = r < 0 ? 0 : (r >= A.nrows ? A.nrows - 1 : r);
+        g = A.table + r * A.gin;
+      } else {
+        g = A.g + (int64_t)b * A.g_bstride;
+      }
+      float acc = 0.f;
+      for (int k = lane; k < P.cin; k += 64) acc += w[k] * g[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+      if (lane == 0) P.out[(int64_t)b * P.out_bstride + row] = acc + (P.bias ? P.bias[row] : 0.f);
+    }
+    return;
+  }
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+  if (A.sid && A.g_out)
+    for (int64_t i = i0; i < (int64_t)A.B * A.gin; i += step) {
+      const int b = (int)(i / A.gin), c = (int)(i - (int64_t)b * A.gin);
+      int64_t r = A.sid[b];
+      r = r < 0 ? 0 : (r >= A.nrows ? A.nrows - 1 : r);
+      A.g_out[i] = A.table[r * A.gin + c];
+    }
+  if (A.mask)
+    for (int64_t i = i0; i < (int64_t)A.B * A.T; i += step) {
+      const int b = (int)(i / A.T), t = (int)(i - (int64_t)b * A.T);
+      A.mask[i] = (!A.lengths || (int64_t)t < A.lengths[b]) ? 1.f : 0.f;
+    }
+  if (A.z)
+    for (int64_t i = i0; i < A.nz; i += step) A.z[i] = A.noise[i] * A.noise_scale;
+}
+
+int launch_front(hipStream_t stream, const FrontArgs& a) {
+  if (a.nprob < 0 || a.nprob > 16 || a.B < 1) return -1;
+  if (a.nprob > 0 && !a.sid && !a.g) return -1;
+  if (a.sid && (!a.table || a.nrows < 1 || a.gin < 1)) return -1;
+  int maxc = 4;
+  for (int i = 0; i < a.nprob; ++i) maxc = a.p[i].cout > maxc ? a.p[i].cout : maxc;
+  dim3 grid((maxc + 3) / 4, a.nprob + 1);
+  hipLaunchKernelGGL(front_kernel, grid, dim3(256), 0, stream, a);
   return BV2_CHECK_LAUNCH();
 }
 
@@ -169,33 +224,7 @@ int launch_convflow_pre(hipStream_t stream, const float* z, int src, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// inverse piecewise rational-quadratic spline with linear tails, K = 10 bins, one thread per (b, t); always fp32.
-// reference transforms.py:49-96 (tails) and :99-187 (inverse branch :160-173); op order kept (softmax, min-width
-// affine, sequential cumsum, knots forced to +-tail, widths as knot differences, searchsorted with +1e-6 on the last knot).
-constexpr int SPK = 10;
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-
-__device__ void spline_knots(const float* u, float lo, float hi, float minw, float wscale, float* cum /*K+1*/,
-                             float* wd /*K*/) {
-  float mx = u[0];
-#pragma unroll
-  for (int i = 1; i < SPK; ++i) mx = fmaxf(mx, u[i]);
-  float e[SPK], sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < SPK; ++i) { e[i] = expf(u[i] - mx); sum += e[i]; }
-  float c = 0.f;
-  cum[0] = lo;
-#pragma unroll
-  for (int i = 0; i < SPK; ++i) {
-    const float w = minw + wscale * (e[i] / sum);
-    c += w;
-    cum[i + 1] = (hi - lo) * c + lo;
-  }
-  cum[SPK] = hi;
-#pragma unroll
-  for (int i = 0; i < SPK; ++i) wd[i] = cum[i + 1] - cum[i];
-}
-
+// inverse piecewise rational-quadratic spline (spline.h), one thread per (b, t); always fp32.
 __global__ void spline_kernel(float* z, int src, int dst, const float* params, int prow, const float* mask,
                               float sqrt_fc, float tail, float cst, float wscale, int T) {
   const int b = blockIdx.y;
@@ -212,33 +241,7 @@ __global__ void spline_kernel(float* z, int src, int dst, const float* params, i
 
   float* zs = z + ((int64_t)b * 2 + src) * T + t;
   float* zd = z + ((int64_t)b * 2 + dst) * T + t;
-  const float y = *zd;
-  float outv = y;
-  if (y >= -tail && y <= tail) {
-    float cw[SPK + 1], w[SPK], ch[SPK + 1], hh[SPK];
-    spline_knots(uw, -tail, tail, 1e-3f, wscale, cw, w);
-    spline_knots(uh, -tail, tail, 1e-3f, wscale, ch, hh);
-    int bin = -1;
-#pragma unroll
-    for (int i = 0; i <= SPK; ++i) {
-      const float kn = (i == SPK) ? ch[i] + 1e-6f : ch[i];
-      bin += (y >= kn) ? 1 : 0;
-    }
-    bin = bin < 0 ? 0 : (bin > SPK - 1 ? SPK - 1 : bin);
-    float icw = 0, iw = 0, ich = 0, ih = 0, d0 = 0, d1 = 0;
-#pragma unroll
-    for (int i = 0; i < SPK; ++i)
-      if (i == bin) { icw = cw[i]; iw = w[i]; ich = ch[i]; ih = hh[i]; d0 = 1e-3f + softplus_f(ud[i]); d1 = 1e-3f + softplus_f(ud[i + 1]); }
-    const float idl = ih / iw;
-    const float tt = y - ich;
-    const float s = d0 + d1 - 2.f * idl;
-    const float a = tt * s + ih * (idl - d0);
-    const float bq = ih * d0 - tt * s;
-    const float cq = -idl * tt;
-    const float disc = bq * bq - 4.f * a * cq;
-    const float root = (2.f * cq) / (-bq - sqrtf(disc));
-    outv = root * iw + icw;
-  }
+  const float outv = rq_spline_inverse_one(*zd, uw, uh, ud, tail, wscale);
   *zd = outv * mk;
   *zs = *zs * mk;
 }
@@ -264,15 +267,17 @@ __global__ void __launch_bounds__(256) durations_kernel(const DurArgs A) {
     const int64_t bt = (int64_t)b * A.T + t;
     const float mk = A.mask[bt];
     const float ls = (A.z[((int64_t)b * 2) * A.T + t] - m0) * il0 * mk;
+    if (A.logw_sdp) A.logw_sdp[bt] = ls;
+    if (!A.logw_dp) continue;                      // bv2_stage_sdp: only the ElementwiseAffine inverse is wanted
     const float ld = A.logw_dp[bt];
     const float lw = ls * A.sdp_ratio + ld * A.one_minus_ratio;
     const float w = expf(lw) * mk * A.length_scale;
     const float wc = ceilf(w);
-    if (A.logw_sdp) A.logw_sdp[bt] = ls;
     A.logw[bt] = lw;
     A.w_ceil[bt] = wc;
     s += wc;
   }
+  if (!A.logw_dp) return;                          // kernel-uniform
   part[threadIdx.x] = s;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
@@ -339,8 +344,10 @@ __global__ void expand_kernel(const ExpandArgs A) {
     lg = A.logs_p[((int64_t)b * A.C + c) * A.T + i];
   }
   const int64_t off = ((int64_t)b * A.C + c) * A.Ty + j;
-  const float nz = A.noise[(int64_t)b * A.nz_bstride + (int64_t)c * A.nz_cstride + j];
-  A.z_p[off] = m + nz * expf(lg) * A.noise_scale;
+  const float nz = A.noise[(int64_t)b * A.nz_bstride + (int64_t)c * A.nz_cstride + (int64_t)j * A.nz_tstride];
+  const float zp = m + nz * expf(lg) * A.noise_scale;
+  A.z_p[off] = zp;
+  if (A.z_p2) A.z_p2[off] = zp;
   if (A.m_e) A.m_e[off] = m;
   if (A.logs_e) A.logs_e[off] = lg;
 }
@@ -352,7 +359,9 @@ __global__ void attn_path_kernel(const int* frame_idx, float* attn, int T, int T
   attn[((int64_t)b * Ty + j) * T + i] = (frame_idx[(int64_t)b * Ty + j] == i) ? 1.f : 0.f;
 }
 
-int launch_expand(hipStream_t stream, const ExpandArgs& a) {
+int launch_expand(hipStream_t stream, const ExpandArgs& a0) {
+  ExpandArgs a = a0;
+  if (a.nz_tstride <= 0) a.nz_tstride = 1;
   hipLaunchKernelGGL(frame_index_kernel, dim3(a.B), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(expand_kernel, dim3((a.Ty + 255) / 256, a.C, a.B), dim3(256), 0, stream, a);
   if (a.attn)

@@ -16,7 +16,7 @@ MAX_RBK = 4
 MAX_RBD = 4
 
 F32, F16, BF16 = 0, 1, 2
-ABI_VERSION = 2      # include/bv2.h BV2_ABI_VERSION
+ABI_VERSION = 3      # include/bv2.h BV2_ABI_VERSION
 
 
 class Config(C.Structure):
@@ -57,7 +57,8 @@ class DecodeIn(C.Structure):
         ("B", C.c_int32), ("T", C.c_int32), ("Ty", C.c_int32), ("max_len", C.c_int32),
         ("m_p", C.c_void_p), ("logs_p", C.c_void_p), ("x_mask", C.c_void_p), ("w_ceil", C.c_void_p),
         ("y_lengths", C.c_void_p), ("g", C.c_void_p), ("noise_z", C.c_void_p),
-        ("nz_bstride", C.c_int64), ("nz_cstride", C.c_int64), ("noise_scale", C.c_float), ("exact_lengths", C.c_int32),
+        ("nz_bstride", C.c_int64), ("nz_cstride", C.c_int64), ("nz_tstride", C.c_int64), ("noise_scale", C.c_float),
+        ("exact_lengths", C.c_int32),
     ]
 
 
@@ -81,14 +82,19 @@ SYMBOLS = [
     ("bv2_packed_bytes", C.c_int64, [_P]),
     ("bv2_pack_weights", C.c_int, [_P, _P, C.c_int64]),
     ("bv2_attach_weights", C.c_int, [_P, _P, C.c_int64]),
+    ("bv2_detach_weights", C.c_int, [_P]),
     ("bv2_set_generator_dtype", C.c_int, [_P, C.c_int]),
     ("bv2_set_flow_dtype", C.c_int, [_P, C.c_int]),
     ("bv2_workspace_bytes", C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     ("bv2_encode_durations", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64]),
     ("bv2_decode", C.c_int, [_P, _P, C.POINTER(DecodeIn), C.POINTER(DecodeOut), _P, C.c_int64]),
-    ("bv2_stage_flow", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
+    ("bv2_stage_emb_g", C.c_int, [_P, _P, C.c_int, _P, _P]),
+    ("bv2_stage_enc_p", C.c_int, [_P, _P, C.c_int, C.c_int] + [_P] * 12 + [_P, C.c_int64]),
+    ("bv2_stage_sdp", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int64]),
+    ("bv2_stage_dp", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
+    ("bv2_stage_flow", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int64]),
     ("bv2_stage_generator", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
-    ("bv2_infer", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.c_int64, C.c_float,
+    ("bv2_infer", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.c_int64, C.c_int64, C.c_float,
                             C.c_int32, C.c_int32, C.POINTER(DecodeOut), C.POINTER(C.c_int32), _P, C.c_int64]),
     ("bv2_pcm16", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int64, _P]),
     ("bv2_graph_capture_encode", C.c_int, [_P, _P, C.POINTER(EncodeIn), C.POINTER(EncodeOut), _P, C.c_int64, C.POINTER(_P)]),
@@ -96,6 +102,7 @@ SYMBOLS = [
     ("bv2_graph_launch", C.c_int, [_P, _P]),
     ("bv2_graph_num_nodes", C.c_int, [_P]),
     ("bv2_graph_destroy", None, [_P]),
+    ("bv2_set_option", C.c_int, [_P, C.c_char_p, C.c_int]),
     ("bv2_set_tap", C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     ("bv2_profile_enable", C.c_int, [_P, C.c_int]),
     ("bv2_profile_reset", C.c_int, [_P]),
@@ -127,6 +134,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             # symbol are checked below); without one there is nothing to fall back to
             if "hipcc not found" not in str(e) or not os.path.exists(_build.LIB):
                 raise
+            # ... but only if it was built from THESE sources: a stale library with the right ABI number would run an older
+            # packer / kernel set against the current host code
+            if os.path.exists(_build.STAMP) and open(_build.STAMP).read().strip() != _build._digest():
+                raise RuntimeError("libbv2.so in the tree was built from different sources and there is no hipcc here to "
+                                   "rebuild it (python -m bert_vits2_amd.build on a box with ROCm)") from e
             import warnings
             warnings.warn("libbv2.so could not be rebuilt (no hipcc here); loading the library that is in the tree")
     if not os.path.exists(_build.LIB):

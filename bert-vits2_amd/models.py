@@ -27,6 +27,21 @@ from . import lib as L
 from .schema import param_shapes
 
 
+def draw_noise_w(B: int, T: int, device) -> torch.Tensor:
+    """Draw #1 of reference infer(), models.py:248-251: ``torch.randn(B, 2, T).to(device=..., dtype=...)`` — taken from the
+    global CPU generator even when the model sits on a GPU, then uploaded.  Same call, same stream position: a seeded
+    reference run and a seeded run of this shim draw the same SDP noise (RNG contract)."""
+    return torch.randn(B, 2, T).to(device=device, dtype=torch.float32)
+
+
+def draw_noise_z(B: int, C: int, Ty: int, device) -> torch.Tensor:
+    """Draw #2, models.py:1071: ``torch.randn_like(m_p)`` where ``m_p`` is a TRANSPOSED view ([B,C,T_y] with strides
+    (C*T_y, 1, C), models.py:1064-1066) on the model's device.  ``randn_like`` fills in memory order, so only a tensor
+    with those strides reproduces the reference's values (plain ``torch.randn(B, C, T_y)`` does not); the
+    C ABI takes the strides (``bv2_decode_in.nz_*stride``), so the tensor is handed over as it is."""
+    return torch.randn_like(torch.empty(B, Ty, C, device=device, dtype=torch.float32).transpose(1, 2))
+
+
 class _Node(nn.Module):
     """A bare namespace module: only there so that parameters carry the reference's dotted names."""
 
@@ -64,7 +79,12 @@ class SynthesizerTrn(nn.Module):
         self.n_speakers, self.gin_channels = n_speakers, gin_channels
         self.use_sdp = use_sdp
         for key, shape in param_shapes(self.hp).items():
-            self._register(key, torch.zeros(shape, dtype=torch.float32))
+            # placeholders until a checkpoint is loaded: LayerNorm gamma / weight_norm g at 1 (the reference's own defaults,
+            # modules.py:22-23), everything else 0.  infer() refuses to run on them (see repack).
+            leaf = key.rsplit(".", 1)[-1]
+            init = torch.ones if leaf in ("gamma", "weight_g") else torch.zeros
+            self._register(key, init(shape, dtype=torch.float32))
+        self._params_loaded = False
         self._lib = None
         self._handle = C.c_void_p()
         self._blob: Optional[torch.Tensor] = None
@@ -86,8 +106,18 @@ class SynthesizerTrn(nn.Module):
             node = node._modules[p]
         node.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
 
-    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+    def _invalidate_weights(self) -> None:
+        """The packed device blob no longer matches the parameters (or is about to move): forget it everywhere — captured
+        graphs baked its address in, and the C handle must not keep pointing at memory torch may free."""
+        if getattr(self, "_graphs", None):
+            self._drop_graphs()
+        if getattr(self, "_lib", None) is not None and getattr(self, "_handle", None):
+            self._lib.bv2_detach_weights(self._handle)
         self._blob = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._invalidate_weights()
+        self._params_loaded = True
         if not strict:
             # the reference loads with strict=False and tolerates training-only keys (enc_q.*, sdp.post_*)
             own = set(k for k, _ in self.named_parameters())
@@ -95,8 +125,8 @@ class SynthesizerTrn(nn.Module):
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def _apply(self, fn, *a, **k):
-        if getattr(self, "_blob", None) is not None:
-            self._blob = None
+        if hasattr(self, "_blob"):
+            self._invalidate_weights()
         self._ws = None
         return super()._apply(fn, *a, **k)
 
@@ -150,9 +180,9 @@ class SynthesizerTrn(nn.Module):
         """Use an already packed blob resident on this GPU (e.g. received through an RCCL broadcast)."""
         lib = self._ensure_handle()
         assert dev_blob.is_cuda and dev_blob.dtype == torch.uint8 and dev_blob.is_contiguous()
+        self._drop_graphs()
         self._check(lib.bv2_attach_weights(self._handle, C.c_void_p(dev_blob.data_ptr()), dev_blob.numel()),
                     "bv2_attach_weights")
-        self._drop_graphs()
         self._blob = dev_blob
 
     def repack(self) -> None:
@@ -161,6 +191,9 @@ class SynthesizerTrn(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("bert_vits2_amd.SynthesizerTrn.infer needs the model on a GPU (model.to('cuda')); "
                                "there is no CPU fallback")
+        if not self._params_loaded:
+            raise RuntimeError("no weights: this SynthesizerTrn never saw load_state_dict() / load_checkpoint() (a rank that only "
+                               "received the packed blob must attach_blob() again after .to(); it has no parameters to repack)")
         with torch.cuda.device(dev):
             self.attach_blob(self.pack_host_blob().to(dev))
 
@@ -310,11 +343,13 @@ class SynthesizerTrn(nn.Module):
     def decode(self, enc: Dict[str, torch.Tensor], noise_z: torch.Tensor, Ty: int, noise_scale=0.667, max_len=None,
                want_attn: bool = True, exact_lengths: bool = False) -> Dict[str, torch.Tensor]:
         """Phase B = reference models.py:1058-1073.  ``noise_z`` [B,inter,>=Ty] replaces randn_like at :1071."""
+        if self._blob is None:
+            self.repack()
         dev = self.device
         hp = self.hp
         B, _, T = enc["x"].shape
         Ci = hp.inter_channels
-        assert noise_z.is_cuda and noise_z.dtype == torch.float32 and noise_z.stride(2) == 1 and noise_z.shape[2] >= Ty
+        assert noise_z.is_cuda and noise_z.dtype == torch.float32 and noise_z.shape[2] >= Ty and noise_z.shape[1] == Ci
         L_dec = Ty if (max_len is None or max_len <= 0 or max_len >= Ty) else int(max_len)
         S = L_dec * hp.total_upsample
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -330,7 +365,8 @@ class SynthesizerTrn(nn.Module):
                 sin["noise_z"] = torch.empty(B, Ci, Ty, dtype=torch.float32, device=dev)
                 sout = mk_out()
                 din = L.DecodeIn(B, T, int(Ty), int(L_dec), *[_ptr(sin[k]) for k in ikeys], _ptr(sin["noise_z"]),
-                                 sin["noise_z"].stride(0), sin["noise_z"].stride(1), float(noise_scale), int(exact_lengths))
+                                 sin["noise_z"].stride(0), sin["noise_z"].stride(1), sin["noise_z"].stride(2),
+                                 float(noise_scale), int(exact_lengths))
                 dout = L.DecodeOut(*[_ptr(sout[k]) for k in okeys])
                 with torch.cuda.device(dev):
                     g = self._capture(self._lib.bv2_graph_capture_decode, C.byref(din), C.byref(dout),
@@ -348,7 +384,7 @@ class SynthesizerTrn(nn.Module):
         out = mk_out()
         din = L.DecodeIn(B, T, int(Ty), int(L_dec), _ptr(enc["m_p"]), _ptr(enc["logs_p"]), _ptr(enc["x_mask"]),
                          _ptr(enc["w_ceil"]), _ptr(enc["y_lengths"]), _ptr(enc["g"]), _ptr(noise_z),
-                         noise_z.stride(0), noise_z.stride(1), float(noise_scale), int(exact_lengths))
+                         noise_z.stride(0), noise_z.stride(1), noise_z.stride(2), float(noise_scale), int(exact_lengths))
         dout = L.DecodeOut(*[_ptr(out[k]) for k in okeys])
         ws = self._workspace(B, T, Ty)
         with torch.cuda.device(dev):
@@ -372,7 +408,7 @@ class SynthesizerTrn(nn.Module):
         dev = self.device
         B, T = x.shape
         if noise_w is None:
-            noise_w = torch.randn(B, 2, T, device=dev, dtype=torch.float32)          # models.py:248-251
+            noise_w = draw_noise_w(B, T, dev)
         enc = self.encode_durations(x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_w,
                                     noise_scale_w=noise_scale_w, sdp_ratio=sdp_ratio, length_scale=length_scale)
         if w_ceil is not None:
@@ -381,49 +417,123 @@ class SynthesizerTrn(nn.Module):
             enc["y_lengths"] = torch.clamp_min(wc.sum(1), 1).long()
         Ty = int(enc["y_lengths"].max().item())        # the reference's one host sync (commons.py:120-122)
         if noise_z is None:
-            noise_z = torch.randn(B, self.hp.inter_channels, Ty, device=dev, dtype=torch.float32)   # models.py:1071
+            noise_z = draw_noise_z(B, self.hp.inter_channels, Ty, dev)
         else:
             noise_z = noise_z.to(dev, torch.float32)
-            if noise_z.stride(2) != 1:
-                noise_z = noise_z.contiguous()
         dec = self.decode(enc, noise_z, Ty, noise_scale=noise_scale, max_len=max_len, want_attn=want_attn,
                           exact_lengths=exact_lengths)
         self.last_encode = enc
         return dec["o"], dec["attn"], dec["y_mask"], (dec["z"], dec["z_p"], dec["m_p"], dec["logs_p"])
 
     # ------------------------------------------------------------------ single stages (reference ONNX seams)
+    # onnx_modules/V230/models_onnx.py:896-1063 cuts infer() into emb_g / enc_p / sdp / dp / flow / dec; the six methods below
+    # are those graphs (same tensor names, see onnx_api.StageSession for the consumer-side glue).
+    def _stage_call(self, fn, B, T_or_Ty, *ptr_args, what):
+        ws = self._workspace(B, max(int(T_or_Ty), 1), max(int(T_or_Ty), 1))
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(fn(self._handle, stream, *ptr_args, C.c_void_p(ws.data_ptr()), ws.numel()), what)
+
+    def _f32(self, t, *shape):
+        t = t.to(self.device, torch.float32)
+        return (t.reshape(*shape) if shape else t).contiguous()
+
+    def _i64(self, t):
+        return t.to(self.device, torch.int64).contiguous()
+
     @torch.no_grad()
-    def stage_flow(self, z_p: torch.Tensor, y_lengths: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    def stage_emb_g(self, sid: torch.Tensor) -> torch.Tensor:
+        """``emb_g.run({"sid"})`` -> g [B, gin]."""
+        if self._blob is None:
+            self.repack()
+        sid = self._i64(sid).reshape(-1)
+        B = sid.shape[0]
+        g = torch.empty(B, self.hp.gin_channels, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self._lib.bv2_stage_emb_g(self._handle, stream, B, _ptr(sid), _ptr(g)), "bv2_stage_emb_g")
+        return g
+
+    @torch.no_grad()
+    def stage_enc_p(self, x, t, language, bert_0, bert_1, bert_2, g, x_lengths=None):
+        """``enc.run({"x","t","language","bert_0","bert_1","bert_2","g"})`` -> (xout, m_p, logs_p, x_mask [B,1,T])."""
+        if self._blob is None:
+            self.repack()
+        x, t, language = self._i64(x), self._i64(t), self._i64(language)
+        B, T = x.shape
+        b0, b1, b2 = (self._f32(v, B, H.BERT_DIM, T) for v in (bert_0, bert_1, bert_2))
+        g = self._f32(g, B, -1)
+        xl = None if x_lengths is None else self._i64(x_lengths)
+        hp, dev = self.hp, self.device
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        xout, m_p, logs_p, x_mask = e(B, hp.hidden_channels, T), e(B, hp.inter_channels, T), e(B, hp.inter_channels, T), e(B, 1, T)
+        self._stage_call(self._lib.bv2_stage_enc_p, B, T, B, T, _ptr(x), _ptr(t), _ptr(language), _ptr(b0), _ptr(b1), _ptr(b2),
+                         _ptr(g), _ptr(xl), _ptr(xout), _ptr(m_p), _ptr(logs_p), _ptr(x_mask), what="bv2_stage_enc_p")
+        return xout, m_p, logs_p, x_mask
+
+    @torch.no_grad()
+    def stage_sdp(self, x, x_mask, zin, g) -> torch.Tensor:
+        """``sdp.run({"x","x_mask","zin","g"})`` -> logw [B,1,T]; ``zin`` [B,2,T] is the already scaled noise."""
+        if self._blob is None:
+            self.repack()
+        B, _, T = x.shape
+        x, x_mask, zin, g = self._f32(x), self._f32(x_mask, B, T), self._f32(zin, B, 2, T), self._f32(g, B, -1)
+        logw = torch.empty(B, 1, T, dtype=torch.float32, device=self.device)
+        self._stage_call(self._lib.bv2_stage_sdp, B, T, B, T, _ptr(x), _ptr(x_mask), _ptr(zin), _ptr(g), _ptr(logw),
+                         what="bv2_stage_sdp")
+        return logw
+
+    @torch.no_grad()
+    def stage_dp(self, x, x_mask, g) -> torch.Tensor:
+        """``dp.run({"x","x_mask","g"})`` -> logw [B,1,T]."""
+        if self._blob is None:
+            self.repack()
+        B, _, T = x.shape
+        x, x_mask, g = self._f32(x), self._f32(x_mask, B, T), self._f32(g, B, -1)
+        logw = torch.empty(B, 1, T, dtype=torch.float32, device=self.device)
+        self._stage_call(self._lib.bv2_stage_dp, B, T, B, T, _ptr(x), _ptr(x_mask), _ptr(g), _ptr(logw), what="bv2_stage_dp")
+        return logw
+
+    @torch.no_grad()
+    def stage_flow(self, z_p: torch.Tensor, y_lengths: Optional[torch.Tensor], g: torch.Tensor,
+                   y_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``flow.run({"z_p","y_mask","g"})`` -> z.  The frame mask is given as ``y_lengths`` [B] or as ``y_mask`` [B,1,Ty]."""
         if self._blob is None:
             self.repack()
         B, Ci, Ty = z_p.shape
-        z_p = z_p.to(self.device, torch.float32).contiguous()
+        z_p = self._f32(z_p)
         z = torch.empty_like(z_p)
-        yl = y_lengths.to(self.device, torch.int64).contiguous()
-        g = g.to(self.device, torch.float32).reshape(B, -1).contiguous()
-        ws = self._workspace(B, 1, Ty)
-        with torch.cuda.device(self.device):
-            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self._check(self._lib.bv2_stage_flow(self._handle, stream, B, Ty, _ptr(z_p), _ptr(yl), _ptr(g), _ptr(z),
-                                                 C.c_void_p(ws.data_ptr()), ws.numel()), "bv2_stage_flow")
+        yl = None if y_lengths is None else self._i64(y_lengths)
+        ym = None if y_mask is None else self._f32(y_mask, B, Ty)
+        if (yl is None) == (ym is None):
+            raise ValueError("stage_flow needs exactly one of y_lengths / y_mask")
+        g = self._f32(g, B, -1)
+        self._stage_call(self._lib.bv2_stage_flow, B, Ty, B, Ty, _ptr(z_p), _ptr(yl), _ptr(ym), _ptr(g), _ptr(z),
+                         what="bv2_stage_flow")
         return z
 
     @torch.no_grad()
-    def stage_generator(self, z: torch.Tensor, y_lengths: torch.Tensor, g: torch.Tensor, L_frames: Optional[int] = None):
+    def stage_generator(self, z: torch.Tensor, y_lengths: Optional[torch.Tensor], g: torch.Tensor,
+                        L_frames: Optional[int] = None):
+        """``dec.run({"z_in","g"})`` -> o [B,1,L*hop].  With ``y_lengths`` the input is (z*y_mask)[:, :, :L] (models.py:1073);
+        with ``None`` z is taken as it is (the exported graph)."""
         if self._blob is None:
             self.repack()
         B, Ci, Ty = z.shape
         Lf = Ty if L_frames is None else int(L_frames)
-        z = z.to(self.device, torch.float32).contiguous()
-        yl = y_lengths.to(self.device, torch.int64).contiguous()
-        g = g.to(self.device, torch.float32).reshape(B, -1).contiguous()
+        z = self._f32(z)
+        yl = None if y_lengths is None else self._i64(y_lengths)
+        g = self._f32(g, B, -1)
         o = torch.empty(B, 1, Lf * self.hp.total_upsample, dtype=torch.float32, device=self.device)
-        ws = self._workspace(B, 1, Ty)
-        with torch.cuda.device(self.device):
-            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self._check(self._lib.bv2_stage_generator(self._handle, stream, B, Ty, Lf, _ptr(z), _ptr(yl), _ptr(g), _ptr(o),
-                                                      C.c_void_p(ws.data_ptr()), ws.numel()), "bv2_stage_generator")
+        self._stage_call(self._lib.bv2_stage_generator, B, Ty, B, Ty, Lf, _ptr(z), _ptr(yl), _ptr(g), _ptr(o),
+                         what="bv2_stage_generator")
         return o
+
+    def set_option(self, key: str, value: int) -> None:
+        """Kernel-selection switches of ``bv2_set_option`` ("fused_resblock", "fused_dds"); tests only."""
+        self._ensure_handle()
+        self._check(self._lib.bv2_set_option(self._handle, key.encode(), int(value)), "bv2_set_option")
+        self._drop_graphs()
 
     # ------------------------------------------------------------------ measurement
     def profile(self, on=1):

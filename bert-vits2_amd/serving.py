@@ -123,14 +123,17 @@ def synthesize(model, utts: Sequence[Utterance], *, sdp_ratio=0.5, noise_scale=0
                                           batch["bert"], batch["ja_bert"], batch["en_bert"], sdp_ratio=sdp_ratio,
                                           noise_scale=noise_scale, noise_scale_w=noise_scale_w, length_scale=length_scale,
                                           want_attn=False, exact_lengths=True, **kw)
-        y_len = y_mask.sum((1, 2)).long()
+        y_len = model.last_encode["y_lengths"]             # int64 [B], already on the device (phase A output)
         audio = pcm16(model, o, y_len) if as_pcm16 else o[:, 0]
-        # one async D2H per bucket into pinned memory; the next bucket's kernels overlap the copy
+        # one async D2H per bucket into pinned memory (audio AND lengths): nothing here blocks the host, so the next bucket's
+        # kernels are enqueued while this copy runs; the drain loop below waits on the bucket's event
         host = torch.empty(audio.shape, dtype=audio.dtype, pin_memory=True)
         host.copy_(audio, non_blocking=True)
+        host_len = torch.empty(y_len.shape, dtype=torch.int64, pin_memory=True)
+        host_len.copy_(y_len, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        pending.append((idx, host, y_len.cpu(), ev))
+        pending.append((idx, host, host_len, ev))
     for idx, host, y_len, ev in pending:
         ev.synchronize()
         for r, i in enumerate(idx):

@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define BV2_ABI_VERSION 2   /* 2: bv2_decode_in.exact_lengths, fp16 / tap-major weight streams in the blob */
+#define BV2_ABI_VERSION 3   /* 3: bv2_decode_in.nz_tstride, the six ONNX-seam stage calls, bv2_detach_weights,
+                               pack-layout version in the blob header */
+#define BV2_PACK_LAYOUT 7   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
+                               a blob cached on disk by an older packer is rejected by bv2_attach_weights */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
 #define BV2_MAX_RESBLOCK_DILATIONS 4
@@ -79,6 +82,9 @@ int bv2_pack_weights(bv2_handle* h, void* host_blob, int64_t bytes);
 /* Point the handle at a packed blob resident in DEVICE memory (caller-owned; e.g. uploaded by rank 0 and broadcast
  * to the other GPUs with RCCL).  Verifies the blob header against this handle's config. */
 int bv2_attach_weights(bv2_handle* h, const void* dev_blob, int64_t bytes);
+/* Forget the attached blob (the caller is about to free or move it): every compute entry point fails with -8 until the
+ * next bv2_attach_weights.  Captured graphs that baked the old address in must be destroyed by the caller. */
+int bv2_detach_weights(bv2_handle* h);
 
 /* ---- precision (BASELINE config 3: "bf16 weights/activations, fp32 accumulate") ------------------------------- */
 /* Arithmetic of the HiFi-GAN Generator (dec, reference models.py:538-557 — 90 % of the path's FLOPs): BV2_F32 (default;
@@ -143,8 +149,10 @@ typedef struct bv2_decode_in {
   const float* w_ceil;       /* [B,T]  (the caller may substitute durations, as train_ms.evaluate-style tooling does) */
   const int64_t* y_lengths;  /* [B] */
   const float* g;            /* [B,gin] */
-  const float* noise_z;      /* N(0,1) for models.py:1071; element (b,c,j) at noise_z[b*nz_bstride + c*nz_cstride + j] */
-  int64_t nz_bstride, nz_cstride;
+  const float* noise_z;      /* N(0,1) for models.py:1071; element (b,c,j) at noise_z[b*nz_bstride + c*nz_cstride + j*nz_tstride].
+                                The reference draws it with randn_like on a TRANSPOSED view (strides (C*Ty, 1, C)); passing the
+                                strides lets the caller hand that tensor over as it is (the RNG contract). */
+  int64_t nz_bstride, nz_cstride, nz_tstride;   /* nz_tstride <= 0 means 1 */
   float noise_scale;
   int32_t exact_lengths;     /* 0: the reference's batch semantics — dec is unmasked, so in a padded batch the activations
                                 past an utterance's end bleed into its last ~40 ms (models.py:1073 masks only z).
@@ -167,12 +175,33 @@ typedef struct bv2_decode_out {   /* all DEVICE, caller-allocated; any pointer e
 int bv2_decode(bv2_handle* h, bv2_stream stream, const bv2_decode_in* in, const bv2_decode_out* out,
                void* workspace, int64_t workspace_bytes);
 
-/* ---- single stages (the reference's ONNX seams; used by the parity tests and by stage-level consumers) ------- */
-/* flow(z_p, y_mask, g, reverse=True), models.py:1072.  z_p is not modified; z receives the result. */
+/* ---- single stages: the reference's own ONNX cut of infer() --------------------------------------------------------
+ * onnx_modules/V230/models_onnx.py:896-1063 exports six graphs (emb_g, enc_p, sdp, dp, flow, dec) and
+ * onnx_modules/V230_OnnxInference/__init__.py:44-126 runs them with the numpy glue in between.  The six calls below take
+ * the tensors of those graphs under the same names (comments give "onnx name"), so a MoeVS-style consumer can swap the
+ * runtime stage by stage; the parity tests tap them against the oracle.  All fp32 [B,C,T] / int64, DEVICE, caller-owned. */
+/* emb_g.run({"sid"}) -> g [B,gin]   (models.py:1046; the consumer unsqueezes to [B,gin,1]) */
+int bv2_stage_emb_g(bv2_handle* h, bv2_stream stream, int B, const int64_t* sid, float* g);
+/* enc.run({"x","t","language","bert_0","bert_1","bert_2","g"}) -> xout, m_p, logs_p, x_mask   (TextEncoder, models.py:377-400).
+ * x_lengths may be NULL: every utterance is T symbols long, as in the exported graph (which has no length input). */
+int bv2_stage_enc_p(bv2_handle* h, bv2_stream stream, int B, int T, const int64_t* x, const int64_t* t, const int64_t* language,
+                    const float* bert_0, const float* bert_1, const float* bert_2, const float* g, const int64_t* x_lengths,
+                    float* xout, float* m_p, float* logs_p, float* x_mask, void* workspace, int64_t workspace_bytes);
+/* sdp.run({"x","x_mask","zin","g"}) -> logw [B,1,T]: StochasticDurationPredictor reverse (models.py:197-204, 245-256) where
+ * zin [B,2,T] is the ALREADY SCALED noise (randn * noise_scale_w), exactly as the exported graph takes it. */
+int bv2_stage_sdp(bv2_handle* h, bv2_stream stream, int B, int T, const float* x, const float* x_mask, const float* zin,
+                  const float* g, float* logw, void* workspace, int64_t workspace_bytes);
+/* dp.run({"x","x_mask","g"}) -> logw [B,1,T]: DurationPredictor (models.py:285-299) */
+int bv2_stage_dp(bv2_handle* h, bv2_stream stream, int B, int T, const float* x, const float* x_mask, const float* g,
+                 float* logw, void* workspace, int64_t workspace_bytes);
+/* flow.run({"z_p","y_mask","g"}) -> z: flow(z_p, y_mask, g, reverse=True), models.py:1072.  The frame mask comes either as
+ * y_lengths [B] (int64) or as the graph's y_mask [B,1,Ty] (fp32 0/1) — exactly one of the two is non-NULL.  z_p is not
+ * modified; z receives the result. */
 int bv2_stage_flow(bv2_handle* h, bv2_stream stream, int B, int Ty, const float* z_p, const int64_t* y_lengths,
-                   const float* g, float* z, void* workspace, int64_t workspace_bytes);
-/* dec((z*y_mask)[:, :, :L], g), models.py:1073 / Generator.forward models.py:538-557.  o is [B,1,L*prod(rates)];
- * z has row stride Ty. */
+                   const float* y_mask, const float* g, float* z, void* workspace, int64_t workspace_bytes);
+/* dec.run({"z_in","g"}) -> o: Generator.forward models.py:538-557 on z_in[:, :, :L] (z_in has row stride Ty); with y_lengths
+ * non-NULL the input is (z*y_mask)[:, :, :L] as at models.py:1073, with NULL it is taken as it is (the exported graph).
+ * o is [B,1,L*prod(rates)]. */
 int bv2_stage_generator(bv2_handle* h, bv2_stream stream, int B, int Ty, int L, const float* z, const int64_t* y_lengths,
                         const float* g, float* o, void* workspace, int64_t workspace_bytes);
 
@@ -180,7 +209,7 @@ int bv2_stage_generator(bv2_handle* h, bv2_stream stream, int B, int Ty, int L, 
 /* Outputs must be sized for Ty_cap frames; returns -3 (and sets *Ty_out) if the realised Ty exceeds Ty_cap.
  * Row strides of the [.,.,Ty] outputs are the realised Ty (*Ty_out), tensors are written densely. */
 int bv2_infer(bv2_handle* h, bv2_stream stream, const bv2_encode_in* in, const bv2_encode_out* enc_out,
-              const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, float noise_scale, int32_t max_len,
+              const float* noise_z, int64_t nz_bstride, int64_t nz_cstride, int64_t nz_tstride, float noise_scale, int32_t max_len,
               int32_t Ty_cap, const bv2_decode_out* dec_out, int32_t* Ty_out, void* workspace, int64_t workspace_bytes);
 
 /* ---- 16-bit PCM (serving glue; replaces the host-side gradio convert_to_16_bit_wav the reference's callers run after
@@ -209,6 +238,12 @@ int bv2_graph_num_nodes(const bv2_graph* graph);
 void bv2_graph_destroy(bv2_graph* graph);
 
 /* ---- debugging / measurement ------------------------------------------------------------------------------ */
+/* Kernel-selection switches, for tests that hold the fused kernels to the layer-wise ones (default 1 = fused):
+ *   "fused_resblock"  the narrow Generator stages as whole-ResBlock / fused-pair kernels (0: one conv per launch)
+ *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
+ * Captured graphs keep whatever was selected when they were recorded. */
+int bv2_set_option(bv2_handle* h, const char* key, int value);
+
 /* Ask the executor to copy a named intermediate (e.g. "dec.ups.0", "dec.stage.2", "flow.3.h", "enc.layer.1")
  * into dev_dst (capacity in floats) the next time it is produced.  name==NULL clears all taps. */
 int bv2_set_tap(bv2_handle* h, const char* name, float* dev_dst, int64_t capacity_floats);

@@ -68,6 +68,23 @@ int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode,
                        const float* in_mask, const float* gamma, const float* beta, int post_gelu, const float* res,
                        const float* vec, const float* mask, float* out, int B, int C, int T, int nslab, int64_t slab_stride);
 
+/* one fused DDSConv layer (kernels/dds_fused.hip) on x [B][C][T] -> out [B][C][T] (out != x): depthwise k=3 conv (dww_host [C][3],
+ * dwb_host [C], dilation dil) + LN1 (g1/b1) + GELU + 1x1 conv (w_host [C][C], bias_host [C]) + LN2 (g2/b2) + GELU + residual,
+ * times mask when last_mask.  Optional ConvFlow.pre input transform: pre_w/pre_b HOST [C] with z [B][2][T], z_src and g [B][C][T]
+ * (x is ignored then).  Optional post projection post_w_host [post_cout][C] / post_b_host [post_cout]: with post_out
+ * [B][post_cout][T] it is written as (W y + b) * mask; with post_out NULL and zio [B][2][T] the 29 rows are the spline
+ * parameters applied to zio (z_src / z_dst).  Host arrays are packed into wpack_dev (>= bv2_test_dds_pack_floats(C) floats). */
+int64_t bv2_test_dds_pack_floats(int C);
+int bv2_test_dds_layer(void* stream, const float* x, const float* pre_w_host, const float* pre_b_host, const float* z, int z_src,
+                       const float* g, const float* mask, const float* dww_host, const float* dwb_host, const float* g1_host,
+                       const float* b1_host, const float* g2_host, const float* b2_host, const float* w_host,
+                       const float* bias_host, float* out, int dil, int last_mask, const float* post_w_host,
+                       const float* post_b_host, int post_cout, float* post_out, float* zio, int z_dst, float* wpack_dev,
+                       int B, int C, int T);
+
+/* tuning experiments (tools/kbench.py): force the split-K wave count / C_in chunk / tile-count target of the fp32 conv; 0 = default */
+void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target);
+
 /* inverse RQ spline on channel `dst` of z [B][2][T] with params [B][prow][T] (DEVICE) */
 int bv2_test_spline(void* stream, float* z, int src, int dst, const float* params, int prow, const float* mask,
                     float sqrt_fc, float tail, int B, int T);

@@ -26,7 +26,19 @@ CASES = {
     "wn_b1_t16": dict(hp=dict(use_transformer_flow=False), lengths=[16], languages=[0], sids=[11], seed=0,
                       kw=dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=1.0, length_scale=1.2)),
     "short_b3": dict(hp={}, lengths=[3, 9, 1], languages=[0, 1, 2], sids=[1, 2, 3], seed=0, kw=INFER_KW),
+    # padded T < window+1 = 5: the reference's relative-position helpers SLICE the embedding table instead of padding it
+    # (attentions.py:345-357); T = 1 is the degenerate single-blank utterance
+    "t1_b1": dict(hp={}, lengths=[1], languages=[0], sids=[7], seed=0, kw=INFER_KW),
+    "t3_b1": dict(hp={}, lengths=[3], languages=[1], sids=[8], seed=0, kw=INFER_KW),
+    "t4_b2": dict(hp={}, lengths=[4, 2], languages=[2, 0], sids=[9, 10], seed=0, kw=INFER_KW),
+    # T >= 64 (several 32-column tiles per row in every kernel, T_y of a few hundred frames); also carries the reference's
+    # own reduced-precision runs (dec under bf16 autocast, flow under fp16 autocast) — see AUTOCAST_KEYS
+    "mid_b2_t72": dict(hp={}, lengths=[72, 64], languages=[0, 2], sids=[3, 421], seed=0, kw=INFER_KW, autocast=True),
+    "wn_b2_t40": dict(hp=dict(use_transformer_flow=False), lengths=[40, 33], languages=[0, 1], sids=[11, 12], seed=0,
+                      kw=INFER_KW),
 }
+# cases whose fixture also stores the reference's autocast runs
+AUTOCAST_CASES = [n for n, c in CASES.items() if c.get("autocast")] + ["mix_b2_ragged"]
 
 T_Y_CAP = 1024     # noise_z is generated for this many frames and sliced to the realised T_y
 
@@ -50,6 +62,14 @@ CHECKSUM_KEYS = ["enc_p.emb.weight", "dec.resblocks.4.convs1.1.weight_v", "flow.
 def weight_checksums(sd):
     return {k: float(sd[k].double().sum()) for k in CHECKSUM_KEYS if k in sd}
 
+
+# reference run with `dec` under torch.autocast("cpu", bfloat16) on the fp32 z; `flow` under torch.autocast("cpu", float16)
+# on the fp32 z_p (and the fp32 / bf16-autocast dec on that z): what BASELINE configs 3 / 5 mean on the reference side
+AUTOCAST_KEYS = ["o_bf16dec", "z_f16flow", "o_f16flow", "o_f16flow_bf16dec"]
+
+# un-injected run: torch.manual_seed(SEEDED_SEED); net.infer(...) — pins the RNG contract of SURVEY.md §8(b)
+SEEDED_CASE = "mix_b2_ragged"
+SEEDED_SEED = 20240923
 
 GOLDEN_KEYS = ["o", "z", "z_p", "m_p", "logs_p", "enc_x", "enc_m", "enc_logs", "logw", "logw_sdp", "logw_dp", "w_ceil",
                "y_mask", "attn"]

@@ -25,12 +25,15 @@ from oracle import cases, ref_import  # noqa: E402
 
 
 def main():
+    only = set(sys.argv[1:])                     # optional: regenerate only the named cases
     torch.set_num_threads(1)
     torch.use_deterministic_algorithms(True)
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     nets = {}
     for name in cases.CASES:
+        if only and name not in only:
+            continue
         hp, seed, batch, noise_w, noise_z, kw = cases.build_case(name)
         key = (hp.use_transformer_flow, seed)
         if key not in nets:
@@ -40,10 +43,21 @@ def main():
         ref = ref_import.reference_infer(net, batch, noise_w, noise_z, **kw)
         arrays = {k: ref[k].detach().float().numpy() for k in cases.GOLDEN_KEYS}
         arrays["y_lengths"] = ref["y_mask"].sum([1, 2]).long().numpy()
+        if name in cases.AUTOCAST_CASES:
+            ac = ref_import.reference_autocast_runs(net, ref, batch["sid"])
+            arrays.update({k: ac[k].detach().float().numpy() for k in cases.AUTOCAST_KEYS})
+        if name == cases.SEEDED_CASE:
+            sr = ref_import.reference_seeded_infer(net, batch, cases.SEEDED_SEED, **kw)
+            sa = {k: v.detach().numpy() for k, v in sr.items()}
+            np.savez_compressed(os.path.join(out_dir, "seeded_" + name + ".npz"),
+                                meta=json.dumps(dict(case=name, seed=cases.SEEDED_SEED, torch=torch.__version__)), **sa)
+            print("seeded", name, {k: v.shape for k, v in sa.items()})
         meta = dict(case=name, torch=torch.__version__, checksums=cases.weight_checksums(sd),
                     o_rms=float(ref["o"].pow(2).mean().sqrt()), T_y=int(ref["y_mask"].shape[2]))
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=json.dumps(meta), **arrays)
         print(name, meta)
+    if only:
+        return
     # the reference's own state_dict schema (inference sub-networks), to pin bert_vits2_amd/schema.py
     hp_t, _, *_ = cases.build_case("zh_b1_t24")
     hp_w, _, *_ = cases.build_case("wn_b1_t16")

@@ -135,3 +135,54 @@ def reference_infer(net, batch, noise_w, noise_z, **kw):
     w_ceil = torch.ceil(torch.exp(logw) * xm * kw.get("length_scale", 1))
     return dict(o=o, attn=attn, y_mask=y_mask, z=z, z_p=z_p, m_p=m_p, logs_p=logs_p, enc_x=ex, enc_m=em,
                 enc_logs=el, x_mask=xm, logw=logw, logw_sdp=taps["sdp"], logw_dp=taps["dp"], w_ceil=w_ceil)
+
+
+@torch.no_grad()
+def reference_autocast_runs(net, ref, sid):
+    """The reference's own reduced-precision behaviour, on the intermediate tensors of an fp32 run ``ref``
+    (= reference_infer output): ``dec`` under ``torch.autocast("cpu", bfloat16)`` fed the fp32 ``z`` (BASELINE config 3's
+    reference-side meaning), ``flow`` under ``torch.autocast("cpu", float16)`` fed the fp32 ``z_p`` (config 5), and the
+    two decoders on that fp16-flow ``z``.  The reference source is not modified: autocast is entered around calls of its
+    own sub-modules, exactly as a user would wrap them."""
+    g = net.emb_g(sid).unsqueeze(-1)
+    zin = ref["z"] * ref["y_mask"]
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o_bf16dec = net.dec(zin, g=g).float()
+    with torch.autocast("cpu", dtype=torch.float16):
+        z_f16 = net.flow(ref["z_p"], ref["y_mask"], g=g, reverse=True).float()
+    o_f16flow = net.dec(z_f16 * ref["y_mask"], g=g)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o_both = net.dec(z_f16 * ref["y_mask"], g=g).float()
+    return dict(o_bf16dec=o_bf16dec, z_f16flow=z_f16, o_f16flow=o_f16flow, o_f16flow_bf16dec=o_both)
+
+
+@torch.no_grad()
+def reference_seeded_infer(net, batch, seed, **kw):
+    """``torch.manual_seed(seed); net.infer(...)`` with NO injection: the reference draws its own noise from the global
+    CPU generator.  The two draws are recorded on the way (the real ``torch.randn`` / ``torch.randn_like`` are called and
+    their results kept), so a fixture can pin both the noise and the outputs of a seeded reference run (the RNG contract
+    of SURVEY.md §8b)."""
+    real_randn, real_like = torch.randn, torch.randn_like
+    rec = {}
+
+    def rec_randn(*a, **k):
+        t = real_randn(*a, **k)
+        rec.setdefault("noise_w", t.clone())
+        return t
+
+    def rec_like(t, **k):
+        r = real_like(t, **k)
+        rec.setdefault("noise_z", r.clone())
+        rec.setdefault("noise_z_strides", tuple(t.stride()))
+        return r
+
+    torch.manual_seed(seed)
+    torch.randn, torch.randn_like = rec_randn, rec_like
+    try:
+        o, attn, y_mask, (z, z_p, m_p, logs_p) = net.infer(
+            batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"],
+            batch["bert"], batch["ja_bert"], batch["en_bert"], **kw)
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+    return dict(o=o, attn=attn, y_mask=y_mask, z=z, z_p=z_p, noise_w=rec["noise_w"], noise_z=rec["noise_z"].contiguous(),
+                noise_z_strides=torch.tensor(rec["noise_z_strides"]))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libbv2.so does not export {n}"
     assert sorted(s[0] for s in L.SYMBOLS) == _declared("bv2.h"), "lib.py binding list drifted from include/bv2.h"
-    assert lib.bv2_abi_version() == 2
+    assert lib.bv2_abi_version() == 3
 
 
 def test_create_rejects_bad_config_with_message():

@@ -62,13 +62,13 @@ def main():
         for name, (cin, cout, k, L) in dict(ffn1_flow=(192, 768, 5, 384), ffn2_flow=(768, 192, 5, 384), qkv_flow=(192, 594, 1, 384),
                                              ffn1_enc=(192, 768, 3, 128), ffn2_enc=(768, 192, 3, 128), conv_pre=(192, 512, 7, 384)).items():
             for waves in (4, 8, 16):
-                os.environ["BV2_SPLITK_WAVES"] = str(waves)
+                lib.bv2_test_set_tuning(waves, 0, 0)
                 row = []
                 for ks in (1, 2, 4, 8):
                     r = bench_conv(lib, 1, cin, cout, k, 1, L, 6, ks)
                     row.append("   n/a      " if r is None else f"{r[0]:7.2f}us {r[1]:5.1f}TF")
                 print(f"{name:10s} waves={waves:2d}  ks=1,2,4,8: " + " | ".join(row))
-            os.environ.pop("BV2_SPLITK_WAVES", None)
+            lib.bv2_test_set_tuning(0, 0, 0)
             for tile, tn in ((4, "32x128"), (3, "64x64"), (2, "64x128")):
                 r = bench_conv(lib, 1, cin, cout, k, 1, L, tile)
                 print(f"{name:10s} tiled {tn:8s}: " + ("n/a" if r is None else f"{r[0]:7.2f}us {r[1]:5.1f}TF"))
