@@ -4,16 +4,26 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one full ``infer()`` (phase A + the reference's one host sync + phase B) over one batch of synthetic
-utterances already resident in HBM.  N=1 workload = BASELINE config 2: B=1, T=128 symbols, fp32, durations pinned to
-3 frames/symbol (T_y=384, 196 608 samples = 4.458 s of 44.1 kHz audio).  N>1: utterances are independent units, so each
-rank runs the same per-GPU workload on its own utterance (weak scaling, no data-path collective); the only collective is
-the one-time RCCL broadcast of the packed weight blob from rank 0, timed separately.
-Prints ONE JSON line on rank 0.
+A "step" is one full ``infer()`` (phase A + the reference's one host sync + phase B) over one batch of synthetic utterances already
+resident in HBM.  Workloads (BASELINE.json ``configs``):
+
+  2  B=1, T=128 symbols, fp32, durations pinned to 3 frames/symbol (T_y=384, 196 608 samples = 4.458 s) — the config the metric is
+     quoted on: the N=1 default, and ``value`` of the line
+  3  B=32 x T=128, bf16 Generator + fp16 flow convolutions, hipGraph replay
+  4  per GPU B=32 utterances of uniform [96,128] symbols, ZH/JA/EN round-robin, random speakers, precisions of config 3 — the N>1
+     default (BASELINE: "8xMI355X utterance-sharded throughput"): utterances are independent, each rank runs its own shard, NO
+     data-path collective; the only collective is the one-time RCCL broadcast of the packed weight blob, timed separately
+  5  B=8 x T=512 (T_y=1536), bf16 Generator + fp16 flow
+
+At N=1 the line also carries ``secondary``: configs 3, 4 (one GPU's share) and 5 measured in the same process right after the primary,
+each with its own roofline block, so the driver-run line documents every BASELINE configuration.  Nothing is profiled inside a timed
+region: the per-kernel HIP-event pass (roofline) is a separate eager pass after it.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -30,9 +40,16 @@ from bert_vits2_amd import hparams as H, models, sharding, synth  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix = fp32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA
 PEAK_HBM_GBPS = 8000.0             # same guide: HBM3E
-CONFIGS = {2: dict(batch=1, symbols=128, dtype="f32", flow="f32"), 3: dict(batch=32, symbols=128, dtype="bf16", flow="f16", graph=1),
-           5: dict(batch=8, symbols=512, dtype="bf16", flow="f16")}
-GEN_FLOP_PER_FRAME = 651.6e6       # Generator algorithmic FLOPs per latent frame
+CONFIGS = {
+    2: dict(batch=1, symbols=128, dtype="f32", flow="f32", graph=0, ragged=False),
+    3: dict(batch=32, symbols=128, dtype="bf16", flow="f16", graph=1, ragged=False),
+    4: dict(batch=32, symbols=128, dtype="bf16", flow="f16", graph=1, ragged=True),
+    5: dict(batch=8, symbols=512, dtype="bf16", flow="f16", graph=0, ragged=False),
+}
+KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
+KERNEL_SOURCES = {"conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
+                  "conv_cl_bf16": "gen_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "conv_f16": "enc_f16.hip",
+                  "attention": "attention.hip"}
 
 
 def parse():
@@ -40,18 +57,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
-                    help="BASELINE.json config: 2 = B=1 T=128 fp32 (the metric's config, default), 3 = B=32 T=128 bf16 Generator, "
-                         "5 = long-form B=8 T=512")
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5),
+                    help="BASELINE.json config (default: 2 at --gpus 1, 4 at --gpus N>1)")
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (overrides the config's)")
     ap.add_argument("--symbols", type=int, default=None, help="symbols per utterance (overrides the config's)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="Generator arithmetic (overrides the config's)")
     ap.add_argument("--flow-dtype", choices=("f32", "f16"), default=None, help="transformer-flow conv arithmetic (overrides the config's)")
-    ap.add_argument("--graph", type=int, default=None, choices=(0, 1),
-                    help="replay each phase as a captured hipGraph (default: the config's setting)")
+    ap.add_argument("--graph", type=int, default=None, choices=(0, 1), help="replay each phase as a captured hipGraph")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the secondary configs 3 / 4 / 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
-    ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel family")
+    ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
     return ap.parse_args()
 
 
@@ -80,47 +96,239 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(hp, sd, batch, kw, iters, budget_s=45.0):
-    """The oracle restatement (same aten CPU kernels and per-call weight_norm fold as the reference's infer) timed on
-    this box's host cores — a reported baseline, kind "port" (the Python reference cannot travel to the GPU box).
-    Bounded: stops after ``iters`` timed runs or ``budget_s`` seconds, whichever comes first."""
+def cpu_baseline(hp, sd, iters, budget_s=40.0):
+    """The oracle restatement (same aten CPU kernels and per-call weight_norm fold as the reference's infer) timed on this box's
+    host cores — a reported baseline, kind "port" (the Python reference cannot travel to the GPU box).  Config 2's utterance on all
+    usable threads (2 warm-ups, median of up to ``iters`` runs), plus config 1's shape (T=64) and a single-thread figure, all
+    inside ``budget_s`` seconds."""
     from oracle import bv2_oracle as O
     nthreads = min(usable_cores(), 64)
+    t_begin = time.perf_counter()
+
+    def timed(T, threads, warm, n):
+        torch.set_num_threads(threads)
+        batch = synth.synthetic_batch([T])
+        nw, nz = synth.synthetic_noise(1, T, 3 * T + 8, hp.inter_channels)
+        run = lambda: O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"], batch["bert"],
+                              batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, **KW)
+        for _ in range(warm):
+            out = run()
+        ts = []
+        while len(ts) < n and (not ts or time.perf_counter() - t_begin < budget_s):
+            t0 = time.perf_counter()
+            out = run()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        audio = float(out["y_lengths"].sum()) * hp.total_upsample / hp.sampling_rate
+        return audio / med, med, len(ts), audio, int(out["y_lengths"].max())
+
+    v2, med2, n2, audio2, ty2 = timed(128, nthreads, 2, iters)
+    log(f"cpu baseline: config 2 on {nthreads} threads {v2:.2f} audio-s/s ({med2 * 1e3:.1f} ms)")
+    v1, med1, n1, _, _ = timed(64, nthreads, 1, 3)
+    vs, meds, ns, _, _ = timed(128, 1, 0, 1) if time.perf_counter() - t_begin < budget_s - 8 else (None, None, 0, None, None)
     torch.set_num_threads(nthreads)
-    B, T = batch["x"].shape
-    nw, nz = synth.synthetic_noise(B, T, 3 * T + 8, hp.inter_channels)
-    run = lambda: O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"],
-                          batch["bert"], batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, **kw)
-    t_start = time.perf_counter()
-    out = run()                                     # warm-up
-    log(f"cpu baseline warm-up {time.perf_counter() - t_start:.2f}s on {nthreads} threads")
-    ts = []
-    while len(ts) < iters and (time.perf_counter() - t_start) < budget_s:
-        t0 = time.perf_counter()
-        out = run()
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    audio_s = float(out["y_lengths"].sum()) * hp.total_upsample / hp.sampling_rate
-    return dict(value=round(audio_s / med, 3), unit="audio-seconds/sec", cores=nthreads, kind="port",
-                sample=f"{len(ts)} timed runs (median) of the same workload (B={B}, T={T}, T_y={int(out['y_lengths'].max())}, "
-                       f"{audio_s:.3f} s audio) after 1 warm-up, torch CPU fp32", ms_per_step=round(med * 1e3, 2))
+    return dict(value=round(v2, 3), unit="audio-seconds/sec", cores=nthreads, kind="port",
+                sample=f"median of {n2} timed runs of config 2's utterance (B=1, T=128, T_y={ty2}, {audio2:.3f} s audio) after 2 warm-ups, "
+                       f"torch CPU fp32, oracle restatement",
+                ms_per_step=round(med2 * 1e3, 2),
+                config1_T64=dict(value=round(v1, 3), ms_per_step=round(med1 * 1e3, 2), runs=n1),
+                single_thread=None if vs is None else dict(value=round(vs, 3), ms_per_step=round(meds * 1e3, 2), cores=1, runs=ns))
+
+
+def file_digest(name):
+    with open(os.path.join(ROOT, "bert-vits2_amd", "csrc", "kernels", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes of tools/collect_traffic.py (rocprofv3 cannot wrap the timed run
-    itself without perturbing it, so the counters come from separate passes of this same command, committed under
-    profiles/): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE.  None when no such profile exists."""
-    import glob
+    """HBM bytes per launch of `kernel` from the PMC passes of tools/collect_traffic.py (rocprofv3 cannot wrap the timed run itself
+    without perturbing it, so the counters come from separate passes of this same command, committed under profiles/): FETCH_SIZE
+    x2 (gfx950 correction) + WRITE_SIZE.  Only a profile taken with the CURRENT source of that kernel counts: the traffic file
+    records the digest of every kernel source; a stale one is refused (returns a note instead of numbers)."""
+    src = next((v for k, v in KERNEL_SOURCES.items() if kernel.startswith(k)), None)
+    want = file_digest(src) if src else None
+    stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:
-            k = json.load(open(path))["kernels"].get(kernel)
-            if k:
-                return dict(bytes_per_launch=round(k["traffic_bytes"]), fetch_bytes=round(k["fetch_bytes"]),
-                            write_bytes=round(k["write_bytes"]), source=os.path.relpath(path, ROOT))
+            d = json.load(open(path))
+            k = d["kernels"].get(kernel)
+            if not k:
+                continue
+            have = (d.get("source_digests") or {}).get(src)
+            if want is None or have != want:
+                stale = stale or os.path.relpath(path, ROOT)
+                continue
+            return dict(bytes_per_launch=round(k["traffic_bytes"]), fetch_bytes=round(k["fetch_bytes"]),
+                        write_bytes=round(k["write_bytes"]), source=os.path.relpath(path, ROOT), kernel_source_digest=have)
         except Exception:
             continue
-    return None
+    return dict(bytes_per_launch=None, note=f"no PMC profile of the current {src} under profiles/" + (f" (newest stale: {stale})" if stale else ""))
+
+
+def make_batch(cfg, B, T, rank):
+    """This rank's utterances (weak scaling: same per-GPU work, different utterances).  Ragged (config 4): lengths uniform in
+    [96, T], languages ZH/JA/EN round-robin, speakers uniform over the table — seeded per rank."""
+    if not cfg["ragged"]:
+        return synth.synthetic_batch([T] * B, first_index=rank * B), [T] * B
+    g = torch.Generator().manual_seed(977 + rank)
+    lengths = [T] + torch.randint(96, T + 1, (B - 1,), generator=g).tolist()      # one full-length utterance fixes the padded shape
+    langs = [(rank * B + i) % 3 for i in range(B)]
+    sids = torch.randint(0, 850, (B,), generator=g).tolist()
+    return synth.synthetic_batch(lengths, langs, sids, first_index=rank * B), lengths
+
+
+def roofline_block(prof, psteps):
+    dom = max(prof, key=lambda r: r["total_ms"])
+    gen_ms = sum(r["total_ms"] for r in prof) / psteps
+    # the roof that binds the dominant kernel: its layer-wise arithmetic intensity against the machine balance
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom["name"] or "f16" in dom["name"]) else PEAK_FP32_MFMA_TFLOPS
+    ai = dom["flops"] / max(dom["bytes"], 1.0)
+    secs = dom["total_ms"] * 1e-3
+    if ai >= peak_tf * 1e12 / (PEAK_HBM_GBPS * 1e9):
+        ach, peak, unit, bound = dom["flops"] / secs / 1e12, peak_tf, "TFLOP/s", "mfma"
+    else:
+        ach, peak, unit, bound = dom["bytes"] / secs / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
+    tr = pmc_traffic(dom["name"])
+    return dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                arithmetic_intensity_flop_per_byte=round(ai, 1), traffic=tr.get("bytes_per_launch"), traffic_detail=tr,
+                alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]), launches_per_step=dom["launches"] / psteps,
+                avg_launch_us=round(dom["total_ms"] * 1e3 / dom["launches"], 2), flops_per_launch=dom["flops"] / dom["launches"],
+                generator_ms_per_step=round(gen_ms, 4),
+                generator_tflops=round(sum(r["flops"] for r in prof) / psteps / (gen_ms * 1e-3) / 1e12, 3),
+                timing="HIP events around the Generator's launches in a separate eager pass AFTER the timed region",
+                families=[dict(name=r["name"], launches=r["launches"] / psteps, ms_per_step=round(r["total_ms"] / psteps, 4),
+                               tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 3),
+                               alg_GBps=round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)) for r in prof])
+
+
+def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False):
+    """Time `steps` steps of BASELINE config `num` on this rank; returns the result dict (rank-local times; the caller reduces)."""
+    cfg = dict(CONFIGS[num])
+    B = overrides.get("batch") or cfg["batch"]
+    T = overrides.get("symbols") or cfg["symbols"]
+    gen_dtype = overrides.get("dtype") or cfg["dtype"]
+    flow_dtype = overrides.get("flow") or cfg["flow"]
+    use_graph = bool(cfg["graph"]) if overrides.get("graph") is None else bool(overrides["graph"])
+    model.enable_graphs(False)
+    model.set_generator_dtype(torch.bfloat16 if gen_dtype == "bf16" else torch.float32)
+    model.set_flow_dtype(torch.float16 if flow_dtype == "f16" else torch.float32)
+    batch, lengths = make_batch(cfg, B, T, rank)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    call = lambda b=dbatch: model.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"],
+                                        b["en_bert"], **KW)
+    frames_per_step = 3 * sum(lengths)                 # pinned durations: ceil(2.5) = 3 frames per symbol, valid frames only
+    audio_per_step = frames_per_step * hp.total_upsample / hp.sampling_rate
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    model.enable_graphs(use_graph)
+    model.profile(0)
+    for i in range(warmup):
+        out = call()
+    torch.cuda.synchronize()
+    assert int(out[2].sum().item()) == frames_per_step, (int(out[2].sum().item()), frames_per_step)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        o, attn, y_mask, _rest = call()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    Ty = y_mask.shape[2]
+    res = dict(config=num, B=B, T=T, Ty=Ty, gen_dtype=gen_dtype, flow_dtype=flow_dtype, graph=use_graph, dt=dt, steps=steps,
+               audio_per_step=audio_per_step, lengths=lengths)
+    if rank != 0:
+        model.enable_graphs(False)
+        return res
+
+    # ---- PCIe-inclusive variant (SURVEY 8d): inputs start in pinned HOST memory, the audio ends in pinned HOST memory
+    hbatch = {k: v.pin_memory() for k, v in batch.items()}
+    S = Ty * hp.total_upsample
+    host_o = torch.empty(B, 1, S, dtype=torch.float32, pin_memory=True)
+    n_io = max(3, min(steps, 10))
+
+    def call_io():
+        b = {k: v.to(dev, non_blocking=True) for k, v in hbatch.items()}
+        o = call(b)[0]
+        host_o.copy_(o, non_blocking=True)
+
+    call_io()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_io):
+        call_io()
+    torch.cuda.synchronize()
+    res["io_ms_per_step"] = (time.perf_counter() - t1) / n_io * 1e3
+    res["io_bytes_per_step"] = sum(v.numel() * v.element_size() for v in batch.values()) + host_o.numel() * 4
+
+    # ---- roofline leg: per-launch HIP events on the Generator's kernels, separate eager pass (events cannot be recorded inside a
+    # captured graph, and inside the timed loop they cost ~10 us of bubble per event pair)
+    model.enable_graphs(False)
+    psteps = max(3, min(steps, 150 if B == 1 else 20))
+    call()
+    model.profile(2)
+    torch.cuda.synchronize()
+    for _ in range(psteps):
+        call()
+    torch.cuda.synchronize()
+    prof = model.profile_report()
+    model.profile(0)
+    res["roofline"] = roofline_block(prof, psteps) if prof else None
+    if full_profile:
+        model.profile(3)               # one row per launch site and shape
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        full = [dict(name=r["name"], launches=r["launches"] / 3, ms_per_step=round(r["total_ms"] / 3, 4),
+                     us_per_launch=round(r["total_ms"] * 1e3 / r["launches"], 2),
+                     tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 3)) for r in model.profile_report()]
+        model.profile(0)
+        for r in sorted(full, key=lambda r: -r["ms_per_step"]):
+            log(f"  {r['ms_per_step']:8.4f} ms/step  {r['launches']:5.0f} x {r['us_per_launch']:8.2f} us  {r['tflops']:7.2f} TF  {r['name']}")
+        res["full"] = full
+    return res
+
+
+def describe(res, hp, world):
+    gd, fd = res["gen_dtype"], res["flow_dtype"]
+    ragged = CONFIGS[res["config"]]["ragged"]
+    shape = (f"B={res['B']} utterances of uniform [96,{res['T']}] symbols (mean {sum(res['lengths']) / res['B']:.1f}), ZH/JA/EN round-robin, "
+             f"random speakers" if ragged else f"B={res['B']} x T={res['T']} symbols")
+    return (f"BASELINE config {res['config']}: {shape} per GPU, "
+            f"{'bf16 Generator (fp32 accumulate)' if gd == 'bf16' else 'fp32 Generator'}, "
+            f"{'fp16 flow convs (fp32 accumulate / LayerNorm / softmax)' if fd == 'f16' else 'fp32 flow'}, "
+            f"fp32 text encoder / durations / spline, T_y={res['Ty']} frames "
+            f"({res['Ty'] * hp.total_upsample} samples, {res['Ty'] * hp.total_upsample / hp.sampling_rate:.3f} s) per padded utterance, "
+            f"transformer flow, synthetic seeded weights, durations pinned to 3 frames/symbol, hipGraph={'on' if res['graph'] else 'off'}")
+
+
+def summary(res, hp, world, dt=None, audio=None):
+    dt = res["dt"] if dt is None else dt
+    audio = res["audio_per_step"] * res["steps"] * world if audio is None else audio
+    out = dict(workload=describe(res, hp, world), value=round(audio / dt, 2), unit="audio-seconds/sec",
+               ms_per_step=round(dt / res["steps"] * 1e3, 4), steps=res["steps"],
+               dtype=dtype_label(res), utterances_per_gpu=res["B"], symbols=res["T"], frames=res["Ty"], hipgraph=res["graph"],
+               rtf=round(dt / audio, 6))
+    if "io_ms_per_step" in res:
+        out["pcie_inclusive"] = dict(value=round(res["audio_per_step"] / (res["io_ms_per_step"] * 1e-3), 2),
+                                     ms_per_step=round(res["io_ms_per_step"], 4), bytes_per_step=res["io_bytes_per_step"],
+                                     note="inputs copied from pinned host memory and the audio copied back to pinned host memory every step")
+    if res.get("roofline") is not None:
+        out["roofline"] = res["roofline"]
+    return out
+
+
+def dtype_label(res):
+    gd, fd = res["gen_dtype"], res["flow_dtype"]
+    if gd == "f32" and fd == "f32":
+        return "f32"
+    return f"gen={gd},flow={fd}"                 # what each part computes in (fp32 accumulate everywhere)
 
 
 def main():
@@ -139,12 +347,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)     # RCCL
 
     hp = H.default_v23()
-    cfgd = CONFIGS[args.config]
-    B = args.batch if args.batch is not None else cfgd["batch"]
-    T = args.symbols if args.symbols is not None else cfgd["symbols"]
-    gen_dtype = args.dtype or cfgd["dtype"]
-    flow_dtype = args.flow_dtype or cfgd["flow"]
-    kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
+    primary = args.config if args.config is not None else (2 if world == 1 else 4)
+    overrides = dict(batch=args.batch, symbols=args.symbols, dtype=args.dtype, flow=args.flow_dtype, graph=args.graph)
 
     # ---- weights: rank 0 folds/packs the seeded synthetic checkpoint, every other rank receives the blob over RCCL
     model = models.from_hparams(hp)
@@ -155,136 +359,50 @@ def main():
     log(f"rank {rank}/{world}: packing / distributing weights")
     t_bcast = sharding.distribute_weights(model, dev, src=0)
     log("weights attached")
-    if gen_dtype == "bf16":
-        model.set_generator_dtype(torch.bfloat16)
-    if flow_dtype == "f16":
-        model.set_flow_dtype(torch.float16)
-    use_graph = bool(cfgd.get("graph", 0)) if args.graph is None else bool(args.graph)
 
-    # ---- this rank's utterances (weak scaling: same per-GPU work, different utterances)
-    batch = synth.synthetic_batch([T] * B, first_index=rank * B)
-    dbatch = {k: v.to(dev) for k, v in batch.items()}
-    call = lambda: model.infer(dbatch["x"], dbatch["x_lengths"], dbatch["sid"], dbatch["tone"], dbatch["language"],
-                               dbatch["bert"], dbatch["ja_bert"], dbatch["en_bert"], **kw)
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-
-    model.enable_graphs(use_graph)
-    for i in range(args.warmup):
-        out = call()
-        if i == 0:
-            torch.cuda.synchronize()
-            log("first infer() done")
-    model.profile(0 if use_graph else 2)   # HIP events around the Generator's kernel launches only (dominant family)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    frames = 0
-    prof_steps = min(args.steps, 150)              # the event pool holds 8192 launches (~40 Generator launches per step)
-    for i in range(args.steps):
-        if i == prof_steps and not use_graph:
-            model.profile_pause()
-        o, attn, y_mask, _rest = call()
-        frames += y_mask.shape[2] * B              # pinned durations: every frame of every utterance is valid
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
-    prof = model.profile_report() if not use_graph else None
-    model.profile(0)
-    Ty = y_mask.shape[2]
-    if use_graph:
-        # events cannot be recorded inside a captured graph: the roofline leg times the same launches in an eager pass
-        # of the same K steps right after the timed (graph-replayed) region
-        model.enable_graphs(False)
-        call()
-        model.profile(2)
-        torch.cuda.synchronize()
-        for _ in range(prof_steps):
-            call()
-        torch.cuda.synchronize()
-        prof = model.profile_report()
-        model.profile(0)
-
+    res = run_config(primary, model, hp, dev, rank, world, args.steps, args.warmup, overrides, args.full_profile)
+    log(f"config {primary}: timed region {res['dt']:.3f}s for {args.steps} steps")
+    dt, audio = res["dt"], res["audio_per_step"] * args.steps
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        ftot = torch.tensor([frames], dtype=torch.float64, device=dev)
-        dist.all_reduce(ftot, op=dist.ReduceOp.SUM)
-        frames = float(ftot.item())
-    audio_s = frames * hp.total_upsample / hp.sampling_rate
-    value = audio_s / dt
+        atot = torch.tensor([audio], dtype=torch.float64, device=dev)
+        dist.all_reduce(atot, op=dist.ReduceOp.SUM)
+        audio = float(atot.item())
+
+    secondary = {}
+    if world == 1 and rank == 0 and not args.no_secondary and args.config is None:
+        for num in (3, 4, 5):
+            try:
+                r = run_config(num, model, hp, dev, 0, 1, max(5, min(args.steps, 10)), 3, {})
+                secondary[f"config{num}"] = summary(r, hp, 1)
+                log(f"secondary config {num}: {secondary[f'config{num}']['value']} audio-s/s ({secondary[f'config{num}']['ms_per_step']} ms/step)")
+            except Exception as e:          # a secondary workload must never take the primary line down
+                secondary[f"config{num}"] = dict(error=repr(e)[:300])
 
     if rank == 0:
-        # ---- roofline of the dominant kernel family (the MFMA implicit-GEMM conv that runs the Generator)
-        roof = None
-        if prof:
-            dom = max(prof, key=lambda r: r["total_ms"])
-            psteps = prof_steps                      # steps whose launches were event-timed
-            gen_ms = sum(r["total_ms"] for r in prof) / psteps
-            # the roof that binds the dominant kernel: its layer-wise arithmetic intensity against the machine balance
-            peak_tf = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["name"] else PEAK_FP32_MFMA_TFLOPS
-            ai = dom["flops"] / max(dom["bytes"], 1.0)
-            secs = dom["total_ms"] * 1e-3
-            if ai >= peak_tf * 1e12 / (PEAK_HBM_GBPS * 1e9):
-                ach, peak, unit, bound = dom["flops"] / secs / 1e12, peak_tf, "TFLOP/s", "mfma"
-            else:
-                ach, peak, unit, bound = dom["bytes"] / secs / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
-            roof = dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit,
-                        frac=round(ach / peak, 4), arithmetic_intensity_flop_per_byte=round(ai, 1),
-                        traffic=(pmc_traffic(dom["name"]) or {}).get("bytes_per_launch"),
-                        traffic_detail=pmc_traffic(dom["name"]),
-                        alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
-                        launches_per_step=dom["launches"] / psteps,
-                        avg_launch_us=round(dom["total_ms"] * 1e3 / dom["launches"], 2),
-                        flops_per_launch=dom["flops"] / dom["launches"],
-                        generator_ms_per_step=round(gen_ms, 4),
-                        generator_tflops=round(sum(r["flops"] for r in prof) / psteps / (gen_ms * 1e-3) / 1e12, 3),
-                        families=[dict(name=r["name"], launches=r["launches"] / psteps,
-                                       ms_per_step=round(r["total_ms"] / psteps, 4),
-                                       tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 3),
-                                       alg_GBps=round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)) for r in prof])
-        full = None
-        if args.full_profile:
-            model.profile(3)               # one row per launch site and shape (untimed pass; events perturb the run)
-            for _ in range(3):
-                call()
-            torch.cuda.synchronize()
-            full = [dict(name=r["name"], launches=r["launches"] / 3, ms_per_step=round(r["total_ms"] / 3, 4),
-                         us_per_launch=round(r["total_ms"] * 1e3 / r["launches"], 2),
-                         tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 3)) for r in model.profile_report()]
-            model.profile(0)
-            for r in sorted(full, key=lambda r: -r["ms_per_step"]):
-                log(f"  {r['ms_per_step']:8.4f} ms/step  {r['launches']:5.0f} x {r['us_per_launch']:8.2f} us  "
-                    f"{r['tflops']:7.2f} TF  {r['name']}")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle port)")
-            cpu = cpu_baseline(hp, sd, batch, kw, args.cpu_iters)
+            cpu = cpu_baseline(hp, sd, args.cpu_iters)
+        s = summary(res, hp, world, dt, audio)
         line = dict(
-            metric="audio-seconds/sec (44.1 kHz), SynthesizerTrn.infer(), 128-phoneme utterance", value=round(value, 2),
-            unit="audio-seconds/sec", n_gpus=world, steps=args.steps, warmup=args.warmup,
-            ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype=gen_dtype if gen_dtype == "f32" or flow_dtype == "f32" else "bf16+f16", data="synthetic",
-            config=dict(workload=f"BASELINE config {args.config}: B={B} x T={T} symbols per GPU, "
-                                 f"{'bf16 Generator (fp32 accumulate)' if gen_dtype == 'bf16' else 'fp32 Generator'}, "
-                                 f"{'fp16 flow convs (fp32 accumulate / LayerNorm / softmax)' if flow_dtype == 'f16' else 'fp32 flow'}, "
-                                 f"fp32 text encoder / durations / spline, T_y={Ty} frames "
-                                 f"({Ty * hp.total_upsample} samples, {Ty * hp.total_upsample / hp.sampling_rate:.3f} s) per utterance, "
-                                 f"transformer flow, synthetic seeded weights, durations pinned to 3 frames/symbol",
-                        utterances_per_gpu=B, symbols=T, frames=Ty, parallelism=f"utterance-sharded x{world}",
-                        rtf=round(dt / audio_s, 6), x_realtime_per_gpu=round(value / world, 2),
-                        hipgraph=use_graph, weight_broadcast_ms=round(t_bcast * 1e3, 3)),
-            roofline=roof, cpu_baseline=cpu)
-        if full:
-            line["kernel_families_untimed_pass"] = full
+            metric="audio-seconds/sec (44.1 kHz), SynthesizerTrn.infer(), 128-phoneme utterance", value=s["value"],
+            unit="audio-seconds/sec", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=s["ms_per_step"],
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype=s["dtype"], data="synthetic",
+            config=dict(workload=s["workload"], utterances_per_gpu=res["B"], symbols=res["T"], frames=res["Ty"],
+                        parallelism=f"utterance-sharded x{world}", rtf=s["rtf"], x_realtime_per_gpu=round(s["value"] / world, 2),
+                        hipgraph=res["graph"], weight_broadcast_ms=round(t_bcast * 1e3, 3),
+                        pcie_inclusive=s.get("pcie_inclusive"),
+                        note=("N=1 measures BASELINE config 2 (the metric's config); N>1 measures config 4 per GPU — the N=1 figure of "
+                              "that same workload is secondary.config4 of the N=1 line" if args.config is None else None)),
+            roofline=s.get("roofline"), cpu_baseline=cpu)
+        if secondary:
+            line["secondary"] = secondary
+        if res.get("full"):
+            line["kernel_families_untimed_pass"] = res["full"]
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -692,6 +692,11 @@ int bv2_test_layernorm(void* stream, const float* a, const float* add, int mode,
   return launch_layernorm(static_cast<hipStream_t>(stream), l);
 }
 
+void bv2_test_conv_timeline(void* dev_buf, long long capacity_u64) {
+  conv_set_timeline(static_cast<unsigned long long*>(dev_buf), capacity_u64);
+}
+int bv2_test_conv_timeline_report(long long* meta, int max_launches) { return conv_timeline_report(meta, max_launches); }
+
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target) { conv_set_tuning(splitk_waves, force_ck, tile_target); }
 
 int64_t bv2_test_dds_pack_floats(int C) {

@@ -68,7 +68,11 @@ struct ConvLaunch {
   const int64_t* lens = nullptr; int len_mul = 1;
   int ksplit;               // split-K kernel only: K split across workgroups into `ksplit` partial slabs (1 = none)
   int64_t slab_stride;      // floats between the partial slabs of one output (slab z is written at out + z*slab_stride)
+  unsigned long long* dbg = nullptr;   // tools/timeline.py only: 8 u64 per workgroup (s_memtime stamps + HW ids); null in the product
 };
+// tools/timeline.py: while a device buffer is set, every conv launch records per-workgroup timestamps into its own slice of it
+void conv_set_timeline(unsigned long long* dev_buf, long long capacity_u64);
+int conv_timeline_report(long long* meta, int max_launches);   // per launch: {offset_u64, gx, gy, gz, tile id, nprob k0 | k1<<8 | k2<<16, cin, L}
 
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6 };

@@ -70,6 +70,8 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
+  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int b = blockIdx.y / mtiles;
   const int m0 = (blockIdx.y - b * mtiles) * BM;
   const int vt = per_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
@@ -195,6 +197,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   for (int i = 0; i < GR; ++i) { load_unit(i, k == 1 ? (nchunks > 1 ? GR * 256 : 0) : 256); __builtin_amdgcn_sched_barrier(0); }
   store_x(0, 0);
   __syncthreads();
+  if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
   // Unit order inside a chunk: tap-major — for every tap j the GR groups in turn (ring slot = group, a compile-time index;
   // rows 8g of the X chunk are immediate offsets, the tap's column shift is one VGPR add per tap).  Operands of the next
@@ -259,30 +262,70 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
     }
   }
 
-  // epilogue (identical to v1)
+  if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
+  // ---- epilogue.  Every ConvProb field is copied into a register FIRST: P lives in the kernarg segment, and as soon as the
+  // kernel has stored to global memory the compiler must assume the kernarg may have changed, so reading P.* inside the store
+  // loop re-loads it per row (measured: 164 scalar loads / 198 waits, 18-45k cycles per workgroup — a quarter of the kernel).
+  // Offsets are 32-bit element offsets from wave-uniform 64-bit bases (a batch item is < 2^31 floats); the 16 residual / bias
+  // loads of an accumulator tile are issued together, then the arithmetic, then the 16 stores.
+  {
+    const int cout = P.cout, Lout = L.L;
+    const int act = P.act, mask_pre = P.mask_pre, mask_post = P.mask_post, res_mode = P.res_mode;
+    const unsigned o_rs = (unsigned)P.out_rstride, o_ts = (unsigned)P.out_tstride, o_to = (unsigned)P.out_toff;
+    float* const outb = P.out + (int64_t)b * P.out_bstride;
+    const float* const resb = res_mode != RES_NONE ? P.res + (int64_t)b * P.res_bstride : nullptr;
+    const float* const biasp = P.bias;
+    const float* const bias2p = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
+    const float* const omaskp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : nullptr;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
-      if (col >= L.L) continue;
-      const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;       // this lane's rows: row0 + (r & 3) + 8 * (r >> 2)
+      float bs[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (MI * 32) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= P.cout) continue;
-        float v = acc[mi][ni][r];
-        if (P.bias) v += P.bias[row];
-        if (P.bias2) v += P.bias2[(int64_t)b * P.bias2_bstride + row];
-        if (P.act == ACT_RELU) v = fmaxf(v, 0.f);
-        if (P.mask_pre) v *= om;
-        const int64_t oidx = (int64_t)row * P.out_rstride + (int64_t)col * P.out_tstride + P.out_toff;
-        if (P.res_mode == RES_ADD) v += P.res[(int64_t)b * P.res_bstride + oidx];
-        else if (P.res_mode == RES_RSUB) v = P.res[(int64_t)b * P.res_bstride + oidx] - v;
-        if (P.mask_post) v *= om;
-        P.out[(int64_t)b * P.out_bstride + oidx] = v;
+        int row = row0 + (r & 3) + 8 * (r >> 2);
+        row = row < cout ? row : cout - 1;                            // clamped: the load is unconditional, the store is not
+        float v = biasp ? biasp[row] : 0.f;
+        if (bias2p) v += bias2p[row];
+        bs[r] = v;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
+        const bool colok = col < Lout;
+        const int colc = colok ? col : Lout - 1;
+        const float om = omaskp ? omaskp[colc] : 1.f;
+        const unsigned off0 = (unsigned)row0 * o_rs + (unsigned)colc * o_ts + o_to;
+        float rv[16];
+        if (resb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const unsigned off = row0 + dr < cout ? off0 + (unsigned)dr * o_rs : off0;
+            rv[r] = ld_off(resb, 4u * off);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          float v = acc[mi][ni][r] + bs[r];
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          if (mask_pre) v *= om;
+          if (res_mode == RES_ADD) v += rv[r];
+          else if (res_mode == RES_RSUB) v = rv[r] - v;
+          if (mask_post) v *= om;
+          if (colok && row0 + dr < cout) outb[off0 + (unsigned)dr * o_rs] = v;
+        }
       }
     }
+  }
+  if (L.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);                                  // the epilogue's stores have been issued and acknowledged
+    unsigned long long* d = L.dbg + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+    d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);               // HW_ID
+    d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);              // XCC_ID
+    d[6] = (unsigned long long)k; d[7] = 1;
   }
 }
 
@@ -298,6 +341,8 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(red_raw);   // [NWV][32][33]
   // XCD-aware placement: consecutive virtual ids (which share a weight slice) land on the same XCD
   const int bid = blockIdx.x;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
+  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int v = (bid & 7) * per_xcd + (bid >> 3);
   if (v >= total) return;
   int rem = v;
@@ -379,6 +424,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
 
 #pragma unroll
   for (int i = 0; i < SK_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
   for (int u0 = 0; u0 < U; u0 += SK_PD) {
 #pragma unroll
     for (int i = 0; i < SK_PD; ++i) {
@@ -402,39 +448,64 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
     }
   }
 
+  if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
   // reduce the waves' partial tiles through LDS
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r] + acc2[r];
   __syncthreads();
+  // epilogue: every ConvProb field into a register first (see conv1d_mfma_kernel's epilogue: reading P.* after the first
+  // global store re-loads it from the kernarg segment per row), 32-bit element offsets from wave-uniform bases
   const int col = t0 + (tid & 31);
-  if (col >= L.L) return;
-  const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
-  float* outp = P.out + (int64_t)z * L.slab_stride;
-  constexpr int RPP = 2 * NWV;                    // rows per pass (one element per thread per pass)
+  const bool colok = col < L.L;
+  {
+    const int cout = P.cout, act = P.act, mask_pre = P.mask_pre, mask_post = P.mask_post, res_mode = P.res_mode;
+    const unsigned o_rs = (unsigned)P.out_rstride, o_ts = (unsigned)P.out_tstride, o_to = (unsigned)P.out_toff;
+    float* const outb = P.out + (int64_t)z * L.slab_stride + (int64_t)b * P.out_bstride;
+    const float* const resb = (res_mode != RES_NONE && z == 0) ? P.res + (int64_t)b * P.res_bstride : nullptr;
+    const float* const biasp = z == 0 ? P.bias : nullptr;
+    const float* const bias2p = (z == 0 && P.bias2) ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
+    const float om = (P.out_mask && colok) ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
+    const unsigned coff = (unsigned)(colok ? col : 0) * o_ts + o_to;
+    constexpr int RPP = 2 * NWV;                    // rows per pass (one element per thread per pass)
+    float rvv[32 / RPP], bsv[32 / RPP];
 #pragma unroll
-  for (int i = 0; i < 32 / RPP; ++i) {
-    const int rl = (tid >> 5) + RPP * i;
-    const int row = m0 + rl;
-    if (row >= P.cout) continue;
-    float vv = 0.f;
+    for (int i = 0; i < 32 / RPP; ++i) {
+      const int rl = (tid >> 5) + RPP * i;
+      int row = m0 + rl;
+      row = row < cout ? row : cout - 1;
+      float bsum = biasp ? biasp[row] : 0.f;
+      if (bias2p) bsum += bias2p[row];
+      bsv[i] = bsum;
+      rvv[i] = resb ? ld_off(resb, 4u * ((unsigned)row * o_rs + coff)) : 0.f;
+    }
 #pragma unroll
-    for (int w = 0; w < NWV; w += 4)
-      vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
-    if (z == 0) {
-      if (P.bias) vv += P.bias[row];
-      if (P.bias2) vv += P.bias2[(int64_t)b * P.bias2_bstride + row];
+    for (int i = 0; i < 32 / RPP; ++i) {
+      const int rl = (tid >> 5) + RPP * i;
+      const int row = m0 + rl;
+      float vv = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; w += 4)
+        vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
+      vv += bsv[i];
+      if (act == ACT_RELU) vv = fmaxf(vv, 0.f);             // host guarantees act == NONE when ksplit > 1
+      if (mask_pre) vv *= om;
+      if (z == 0) {
+        if (res_mode == RES_ADD) vv += rvv[i];
+        else if (res_mode == RES_RSUB) vv = rvv[i] - vv;
+      } else if (res_mode == RES_RSUB) {
+        vv = -vv;
+      }
+      if (mask_post) vv *= om;
+      if (colok && row < cout) outb[(unsigned)row * o_rs + coff] = vv;
     }
-    if (P.act == ACT_RELU) vv = fmaxf(vv, 0.f);           // host guarantees act == NONE when ksplit > 1
-    if (P.mask_pre) vv *= om;
-    const int64_t oidx = (int64_t)row * P.out_rstride + (int64_t)col * P.out_tstride + P.out_toff;
-    if (z == 0) {
-      if (P.res_mode == RES_ADD) vv += P.res[(int64_t)b * P.res_bstride + oidx];
-      else if (P.res_mode == RES_RSUB) vv = P.res[(int64_t)b * P.res_bstride + oidx] - vv;
-    } else if (P.res_mode == RES_RSUB) {
-      vv = -vv;
-    }
-    if (P.mask_post) vv *= om;
-    outp[(int64_t)b * P.out_bstride + oidx] = vv;
+  }
+  if (L.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* d = L.dbg + 8ull * blockIdx.x;
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+    d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    d[6] = (unsigned long long)U; d[7] = 1;
   }
 }
 
@@ -447,14 +518,43 @@ static const TileCfg kTiles[] = {
     {TILE_32x128, 32, 128, 3, "conv1d_mfma<32x128>"},
 };
 
+static unsigned long long* g_tl_buf = nullptr;
+static long long g_tl_cap = 0, g_tl_off = 0;
+struct TlMeta { long long off; int gx, gy, gz, tile, ks, cin, L; };
+static TlMeta g_tl_meta[512];
+static int g_tl_n = 0;
+void conv_set_timeline(unsigned long long* dev_buf, long long capacity_u64) { g_tl_buf = dev_buf; g_tl_cap = capacity_u64; g_tl_off = 0; g_tl_n = 0; }
+int conv_timeline_report(long long* meta, int max_launches) {
+  int n = g_tl_n < max_launches ? g_tl_n : max_launches;
+  for (int i = 0; i < n; ++i) {
+    const TlMeta& m = g_tl_meta[i];
+    long long* o = meta + 8 * i;
+    o[0] = m.off; o[1] = m.gx; o[2] = m.gy; o[3] = m.gz; o[4] = m.tile; o[5] = m.ks; o[6] = m.cin; o[7] = m.L;
+  }
+  return n;
+}
+static ConvLaunch with_timeline(const ConvLaunch& L, dim3 grid, int tile) {
+  ConvLaunch r = L;
+  if (!g_tl_buf) return r;
+  const long long need = 8ll * grid.x * grid.y * grid.z;
+  if (g_tl_off + need > g_tl_cap || g_tl_n >= 512) return r;
+  r.dbg = g_tl_buf + g_tl_off;
+  int ks = 0;
+  for (int i = 0; i < L.nprob && i < 3; ++i) ks |= (L.p[i].k & 255) << (8 * i);
+  g_tl_meta[g_tl_n++] = TlMeta{g_tl_off, (int)grid.x, (int)grid.y, (int)grid.z, tile, ks, L.p[0].cin, L.L};
+  g_tl_off += need;
+  return r;
+}
+
 template <int WM, int WN, int MI, int NI, int XS>
-static int launch_variant(hipStream_t stream, const ConvLaunch& L, int ck, int max_cout_pad, int max_extra, int max_chunks) {
+static int launch_variant(hipStream_t stream, const ConvLaunch& L0, int ck, int max_cout_pad, int max_extra, int max_chunks) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   if (BN + max_extra > XS * 64) return -2;        // halo does not fit the staged tile
   const int mtiles = (max_cout_pad + BM - 1) / BM;
-  const int ntx = (L.L + BN - 1) / BN;
+  const int ntx = (L0.L + BN - 1) / BN;
   const int per_xcd = (ntx % 8 == 0 || ntx >= 64) ? (ntx + 7) / 8 : 0;      // contiguous per-XCD ranges only if they balance
-  dim3 grid(per_xcd ? per_xcd * 8 : ntx, mtiles * L.B, L.nprob);
+  dim3 grid(per_xcd ? per_xcd * 8 : ntx, mtiles * L0.B, L0.nprob);
+  const ConvLaunch L = with_timeline(L0, grid, BM * 1000 + BN);
   const int nxbuf = max_chunks > 1 ? 2 : 1;     // a single-chunk problem never re-stages its X tile
   // weights go global -> registers; LDS holds only the (double-buffered) X chunk
   if (ck == 32) {
@@ -513,8 +613,9 @@ static void launch_splitk_nw(hipStream_t stream, const ConvLaunch& L, int nw, di
   }
 }
 
-static int launch_splitk(hipStream_t stream, const ConvLaunch& L, int max_cout_pad, const char** variant_name) {
-  const int mtiles = max_cout_pad / 32, ntiles = (L.L + 31) / 32;
+static int launch_splitk(hipStream_t stream, const ConvLaunch& L0, int max_cout_pad, const char** variant_name) {
+  const int mtiles = max_cout_pad / 32, ntiles = (L0.L + 31) / 32;
+  const ConvLaunch L = with_timeline(L0, dim3(((L0.nprob * L0.B * mtiles * L0.ksplit * ntiles + 7) / 8) * 8), 32032);
   const int total = L.nprob * L.B * mtiles * L.ksplit * ntiles;
   const int per_xcd = (total + 7) / 8;
   bool any_mask = false, all_mask = true;

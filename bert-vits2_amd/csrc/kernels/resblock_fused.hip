@@ -171,11 +171,22 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
     rf_gemm(acc, P.w2, w_lane, groups, k, Tm, RF_TP, RF_LEAD + 32 * wid + l31 - h2, 1, lh);
     const int t = t0 + 32 * wid + l31;
     if (t < L) {
-      float* op = P.out + (int64_t)b * C * L;
+      // pointers and the 16 bias / residual values into registers BEFORE the first store: P lives in the kernarg segment and is
+      // re-loaded after every global store otherwise (see conv_mfma.hip's epilogue)
+      float* const op = P.out + (int64_t)b * C * L;
+      const float* const b2p = P.b2;
+      float bv[16], xv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        row = row < C ? row : C - 1;
+        bv[r] = b2p[row];
+        xv[r] = rf_ld(xp, 4u * ((unsigned)row * (unsigned)L + (unsigned)t));
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < C) op[(int64_t)row * L + t] = acc[r] + P.b2[row] + xp[(int64_t)row * L + t];
+        if (row < C) op[(unsigned)row * (unsigned)L + (unsigned)t] = (acc[r] + bv[r]) + xv[r];   // conv + bias, then + x
       }
     }
   }

@@ -85,6 +85,12 @@ int bv2_test_dds_layer(void* stream, const float* x, const float* pre_w_host, co
 /* tuning experiments (tools/kbench.py): force the split-K wave count / C_in chunk / tile-count target of the fp32 conv; 0 = default */
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target);
 
+/* tools/timeline.py: while dev_buf (capacity_u64 zeroed uint64 on the DEVICE) is set, every fp32 conv launch records 8 uint64 per
+ * workgroup {s_memtime at start, after the prologue, after the main loop, at the end, HW_ID, XCC_ID, k or units, valid} into its own
+ * slice; bv2_test_conv_timeline_report fills 8 int64 per launch {offset, grid x, y, z, tile (BM*1000+BN), k0|k1<<8|k2<<16, cin, L}. */
+void bv2_test_conv_timeline(void* dev_buf, long long capacity_u64);
+int bv2_test_conv_timeline_report(long long* meta, int max_launches);
+
 /* inverse RQ spline on channel `dst` of z [B][2][T] with params [B][prow][T] (DEVICE) */
 int bv2_test_spline(void* stream, float* z, int src, int dst, const float* params, int prow, const float* mask,
                     float sqrt_fc, float tail, int B, int T);

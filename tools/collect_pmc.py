@@ -29,7 +29,7 @@ def one_pass(counters, extra_args):
     d = tempfile.mkdtemp(prefix="bv2pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "--output-format", "csv", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--graph", "0"] + extra_args
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--graph", "0"] + extra_args
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=900)
     tot = collections.defaultdict(collections.Counter)
     n = collections.Counter()

@@ -45,7 +45,7 @@ def one_pass(counter, extra_args):
     d = tempfile.mkdtemp(prefix="bv2pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra_args
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"] + extra_args
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
     tot, n = collections.Counter(), collections.Counter()
     for cc in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
@@ -68,8 +68,13 @@ def main():
     extra = sys.argv[2:]
     fetch = one_pass("FETCH_SIZE", extra)
     write = one_pass("WRITE_SIZE", extra)
+    import hashlib
+    kdir = os.path.join(ROOT, "bert-vits2_amd", "csrc", "kernels")
+    digests = {f: hashlib.sha256(open(os.path.join(kdir, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(kdir)) if f.endswith(".hip")}
     res = {"_method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around `bench.py --steps 3 --warmup 1`; "
                       "KB -> bytes; FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md); WRITE_SIZE uncalibrated",
+           "_bench_args": extra,
+           "source_digests": digests,      # bench.py only trusts this file for a kernel whose source still has this digest
            "kernels": {}}
     for f in sorted(set(fetch) | set(write)):
         fk, n = fetch.get(f, (0.0, 0))

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Offline analysis of tools/timeline.py output (no GPU needed).
+
+    python tools/timeline_report.py gpurun_out/timeline_c2.npz [launch indices...]
+
+s_memtime is per-XCD (the eight counters have different offsets), so spans are taken per XCD.  For each launch: workgroups per CU,
+per-problem (k) phase times, MFMA-pipe utilisation = sum of MFMA cycles issued by all waves / (span x SIMDs), and how the span splits
+into 'all CUs busy' vs tail."""
+import sys
+
+import numpy as np
+
+
+def hw(v):
+    hwid, xcc = v[:, 4], v[:, 5] & 15
+    simd = (hwid >> 4) & 3
+    cu = (hwid >> 8) & 15
+    sh = (hwid >> 12) & 1
+    se = (hwid >> 13) & 7
+    return xcc, se, sh, cu, simd
+
+
+def main():
+    z = np.load(sys.argv[1])
+    meta, raw = z["meta"], z["raw"]
+    sel = [int(a) for a in sys.argv[2:]] or range(len(meta))
+    for i in sel:
+        off, gx, gy, gz, tile, ks, cin, Lc = meta[i]
+        s = raw[off: off + 8 * gx * gy * gz].reshape(-1, 8)
+        v = s[s[:, 7] == 1]
+        if not len(v):
+            continue
+        xcc, se, sh, cu, simd = hw(v)
+        cukey = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+        ncu = len(np.unique(cukey))
+        spans = []
+        for x in np.unique(xcc):
+            m = xcc == x
+            spans.append(v[m, 3].max() - v[m, 0].min())
+        span = float(np.mean(spans))
+        bm, bn = tile // 1000, tile % 1000
+        kk = [(ks >> (8 * j)) & 255 for j in range(3) if (ks >> (8 * j)) & 255]
+        line = f"#{i:3d} {bm}x{bn} k={kk} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU), span {span:9.0f} (per-XCD {min(spans)}..{max(spans)})"
+        if tile != 32032:
+            # MFMA cycles per wave of a workgroup of problem p: (cin/8 groups) * k taps * 4 MFMAs * (MI*NI) * 64 cycles; waves = 4
+            mi_ni = (bm // 64) * (bn // 64) if bm >= 64 and bn >= 64 else (1 if bm * bn <= 32 * 128 else 2)
+            tot = 0.0
+            parts = []
+            for p, k in enumerate(kk):
+                m = v[:, 6] == k
+                if not m.any():
+                    continue
+                cyc = (cin / 8) * k * 4 * mi_ni * 64
+                tot += m.sum() * cyc
+                lo = v[m, 2] - v[m, 1]
+                parts.append(f"k{k}: n {m.sum()} prol {np.mean(v[m, 1] - v[m, 0]):6.0f} loop {lo.mean():8.0f} (ideal alone {cyc:7.0f}, x{lo.mean() / cyc:4.2f}) epi {np.mean(v[m, 3] - v[m, 2]):6.0f}")
+            util = tot / (span * ncu)            # each CU has 4 SIMDs and each workgroup puts one wave on each: cycles per SIMD
+            line += f"  MFMA util {util:5.3f}"
+            print(line)
+            for p in parts:
+                print("      " + p)
+            # concurrency profile on the busiest XCD: how many workgroups are in their main loop over time
+            x = np.bincount(xcc).argmax()
+            m = xcc == x
+            t0 = v[m, 0].min()
+            ev = np.concatenate([np.stack([v[m, 1] - t0, np.ones(m.sum())], 1), np.stack([v[m, 2] - t0, -np.ones(m.sum())], 1)])
+            ev = ev[np.argsort(ev[:, 0])]
+            conc = np.cumsum(ev[:, 1])
+            dt = np.diff(ev[:, 0], append=ev[-1, 0])
+            ncu_x = len(np.unique(cukey[m]))
+            tot_t = ev[-1, 0] - ev[0, 0]
+            for thr in (1.0, 2.0, 3.0):
+                frac = dt[conc >= thr * ncu_x].sum() / tot_t
+                print(f"      XCD {x}: fraction of loop span with >= {thr:.0f} workgroups/CU in the main loop: {frac:5.2f}")
+        else:
+            U = v[:, 6]
+            print(line)
+            print(f"      units/wave {U.mean():5.1f}  prol {np.mean(v[:, 1] - v[:, 0]):6.0f}  loop {np.mean(v[:, 2] - v[:, 1]):7.0f} (ideal {U.mean() * 256:6.0f})  epi {np.mean(v[:, 3] - v[:, 2]):6.0f}"
+                  f"  wg life {np.mean(v[:, 3] - v[:, 0]):7.0f}")
+
+
+if __name__ == "__main__":
+    main()

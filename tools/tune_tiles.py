@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Generator time at BASELINE config 2 (B=1, T_y=384) under different tile-count targets of the fp32 conv's auto picker
+(bv2_test_set_tuning; run ON THE GPU BOX).  Prints ms per Generator pass (event-timed, median of 5 x 10 passes)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bert_vits2_amd import hparams as H, lib as L, models, synth  # noqa: E402
+
+
+def main():
+    lib = L.load()
+    lib.bv2_test_set_tuning.argtypes = [C.c_int, C.c_int, C.c_long]
+    lib.bv2_test_set_tuning.restype = None
+    hp = H.default_v23()
+    m = models.from_hparams(hp)
+    m.load_state_dict(synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5), strict=False)
+    m = m.to("cuda").eval()
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    Ty = 384
+    z = torch.randn(B, hp.inter_channels, Ty, device="cuda")
+    yl = torch.full((B,), Ty, dtype=torch.int64, device="cuda")
+    g = torch.randn(B, hp.gin_channels, device="cuda")
+    for target in (0, 256, 512, 768, 1024, 3072, 6144):
+        lib.bv2_test_set_tuning(0, 0, target)
+        for _ in range(3):
+            m.stage_generator(z, yl, g)
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                m.stage_generator(z, yl, g)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 10)
+        ts.sort()
+        print(f"tile target {target:5d} (0 = default 1536): generator {ts[2]:.4f} ms/pass (min {ts[0]:.4f})")
+    lib.bv2_test_set_tuning(0, 0, 0)
+
+
+if __name__ == "__main__":
+    main()
