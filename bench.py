@@ -225,7 +225,7 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
             import torch.distributed as dist
             dist.barrier()
 
-    model.enable_graphs(use_graph)
+    model.enable_graphs(use_graph, static_io=True)     # serving-loop replay: inputs read in place, outputs are the graph's buffers
     model.profile(0)
     for i in range(warmup):
         out = call()

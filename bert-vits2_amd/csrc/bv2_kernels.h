@@ -72,7 +72,9 @@ struct ConvLaunch {
 };
 // tools/timeline.py: while a device buffer is set, every conv launch records per-workgroup timestamps into its own slice of it
 void conv_set_timeline(unsigned long long* dev_buf, long long capacity_u64);
-int conv_timeline_report(long long* meta, int max_launches);   // per launch: {offset_u64, gx, gy, gz, tile id, nprob k0 | k1<<8 | k2<<16, cin, L}
+int conv_timeline_report(long long* meta, int max_launches);
+// a launch's slice of the timeline buffer (null when none is set); tile / ks / cin / L are only recorded for the report
+unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int tile, int ks, int cin, int L);   // per launch: {offset_u64, gx, gy, gz, tile id, nprob k0 | k1<<8 | k2<<16, cin, L}
 
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6 };
@@ -134,7 +136,8 @@ struct ClProb {
   int cin, cout, cout_pad, k, dil, pad_left;
   int pre_lrelu; float slope;
 };
-struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; const int64_t* lens = nullptr; int len_mul = 1; };
+struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; const int64_t* lens = nullptr; int len_mul = 1;
+                  unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
 int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** variant_name);
 bool conv_cl_bf16_supported(int cin, int cout, int k, int dil);
 // element index (bf16 units) of weight (tap j, input channel ci, output channel co) in the packed stream

@@ -54,6 +54,8 @@ __device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
 // (An earlier form staged the weights through LDS with a barrier every 16 MFMAs: 113 instructions per 16 MFMAs, 92 TF where
 // this one reaches 103 TF on the C=128 stage at batch 1; tools/probe/mfma_probe.hip shows why — every VALU / LDS-dependent
 // instruction between MFMAs costs issue slots the 64-cycle fp32 MFMA cannot hide at 1-3 waves per SIMD.)
+// (Measured and not kept: __launch_bounds__(256, 5) for the 64x64 tile — 96 registers, five workgroups per CU instead of four,
+// 6 spilled registers: the Generator at batch 1 went 2.819 -> 2.856 ms.)
 template <int WM, int WN, int MI, int NI, int CK, int XS>
 __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles, const int per_xcd) {
   constexpr int BM = WM * MI * 32;
@@ -334,11 +336,17 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 constexpr int SK_PD = 8;          // prefetch ring depth (units of 4 MFMAs)
 
 
-template <bool MASK, int NWV>    // NWV waves per workgroup split K inside the workgroup
+// LDSX (k > 1): the workgroup's X tile [its channel groups][32 + (k-1)*dil columns] is staged ONCE in LDS (mask / pre-activation /
+// in_scale applied while it is written) and every tap reads it back shifted, instead of every wave re-loading each column per
+// tap from global memory: tools/timeline.py showed the k = 5 FFN convs bound by the CU's L1 path (246 KB per workgroup, half
+// of it the 5-fold re-read of X), their main loop at 3.7x the MFMA time.  Weights still stream global -> registers.
+constexpr int SK_XP = 64;         // staged tile width (floats): 32 + (k-1)*dil must fit
+constexpr int SK_RPW = 32;        // rows of the staged tile per wave at most
+template <bool MASK, int NWV, bool LDSX>    // NWV waves per workgroup split K inside the workgroup
 __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunch L, const int mtiles, const int ntiles,
                                                                  const int per_xcd, const int total) {
   extern __shared__ __attribute__((aligned(16))) float red_raw[];
-  float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(red_raw);   // [NWV][32][33]
+  float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(red_raw);   // [NWV][32][33]; LDSX: aliases the X tile (barrier between)
   // XCD-aware placement: consecutive virtual ids (which share a weight slice) land on the same XCD
   const int bid = blockIdx.x;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
@@ -406,6 +414,11 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   unsigned goff = group_off(lg), woff = weight_off(lg), joff = 0;   // joff = lj * w_tap
   auto load_unit = [&](int slot) __attribute__((always_inline)) {
     ar[slot] = ld_off4(wp, woff + joff);
+    if (LDSX) {
+      joff += w_tap;
+      if (++lj == k) { lj = 0; joff = 0; ++lg; woff = weight_off(lg); }
+      return;
+    }
     const int t = tcol + lj * dil;
     const bool tok = t >= 0 && t < Lin;
     const unsigned tcl = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
@@ -422,9 +435,68 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
     if (++lj == k) { lj = 0; joff = 0; ++lg; goff = group_off(lg); woff = weight_off(lg); }
   };
 
+  // ---- LDSX: stage the workgroup's X tile.  Row rr = wid + NWV*i of the tile is channel 8*G0 + rr; lane = column.
+  const int G0 = (int)(((int64_t)groups * (z * NWV)) / nsl);
+  float* const Xs = red_raw;
+  if (LDSX) {
+    const int G1 = (int)(((int64_t)groups * ((z + 1) * NWV)) / nsl);
+    const int nrows = 8 * (G1 - G0);
+    const int XW = 32 + (k - 1) * dil;
+    const int t = t0 - P.pad_left + lane;
+    const bool tok = lane < XW && t >= 0 && t < Lin;
+    const unsigned tcl = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
+    const float cs = tok ? (MASK ? in_scale * ld_off(mp, tcl) : in_scale) : 0.f;
+    float xv[SK_RPW];
+#pragma unroll
+    for (int i = 0; i < SK_RPW; ++i) {
+      int row = 8 * G0 + wid + NWV * i;
+      row = row < cin ? row : cin - 1;
+      xv[i] = ld_off(xp, (unsigned)row * x_rs4 + tcl);
+    }
+#pragma unroll
+    for (int i = 0; i < SK_RPW; ++i) {
+      const int rr = wid + NWV * i;
+      float x = xv[i];
+      const float xn = x * slope;
+      x = (lrelu && x < 0.f) ? xn : x;
+      if (rr < nrows) Xs[rr * SK_XP + lane] = (8 * G0 + rr < cin) ? x * cs : 0.f;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < SK_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
+  if (LDSX) __syncthreads();
   if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
+  if (LDSX) {
+    // units run (group, tap) in the order the ring was loaded; the next unit's B operands are read while this unit's MFMAs run
+    int ug = g0, uj = 0;
+    float bq[2][4];
+    {
+      const float* xb = Xs + (8 * (ug - G0) + lh) * SK_XP + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[0][q] = xb[q * 2 * SK_XP];
+    }
+    for (int u0 = 0; u0 < U; u0 += SK_PD) {
+#pragma unroll
+      for (int i = 0; i < SK_PD; ++i) {
+        if (u0 + i < U) {
+          int jn = uj + 1, gn = ug;
+          if (jn == k) { jn = 0; ++gn; }
+          const bool more = u0 + i + 1 < U;
+          const float* xb = Xs + (8 * ((more ? gn : ug) - G0) + lh) * SK_XP + l31 + (more ? jn : uj) * dil;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bq[(i & 1) ^ 1][q] = xb[q * 2 * SK_XP];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].x, bq[i & 1][0], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].y, bq[i & 1][1], acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].z, bq[i & 1][2], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i].w, bq[i & 1][3], acc2, 0, 0, 0);
+          uj = jn; ug = gn;
+        }
+        load_unit(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                              // every wave is done with the X tile before `red` overwrites it
+  } else
   for (int u0 = 0; u0 < U; u0 += SK_PD) {
 #pragma unroll
     for (int i = 0; i < SK_PD; ++i) {
@@ -518,6 +590,14 @@ static const TileCfg kTiles[] = {
     {TILE_32x128, 32, 128, 3, "conv1d_mfma<32x128>"},
 };
 
+// tuning experiments (tools/kbench.py drive these through bv2_test_set_tuning; 0 = the shipped heuristics)
+static int g_tune_splitk_waves = 0, g_tune_force_ck = 0, g_tune_no_ldsx = 0;
+static long g_tune_tile_target = 0;
+void conv_set_tuning(int splitk_waves, int force_ck, long tile_target) {
+  g_tune_no_ldsx = splitk_waves >= 100 ? 1 : 0;                     // +100: the non-staged split-K form (A/B comparisons)
+  g_tune_splitk_waves = splitk_waves % 100; g_tune_force_ck = force_ck; g_tune_tile_target = tile_target;
+}
+
 static unsigned long long* g_tl_buf = nullptr;
 static long long g_tl_cap = 0, g_tl_off = 0;
 struct TlMeta { long long off; int gx, gy, gz, tile, ks, cin, L; };
@@ -533,16 +613,21 @@ int conv_timeline_report(long long* meta, int max_launches) {
   }
   return n;
 }
+unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int tile, int ks, int cin, int L) {
+  if (!g_tl_buf) return nullptr;
+  const long long need = 8ll * gx * gy * gz;
+  if (g_tl_off + need > g_tl_cap || g_tl_n >= 512) return nullptr;
+  unsigned long long* r = g_tl_buf + g_tl_off;
+  g_tl_meta[g_tl_n++] = TlMeta{g_tl_off, (int)gx, (int)gy, (int)gz, tile, ks, cin, L};
+  g_tl_off += need;
+  return r;
+}
 static ConvLaunch with_timeline(const ConvLaunch& L, dim3 grid, int tile) {
   ConvLaunch r = L;
   if (!g_tl_buf) return r;
-  const long long need = 8ll * grid.x * grid.y * grid.z;
-  if (g_tl_off + need > g_tl_cap || g_tl_n >= 512) return r;
-  r.dbg = g_tl_buf + g_tl_off;
   int ks = 0;
   for (int i = 0; i < L.nprob && i < 3; ++i) ks |= (L.p[i].k & 255) << (8 * i);
-  g_tl_meta[g_tl_n++] = TlMeta{g_tl_off, (int)grid.x, (int)grid.y, (int)grid.z, tile, ks, L.p[0].cin, L.L};
-  g_tl_off += need;
+  r.dbg = timeline_slice(grid.x, grid.y, grid.z, tile, ks, L.p[0].cin, L.L);
   return r;
 }
 
@@ -584,13 +669,6 @@ static int splitk_units(const ConvLaunch& L) {
   return units;
 }
 
-// tuning experiments (tools/kbench.py drive these through bv2_test_set_tuning; 0 = the shipped heuristics)
-static int g_tune_splitk_waves = 0, g_tune_force_ck = 0;
-static long g_tune_tile_target = 0;
-void conv_set_tuning(int splitk_waves, int force_ck, long tile_target) {
-  g_tune_splitk_waves = splitk_waves; g_tune_force_ck = force_ck; g_tune_tile_target = tile_target;
-}
-
 static int splitk_waves(const ConvLaunch& L) {
   if (g_tune_splitk_waves == 4 || g_tune_splitk_waves == 8 || g_tune_splitk_waves == 16) return g_tune_splitk_waves;
   const int slices = (splitk_units(L) + SK_UNITS_PER_WAVE - 1) / SK_UNITS_PER_WAVE;   // K slices wanted in total
@@ -598,18 +676,36 @@ static int splitk_waves(const ConvLaunch& L) {
   return per_wg > 4 ? 8 : 4;
 }
 
-template <bool MASK>
+// rows of the X tile a workgroup stages in the LDSX form: the largest channel-group range of any (problem, slice)
+static int splitk_stage_rows(const ConvLaunch& L, int nw) {
+  int rows = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    const int groups = L.p[i].cin_pad / 8, nsl = L.ksplit * nw;
+    for (int z = 0; z < L.ksplit; ++z) {
+      const int a = (int)(((int64_t)groups * (z * nw)) / nsl), b = (int)(((int64_t)groups * ((z + 1) * nw)) / nsl);
+      rows = 8 * (b - a) > rows ? 8 * (b - a) : rows;
+    }
+  }
+  return rows;
+}
+
+template <bool MASK, bool LDSX>
 static void launch_splitk_nw(hipStream_t stream, const ConvLaunch& L, int nw, dim3 grid, int mtiles, int ntiles, int per_xcd,
-                             int total) {
-  const size_t lds = sizeof(float) * (size_t)nw * 32 * 33;
+                             int total, int stage_rows) {
+  size_t lds = sizeof(float) * (size_t)nw * 32 * 33;
+  if (LDSX && sizeof(float) * (size_t)stage_rows * SK_XP > lds) lds = sizeof(float) * (size_t)stage_rows * SK_XP;
   if (nw == 16) {
-    auto kern = conv1d_splitk_kernel<MASK, 16>;
+    auto kern = conv1d_splitk_kernel<MASK, 16, LDSX>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(1024), lds, stream, L, mtiles, ntiles, per_xcd, total);
   } else if (nw == 8) {
-    hipLaunchKernelGGL((conv1d_splitk_kernel<MASK, 8>), grid, dim3(512), lds, stream, L, mtiles, ntiles, per_xcd, total);
+    auto kern = conv1d_splitk_kernel<MASK, 8, LDSX>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, L, mtiles, ntiles, per_xcd, total);
   } else {
-    hipLaunchKernelGGL((conv1d_splitk_kernel<MASK, 4>), grid, dim3(256), lds, stream, L, mtiles, ntiles, per_xcd, total);
+    auto kern = conv1d_splitk_kernel<MASK, 4, LDSX>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, ntiles, per_xcd, total);
   }
 }
 
@@ -627,8 +723,21 @@ static int launch_splitk(hipStream_t stream, const ConvLaunch& L0, int max_cout_
   const int nw = splitk_waves(L);
   if (variant_name) *variant_name = nw == 16 ? "conv1d_splitk<32x32,16w>" : (nw == 8 ? "conv1d_splitk<32x32,8w>" : "conv1d_splitk<32x32,4w>");
   const dim3 grid(per_xcd * 8);
-  if (any_mask) launch_splitk_nw<true>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total);
-  else launch_splitk_nw<false>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total);
+  // LDSX form: every problem has taps to re-use (k > 1), the staged tile fits (32 + (k-1)*dil <= SK_XP columns, <= SK_RPW rows
+  // per wave) and a lane's 32-bit byte offsets reach every element
+  bool ldsx = !g_tune_no_ldsx;
+  const int stage_rows = splitk_stage_rows(L, nw);
+  for (int i = 0; i < L.nprob; ++i)
+    if (L.p[i].k < 2 || 32 + (L.p[i].k - 1) * L.p[i].dil > SK_XP) ldsx = false;
+  if (stage_rows > SK_RPW * nw) ldsx = false;
+  if (variant_name && ldsx) *variant_name = nw == 16 ? "conv1d_splitk_ldsx<32x32,16w>" : (nw == 8 ? "conv1d_splitk_ldsx<32x32,8w>" : "conv1d_splitk_ldsx<32x32,4w>");
+  if (ldsx) {
+    if (any_mask) launch_splitk_nw<true, true>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total, stage_rows);
+    else launch_splitk_nw<false, true>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total, stage_rows);
+  } else {
+    if (any_mask) launch_splitk_nw<true, false>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total, stage_rows);
+    else launch_splitk_nw<false, false>(stream, L, nw, grid, mtiles, ntiles, per_xcd, total, stage_rows);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -139,12 +139,15 @@ __device__ __forceinline__ void hc_stage_ct(unsigned short* xs, int pitch, const
   constexpr int NWV = NT / 64;
   unsigned* xs32 = reinterpret_cast<unsigned*>(xs);
   const int p32 = pitch >> 1;
-  for (int u0 = wid; u0 < units; u0 += 4 * NWV) {
-    float a[4], b[4], m[4];
-    int dst[4];
-    bool wr[4];
+  // HQ units per thread in flight per batch: with batches of 4 a 192-channel x 132-row tile took 7 SERIAL global round trips
+  // (~4.6k cycles each under load, tools/timeline.py) — four times the MFMA time of the FFN conv it feeds
+  constexpr int HQ = 14;
+  for (int u0 = wid; u0 < units; u0 += HQ * NWV) {
+    float a[HQ], b[HQ], m[HQ];
+    int dst[HQ];
+    bool wr[HQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < HQ; ++q) {
       int u = u0 + q * NWV;
       const bool inb = u < units;
       u = inb ? u : units - 1;
@@ -162,7 +165,7 @@ __device__ __forceinline__ void hc_stage_ct(unsigned short* xs, int pitch, const
       dst[q] = r * p32 + cbk * 4 + cq;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < HQ; ++q)
       if (wr[q]) xs32[dst[q]] = h_pack(a[q] * m[q], b[q] * m[q]);
   }
 }
@@ -173,12 +176,13 @@ __device__ __forceinline__ void hc_stage_cl(unsigned short* xs, int pitch, const
                                             int c0, int ck, int Lin, int tid) {
   const int ppr = ck >> 3;
   const int total = rows * ppr;
-  for (int base = 0; base < total; base += 4 * NT) {
-    u32x4 v[4];
-    int dst[4];
-    bool ok[4], inb[4];
+  constexpr int CQ = 9;                           // 16-byte pieces per thread in flight: a 256-channel x 132-row chunk in ONE round trip
+  for (int base = 0; base < total; base += CQ * NT) {
+    u32x4 v[CQ];
+    int dst[CQ];
+    bool ok[CQ], inb[CQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < CQ; ++q) {
       int p = base + q * NT + tid;
       inb[q] = p < total;
       p = inb[q] ? p : total - 1;
@@ -190,7 +194,7 @@ __device__ __forceinline__ void hc_stage_cl(unsigned short* xs, int pitch, const
       v[q] = *reinterpret_cast<const u32x4*>(x + (int64_t)tc * cin + c0 + cb * 8);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < CQ; ++q)
       if (inb[q]) *reinterpret_cast<u32x4*>(xs + dst[q]) = ok[q] ? v[q] : u32x4{0u, 0u, 0u, 0u};
   }
 }

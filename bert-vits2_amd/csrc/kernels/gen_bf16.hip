@@ -41,19 +41,21 @@ constexpr int CL_PD = 8;          // weight prefetch ring depth (units of 4 MFMA
 
 // Stage rows [tb, tb + rows) x cin channels of up to 3 sources into LDS (pitch in elements), applying
 // pre(v) = bf16(lrelu(in_scale * sum)).  Rows outside [0, Lin) are zero (the conv's padding).
-template <int NT>
-__device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const uint16_t* s0, const uint16_t* s1,
-                                         const uint16_t* s2, int nsrc, float in_scale, bool lrelu, float slope, int tb,
-                                         int rows, int cin, int Lin, int tid) {
+// Every load of a batch is issued before the first one is used (QB pieces of 16 B per thread in flight): tools/timeline.py showed
+// the staging at three SERIAL global round trips of ~4.6k cycles each with batches of 4 — as long as the k = 11 GEMM it feeds.
+template <int NT, int QB, bool MULTI>
+__device__ __forceinline__ void cl_stage_impl(unsigned short* xs, int pitch, const uint16_t* s0, const uint16_t* s1,
+                                              const uint16_t* s2, int nsrc, float in_scale, bool lrelu, float slope, int tb,
+                                              int rows, int cin, int Lin, int tid) {
   const int ppr = cin >> 3;                       // 16-byte pieces per row
   const int total = rows * ppr;
   const bool raw = nsrc == 1 && !lrelu;
-  for (int base = 0; base < total; base += 4 * NT) {
-    u32x4 v[4][3];
-    int dst[4];
-    bool ok[4], inb[4];
+  for (int base = 0; base < total; base += QB * NT) {
+    u32x4 v[QB][MULTI ? 3 : 1];
+    int dst[QB];
+    bool ok[QB], inb[QB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QB; ++q) {
       int p = base + q * NT + tid;
       inb[q] = p < total;
       p = inb[q] ? p : total - 1;
@@ -64,11 +66,13 @@ __device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const ui
       const int64_t off = (int64_t)tc * cin + cb * 8;
       dst[q] = r * pitch + cb * 8;
       v[q][0] = *reinterpret_cast<const u32x4*>(s0 + off);
-      if (nsrc > 1) v[q][1] = *reinterpret_cast<const u32x4*>(s1 + off);
-      if (nsrc > 2) v[q][2] = *reinterpret_cast<const u32x4*>(s2 + off);
+      if (MULTI) {
+        if (nsrc > 1) v[q][1] = *reinterpret_cast<const u32x4*>(s1 + off);
+        if (nsrc > 2) v[q][2] = *reinterpret_cast<const u32x4*>(s2 + off);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QB; ++q) {
       if (!inb[q]) continue;
       u32x4 o;
       if (raw) {
@@ -77,9 +81,11 @@ __device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const ui
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           float a = bf_lo(v[q][0][w]), b = bf_hi(v[q][0][w]);
-          if (nsrc > 1) { a += bf_lo(v[q][1][w]); b += bf_hi(v[q][1][w]); }
-          if (nsrc > 2) { a += bf_lo(v[q][2][w]); b += bf_hi(v[q][2][w]); }
-          if (nsrc > 1) { a *= in_scale; b *= in_scale; }
+          if (MULTI) {
+            if (nsrc > 1) { a += bf_lo(v[q][1][w]); b += bf_hi(v[q][1][w]); }
+            if (nsrc > 2) { a += bf_lo(v[q][2][w]); b += bf_hi(v[q][2][w]); }
+            if (nsrc > 1) { a *= in_scale; b *= in_scale; }
+          }
           if (lrelu) { a = a < 0.f ? a * slope : a; b = b < 0.f ? b * slope : b; }
           o[w] = bf_pack(a, b);
         }
@@ -88,6 +94,16 @@ __device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const ui
       *reinterpret_cast<u32x4*>(xs + dst[q]) = o;
     }
   }
+}
+
+// Stage rows [tb, tb + rows) x cin channels of up to 3 sources into LDS (pitch in elements), applying
+// pre(v) = bf16(lrelu(in_scale * sum)).  Rows outside [0, Lin) are zero (the conv's padding).
+template <int NT>
+__device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const uint16_t* s0, const uint16_t* s1,
+                                         const uint16_t* s2, int nsrc, float in_scale, bool lrelu, float slope, int tb,
+                                         int rows, int cin, int Lin, int tid) {
+  if (nsrc == 1) cl_stage_impl<NT, 12, false>(xs, pitch, s0, s1, s2, nsrc, in_scale, lrelu, slope, tb, rows, cin, Lin, tid);
+  else cl_stage_impl<NT, 4, true>(xs, pitch, s0, s1, s2, nsrc, in_scale, lrelu, slope, tb, rows, cin, Lin, tid);
 }
 
 // acc[mi][ni] += sum over units u = (s, j) of Wfrag(mi, u) x B(u, ni);  B(u, ni) = 8 channels [16s + 8lh, +8) of LDS row
@@ -199,8 +215,12 @@ __device__ __forceinline__ void cl_gemm_tm(f32x16 (&acc)[MI][NI], const uint16_t
 
 // workgroup = WN x WM waves; wave (wn, wm) owns MI 32-channel output tiles starting at 32*MI*(cg*WN + wn) and NI 32-step
 // time tiles starting at t0 + 32*NI*wm
+// 4-wave workgroups (one wave per SIMD) with one 32x128 accumulator block per wave want THREE workgroups per CU (the LDS tile
+// allows it): the second launch-bounds argument (waves per SIMD) keeps the register allocation at <= 168 — without it the
+// staging batch below pushed the kernel to 178 registers and one workgroup per CU was lost
 template <int WN, int WM, int MI, int NI, int G>   // G > 0: C_in = 16*G for every problem of the launch (tap-major GEMM)
-__global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
+__global__ void __launch_bounds__(64 * WN * WM, (WN * WM == 4 && MI * NI <= 4) ? 3 : 1)
+conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
   constexpr int NT = 64 * WN * WM;
   constexpr int WT = 32 * NI;
   constexpr int BT = WM * WT;
@@ -211,6 +231,8 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid % WN, wm = wid / WN;
   const int l31 = lane & 31, lh = lane >> 5;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
+  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int b = blockIdx.y / ngrp;
   const int cg = blockIdx.y - b * ngrp;
   const int mt0 = (cg * WN + wn) * MI;
@@ -228,6 +250,7 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
                P.x[2] ? P.x[2] + (int64_t)b * P.x_bstride : nullptr, P.nsrc, P.in_scale, P.pre_lrelu != 0, P.slope,
                t0 - P.pad_left, BT + (k - 1) * dil, cin, Lin, tid);
   __syncthreads();
+  if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
   const bool active = mt0 * 32 < P.cout_pad;      // waves beyond this problem's channels still join the epilogue barriers
 
   f32x16 acc[MI][NI];
@@ -249,6 +272,7 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
                           pitch, dil);
   }
 
+  if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
   // ---- epilogue through LDS.  In the D fragment a lane holds 4 consecutive channels of ONE time step, i.e. 8-byte pieces
   // 2*C bytes apart in HBM: stored (and, for the residual, loaded) directly, every wave instruction touches 32 different
   // rows.  Instead the workgroup's output tile [BT][WGC channels] is assembled in LDS (the input tile is dead by now) and
@@ -260,12 +284,33 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
   const int wch = cout - ch0 < WGC ? cout - ch0 : WGC;             // valid channels of this workgroup (multiple of 8)
   const int rows = L.L - t0 < BT ? L.L - t0 : BT;
   const int ppr = wch >> 3;
-  __syncthreads();                                // every wave is done reading the input tile
-  if (P.res) {
-    const uint16_t* rg = P.res + (int64_t)b * P.res_bstride + (int64_t)t0 * cout + ch0;
-    for (int p = tid; p < rows * ppr; p += NT) {
+  // The residual tile's loads are ALL issued here, before the barrier (they fly while the slower waves finish their GEMM), and
+  // land in LDS after it; a piece loop that loads and stores one 16-byte piece per iteration serialises EPI_PIECES global round
+  // trips (measured: +12k cycles per workgroup on every convs2 launch).
+  constexpr int EPI_PIECES = (BT * (WGC / 8) + NT - 1) / NT;      // 16-byte pieces per thread of a full [BT][WGC] tile
+  const uint16_t* const resp = P.res;
+  u32x4 rv[EPI_PIECES];
+  if (resp) {
+    const uint16_t* rg = resp + (int64_t)b * P.res_bstride + (int64_t)t0 * cout + ch0;
+    const int npc = rows * ppr;
+#pragma unroll
+    for (int i = 0; i < EPI_PIECES; ++i) {
+      int p = tid + i * NT;
+      p = p < npc ? p : npc - 1;
       const int r = p / ppr, c = p - r * ppr;
-      *reinterpret_cast<u32x4*>(xs + r * OP + c * 8) = *reinterpret_cast<const u32x4*>(rg + (int64_t)r * cout + c * 8);
+      rv[i] = *reinterpret_cast<const u32x4*>(rg + (int64_t)r * cout + c * 8);
+    }
+  }
+  __syncthreads();                                // every wave is done reading the input tile
+  if (resp) {
+    const int npc = rows * ppr;
+#pragma unroll
+    for (int i = 0; i < EPI_PIECES; ++i) {
+      const int p = tid + i * NT;
+      if (p < npc) {
+        const int r = p / ppr, c = p - r * ppr;
+        *reinterpret_cast<u32x4*>(xs + r * OP + c * 8) = rv[i];
+      }
     }
     __syncthreads();
   }
@@ -292,7 +337,7 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
             v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
           }
           unsigned short* slot = xs + tr * OP + cl;
-          if (P.res) {
+          if (resp) {
             const u32x2 rr = *reinterpret_cast<const u32x2*>(slot);
             v0 += bf_lo(rr.x); v1 += bf_hi(rr.x); v2 += bf_lo(rr.y); v3 += bf_hi(rr.y);
           }
@@ -304,10 +349,33 @@ __global__ void __launch_bounds__(64 * WN * WM) conv_cl_bf16_kernel(const ClLaun
     }
   }
   __syncthreads();
-  uint16_t* og = P.out + (int64_t)b * P.out_bstride + (int64_t)t0 * cout + ch0;
-  for (int p = tid; p < rows * ppr; p += NT) {
-    const int r = p / ppr, c = p - r * ppr;
-    *reinterpret_cast<u32x4*>(og + (int64_t)r * cout + c * 8) = *reinterpret_cast<const u32x4*>(xs + r * OP + c * 8);
+  {
+    uint16_t* og = P.out + (int64_t)b * P.out_bstride + (int64_t)t0 * cout + ch0;
+    const int npc = rows * ppr;
+    u32x4 ov[EPI_PIECES];
+#pragma unroll
+    for (int i = 0; i < EPI_PIECES; ++i) {       // all LDS reads first, then all stores
+      int p = tid + i * NT;
+      p = p < npc ? p : npc - 1;
+      const int r = p / ppr, c = p - r * ppr;
+      ov[i] = *reinterpret_cast<const u32x4*>(xs + r * OP + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < EPI_PIECES; ++i) {
+      const int p = tid + i * NT;
+      if (p < npc) {
+        const int r = p / ppr, c = p - r * ppr;
+        *reinterpret_cast<u32x4*>(og + (int64_t)r * cout + c * 8) = ov[i];
+      }
+    }
+  }
+  if (L.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* d = L.dbg + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+    d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    d[6] = (unsigned long long)k; d[7] = 1;
   }
 }
 
@@ -328,7 +396,13 @@ static int launch_cl_variant(hipStream_t stream, const ClLaunch& L, int nt, size
   dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
   auto kern = conv_cl_bf16_kernel<WN, WM, MI, NI, G>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WN * WM), lds, stream, L, ngrp);
+  ClLaunch Lt = L;
+  {
+    int ks = 0;
+    for (int i = 0; i < L.nprob && i < 3; ++i) ks |= (L.p[i].k & 255) << (8 * i);
+    Lt.dbg = timeline_slice(grid.x, grid.y, grid.z, -(WN * 1000 + WM * 100 + MI * 10 + NI), ks, cin, L.L);   // negative tile id: bf16
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WN * WM), lds, stream, Lt, ngrp);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -93,6 +93,7 @@ class SynthesizerTrn(nn.Module):
         self.generator_dtype = torch.float32
         self.flow_dtype = torch.float32
         self._graphs_on = False
+        self._graphs_static = False
         self._graphs: Dict[tuple, dict] = {}
         self._cap_stream = None
 
@@ -233,13 +234,18 @@ class SynthesizerTrn(nn.Module):
         return self._ws
 
     # ------------------------------------------------------------------ hipGraph replay of the two phases
-    def enable_graphs(self, on: bool = True) -> None:
+    def enable_graphs(self, on: bool = True, static_io: bool = False) -> None:
         """Record each phase once per shape as a hipGraph (``bv2_graph_capture_*``) and replay it on later calls: one
-        ``hipGraphLaunch`` per phase instead of ~270 kernel launches.  Inputs are copied into buffers the graph owns, so
-        results are identical to the eager path; outputs are returned as fresh tensors."""
+        ``hipGraphLaunch`` per phase instead of ~230 kernel launches.  Default: inputs are copied into buffers the graph owns and
+        outputs are returned as fresh tensors, so the call behaves exactly like the eager one.
+
+        ``static_io=True`` (serving loops): no staging copies — a graph is recorded reading the caller's input tensors IN PLACE
+        (it is re-recorded when a tensor with another address shows up; up to 16 recordings are cached) and the returned tensors
+        are the graph's own output buffers, valid until the next call with the same shapes.  Only the two noise draws still move:
+        the CPU draw of models.py:248-251 is uploaded into the graph's buffer, the device draw of :1071 is made in place."""
         self._graphs_on = bool(on)
-        if not on:
-            self._drop_graphs()
+        self._graphs_static = bool(on and static_io)
+        self._drop_graphs()
 
     def _drop_graphs(self) -> None:
         graphs, self._graphs = getattr(self, "_graphs", {}), {}
@@ -309,8 +315,11 @@ class SynthesizerTrn(nn.Module):
             ins = dict(x=x, x_lengths=x_lengths, sid=sid, tone=tone, language=language, bert=bert, ja_bert=ja_bert,
                        en_bert=en_bert, noise_w=noise_w)
 
+            static = self._graphs_static
+            staged = ("noise_w",) if static else tuple(ins)     # static_io: everything but the noise is read in place
+
             def build():
-                sin = {k: torch.empty_like(v) for k, v in ins.items()}
+                sin = {k: (torch.empty_like(v) if k in staged else v) for k, v in ins.items()}
                 sout = mk_out()
                 ein = L.EncodeIn(B, T, *[_ptr(sin[k]) for k in ("x", "x_lengths", "sid", "tone", "language", "bert", "ja_bert",
                                                                 "en_bert", "noise_w")],
@@ -321,12 +330,15 @@ class SynthesizerTrn(nn.Module):
                                       C.c_void_p(ws.data_ptr()), ws.numel())
                 return dict(graph=g, sin=sin, sout=sout)
 
-            ent = self._graph_entry(("A", B, T, float(noise_scale_w), float(sdp_ratio), float(length_scale)), build)
-            for k, v in ins.items():
-                ent["sin"][k].copy_(v)
+            ptrs = tuple(ins[k].data_ptr() for k in ins if k not in staged)
+            ent = self._graph_entry(("A", B, T, float(noise_scale_w), float(sdp_ratio), float(length_scale), ptrs), build)
+            for k in staged:
+                ent["sin"][k].copy_(ins[k], non_blocking=True)
             with torch.cuda.device(dev):
                 if self._lib.bv2_graph_launch(ent["graph"], C.c_void_p(torch.cuda.current_stream().cuda_stream)):
                     raise RuntimeError("bv2_graph_launch (encode) failed")
+            if static:
+                return dict(ent["sout"])
             return {k: v.clone() for k, v in ent["sout"].items()}
         out = mk_out()
         ein = L.EncodeIn(B, T, _ptr(x), _ptr(x_lengths), _ptr(sid), _ptr(tone), _ptr(language), _ptr(bert), _ptr(ja_bert),
@@ -349,7 +361,9 @@ class SynthesizerTrn(nn.Module):
         hp = self.hp
         B, _, T = enc["x"].shape
         Ci = hp.inter_channels
-        assert noise_z.is_cuda and noise_z.dtype == torch.float32 and noise_z.shape[2] >= Ty and noise_z.shape[1] == Ci
+        draw_z = noise_z is None                        # infer(): draw #2 straight into the graph's buffer (static_io)
+        if not draw_z:
+            assert noise_z.is_cuda and noise_z.dtype == torch.float32 and noise_z.shape[2] >= Ty and noise_z.shape[1] == Ci
         L_dec = Ty if (max_len is None or max_len <= 0 or max_len >= Ty) else int(max_len)
         S = L_dec * hp.total_upsample
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -360,9 +374,12 @@ class SynthesizerTrn(nn.Module):
             ws = self._workspace(B, T, Ty)
             ikeys = ("m_p", "logs_p", "x_mask", "w_ceil", "y_lengths", "g")
 
+            static = self._graphs_static
+
             def build():
-                sin = {k: torch.empty_like(enc[k]) for k in ikeys}
-                sin["noise_z"] = torch.empty(B, Ci, Ty, dtype=torch.float32, device=dev)
+                sin = {k: (enc[k] if static else torch.empty_like(enc[k])) for k in ikeys}
+                # the reference's strides for the prior noise (draw_noise_z): an in-place normal_() on it IS randn_like(m_p)
+                sin["noise_z"] = torch.empty(B, Ty, Ci, dtype=torch.float32, device=dev).transpose(1, 2)
                 sout = mk_out()
                 din = L.DecodeIn(B, T, int(Ty), int(L_dec), *[_ptr(sin[k]) for k in ikeys], _ptr(sin["noise_z"]),
                                  sin["noise_z"].stride(0), sin["noise_z"].stride(1), sin["noise_z"].stride(2),
@@ -373,14 +390,24 @@ class SynthesizerTrn(nn.Module):
                                       C.c_void_p(ws.data_ptr()), ws.numel())
                 return dict(graph=g, sin=sin, sout=sout)
 
-            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale), bool(exact_lengths)), build)
-            for k in ikeys:
-                ent["sin"][k].copy_(enc[k])
-            ent["sin"]["noise_z"].copy_(noise_z[:, :, :Ty])
+            ptrs = tuple(enc[k].data_ptr() for k in ikeys) if static else ()
+            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale), bool(exact_lengths), ptrs),
+                                    build)
+            if not static:
+                for k in ikeys:
+                    ent["sin"][k].copy_(enc[k])
+            if draw_z:
+                ent["sin"]["noise_z"].normal_()
+            else:
+                ent["sin"]["noise_z"].copy_(noise_z[:, :, :Ty])
             with torch.cuda.device(dev):
                 if self._lib.bv2_graph_launch(ent["graph"], C.c_void_p(torch.cuda.current_stream().cuda_stream)):
                     raise RuntimeError("bv2_graph_launch (decode) failed")
+            if static:
+                return dict(ent["sout"])
             return {k: (None if v is None else v.clone()) for k, v in ent["sout"].items()}
+        if draw_z:
+            noise_z = draw_noise_z(B, Ci, Ty, dev)
         out = mk_out()
         din = L.DecodeIn(B, T, int(Ty), int(L_dec), _ptr(enc["m_p"]), _ptr(enc["logs_p"]), _ptr(enc["x_mask"]),
                          _ptr(enc["w_ceil"]), _ptr(enc["y_lengths"]), _ptr(enc["g"]), _ptr(noise_z),
@@ -416,9 +443,7 @@ class SynthesizerTrn(nn.Module):
             enc["w_ceil"] = wc
             enc["y_lengths"] = torch.clamp_min(wc.sum(1), 1).long()
         Ty = int(enc["y_lengths"].max().item())        # the reference's one host sync (commons.py:120-122)
-        if noise_z is None:
-            noise_z = draw_noise_z(B, self.hp.inter_channels, Ty, dev)
-        else:
+        if noise_z is not None:                        # None: decode() draws it (in place in the graph's buffer when replaying)
             noise_z = noise_z.to(dev, torch.float32)
         dec = self.decode(enc, noise_z, Ty, noise_scale=noise_scale, max_len=max_len, want_attn=want_attn,
                           exact_lengths=exact_lengths)

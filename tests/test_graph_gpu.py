@@ -64,3 +64,39 @@ def test_capture_refuses_default_stream_and_taps():
     _run(m, batch, nw, nz, kw)
     assert len(m._graphs) == 0 and float(t.abs().sum()) > 0
     m.set_tap(None)
+
+
+def test_static_io_replay_reads_inputs_in_place_and_matches_eager():
+    """enable_graphs(static_io=True): no staging copies — the graph reads the caller's tensors in place and hands out its own output
+    buffers; the device draw of models.py:1071 is made in place with the reference's strides (seeded run == seeded eager run)."""
+    hp, seed, batch, nw, nz, kw = cases.build_case("mix_b2_ragged")
+    m = _model(hp, seed)
+    args = [batch[k].cuda() for k in ("x", "x_lengths", "sid", "tone", "language", "bert", "ja_bert", "en_bert")]
+    torch.manual_seed(11)
+    eager = m.infer(*args, **kw)
+    e_o, e_z = eager[0].clone(), eager[3][0].clone()
+    m.enable_graphs(True, static_io=True)
+    torch.manual_seed(11)
+    o1 = m.infer(*args, **kw)[0]
+    assert torch.equal(o1, e_o)
+    n_graphs = len(m._graphs)
+    torch.manual_seed(11)
+    o2, _, _, (z2, *_r) = m.infer(*args, **kw)            # pure replay on the same tensors: no new recording
+    assert len(m._graphs) == n_graphs and torch.equal(o2, e_o) and torch.equal(z2, e_z)
+    assert o2.data_ptr() == o1.data_ptr()                 # the graph's own output buffer
+    # new CONTENT in the same input tensors is followed (read in place) ...
+    args[5].mul_(0.5)
+    torch.manual_seed(11)
+    o3 = m.infer(*args, **kw)[0].clone()
+    m.enable_graphs(False)
+    torch.manual_seed(11)
+    assert torch.equal(m.infer(*args, **kw)[0], o3) and not torch.equal(o3, e_o)
+    # ... and a tensor at ANOTHER address triggers a new recording instead of reading stale memory
+    m.enable_graphs(True, static_io=True)
+    torch.manual_seed(11)
+    m.infer(*args, **kw)
+    n1 = len(m._graphs)
+    args2 = [a.clone() for a in args]
+    torch.manual_seed(11)
+    o4 = m.infer(*args2, **kw)[0]
+    assert len(m._graphs) > n1 and torch.equal(o4, o3)

@@ -285,3 +285,36 @@ def test_spline_inverse_kernel():
     torch.cuda.synchronize()
     assert (zd[:, 1].cpu().double() - ref1).abs().max().item() < 2e-5
     assert torch.equal(zd[:, 0].cpu(), z[:, 0] * mask)
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,L,ksplit", [(192, 768, 5, 1, 384, 1), (768, 192, 5, 1, 384, 8), (192, 768, 3, 1, 128, 1),
+                                                     (768, 192, 3, 1, 77, 4), (64, 64, 7, 3, 300, 1), (48, 40, 3, 2, 50, 1),
+                                                     (192, 512, 7, 1, 384, 1), (256, 256, 3, 1, 128, 2)])
+def test_splitk_lds_staged_form_is_bit_identical_to_the_register_form(cin, cout, k, dil, L, ksplit):
+    """The split-K kernel's LDSX form (X tile staged once in LDS, all taps read it back) runs the same MFMA sequence on the same
+    operand values as the form that re-loads X per tap from global memory: results must be bitwise equal (and right)."""
+    lib = _lib()
+    lib.bv2_test_set_tuning.argtypes = [C.c_int, C.c_int, C.c_long]
+    lib.bv2_test_set_tuning.restype = None
+    B = 2
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias = torch.randn(cout, generator=g)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, max(1, L - 9)])[:, None]).float()
+    xd, md = x.cuda(), mask.cuda()
+    wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
+    outs = []
+    for tune in (0, 100):
+        lib.bv2_test_set_tuning(tune, 0, 0)
+        slab = B * cout * L
+        out = torch.full((ksplit, B, cout, L), float("nan"), device="cuda")
+        rc = lib.bv2_test_conv1d(None, P(xd), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, 6, 0.1, 0, None, 0,
+                                 P(md), None, 0, 0, None, 1, None, None, 1.0, ksplit, slab)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append(out.sum(0))
+    lib.bv2_test_set_tuning(0, 0, 0)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv1d(F.leaky_relu(x.double(), 0.1) * mask.double()[:, None], w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil)
+    assert rel_err(outs[0], ref) < 2e-5

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--symbols", type=int, default=128)
+    ap.add_argument("--bf16", action="store_true", help="bf16 Generator + fp16 flow (configs 3 / 5)")
     a = ap.parse_args()
     lib = L.load()
     lib.bv2_test_conv_timeline.argtypes = [C.c_void_p, C.c_longlong]
@@ -34,13 +35,16 @@ def main():
     m = models.from_hparams(hp)
     m.load_state_dict(synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5), strict=False)
     m = m.to("cuda").eval()
+    if a.bf16:
+        m.set_generator_dtype(torch.bfloat16)
+        m.set_flow_dtype(torch.float16)
     b = {k: v.cuda() for k, v in synth.synthetic_batch([a.symbols] * a.batch).items()}
     kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
     call = lambda: m.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"], **kw)
     for _ in range(3):
         call()
     torch.cuda.synchronize()
-    cap = 16 * 1024 * 1024
+    cap = 48 * 1024 * 1024
     buf = torch.zeros(cap, dtype=torch.int64, device="cuda")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lib.bv2_test_conv_timeline(C.c_void_p(buf.data_ptr()), cap)

@@ -41,6 +41,22 @@ def main():
         bm, bn = tile // 1000, tile % 1000
         kk = [(ks >> (8 * j)) & 255 for j in range(3) if (ks >> (8 * j)) & 255]
         line = f"#{i:3d} {bm}x{bn} k={kk} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU), span {span:9.0f} (per-XCD {min(spans)}..{max(spans)})"
+        if tile < 0:
+            # bf16 channels-last conv: tile id -(WN*1000 + WM*100 + MI*10 + NI); MFMA cycles per wave = (cin/16)*k units * MI*NI * 32
+            t = -tile
+            wn, wm, mi, ni = t // 1000, (t // 100) % 10, (t // 10) % 10, t % 10
+            print(f"#{i:3d} bf16 {wn}x{wm} MI{mi} NI{ni} k={kk} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.1f}/CU)")
+            tot = 0.0
+            for k in kk:
+                m = v[:, 6] == k
+                if not m.any():
+                    continue
+                cyc = (cin / 16) * k * mi * ni * 32
+                tot += m.sum() * cyc * (wn * wm / 4.0)
+                lo = v[m, 2] - v[m, 1]
+                print(f"      k{k}: n {m.sum()} stage {np.mean(v[m, 1] - v[m, 0]):7.0f} gemm {lo.mean():8.0f} (MFMA-only {cyc:7.0f}, x{lo.mean() / cyc:4.2f}) "
+                      f"epilogue {np.mean(v[m, 3] - v[m, 2]):7.0f}  life {np.mean(v[m, 3] - v[m, 0]):8.0f}")
+            continue
         if tile != 32032:
             # MFMA cycles per wave of a workgroup of problem p: (cin/8 groups) * k taps * 4 MFMAs * (MI*NI) * 64 cycles; waves = 4
             mi_ni = (bm // 64) * (bn // 64) if bm >= 64 and bn >= 64 else (1 if bm * bn <= 32 * 128 else 2)
