@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="Generator arithmetic (overrides the config's)")
     ap.add_argument("--flow-dtype", choices=("f32", "f16"), default=None, help="transformer-flow conv arithmetic (overrides the config's)")
     ap.add_argument("--graph", type=int, default=None, choices=(0, 1), help="replay each phase as a captured hipGraph")
+    ap.add_argument("--residual-flow", action="store_true",
+                    help="the ResidualCouplingBlock / WN flow (use_transformer_flow=false) instead of the transformer flow; fp32 flow only")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the secondary configs 3 / 4 / 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
@@ -212,7 +214,8 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     use_graph = bool(cfg["graph"]) if overrides.get("graph") is None else bool(overrides["graph"])
     model.enable_graphs(False)
     model.set_generator_dtype(torch.bfloat16 if gen_dtype == "bf16" else torch.float32)
-    model.set_flow_dtype(torch.float16 if flow_dtype == "f16" else torch.float32)
+    if hp.use_transformer_flow:
+        model.set_flow_dtype(torch.float16 if flow_dtype == "f16" else torch.float32)
     batch, lengths = make_batch(cfg, B, T, rank)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
     call = lambda b=dbatch: model.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"],
@@ -305,7 +308,8 @@ def describe(res, hp, world):
             f"{'fp16 flow convs (fp32 accumulate / LayerNorm / softmax)' if fd == 'f16' else 'fp32 flow'}, "
             f"fp32 text encoder / durations / spline, T_y={res['Ty']} frames "
             f"({res['Ty'] * hp.total_upsample} samples, {res['Ty'] * hp.total_upsample / hp.sampling_rate:.3f} s) per padded utterance, "
-            f"transformer flow, synthetic seeded weights, durations pinned to 3 frames/symbol, hipGraph={'on' if res['graph'] else 'off'}")
+            f"{'transformer' if hp.use_transformer_flow else 'residual (WN)'} flow, synthetic seeded weights, durations pinned to 3 frames/symbol, "
+            f"hipGraph={'on' if res['graph'] else 'off'}")
 
 
 def summary(res, hp, world, dt=None, audio=None):
@@ -346,9 +350,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)     # RCCL
 
-    hp = H.default_v23()
+    hp = H.default_v23(use_transformer_flow=not args.residual_flow)
     primary = args.config if args.config is not None else (2 if world == 1 else 4)
     overrides = dict(batch=args.batch, symbols=args.symbols, dtype=args.dtype, flow=args.flow_dtype, graph=args.graph)
+    if args.residual_flow:
+        overrides["flow"] = "f32"                     # the WN flow has no fp16 form (bv2_set_flow_dtype returns -2)
 
     # ---- weights: rank 0 folds/packs the seeded synthetic checkpoint, every other rank receives the blob over RCCL
     model = models.from_hparams(hp)
@@ -373,7 +379,7 @@ def main():
         audio = float(atot.item())
 
     secondary = {}
-    if world == 1 and rank == 0 and not args.no_secondary and args.config is None:
+    if world == 1 and rank == 0 and not args.no_secondary and args.config is None and not args.residual_flow:
         for num in (3, 4, 5):
             try:
                 r = run_config(num, model, hp, dev, 0, 1, max(5, min(args.steps, 10)), 3, {})

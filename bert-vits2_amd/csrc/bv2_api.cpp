@@ -198,6 +198,10 @@ int bv2_encode_durations(bv2_handle* h, bv2_stream stream, const bv2_encode_in* 
   if (!in->x || !in->x_lengths || !in->sid || !in->tone || !in->language || !in->bert || !in->ja_bert || !in->en_bert ||
       !in->noise_w || !out->g || !out->x || !out->m_p || !out->logs_p || !out->x_mask || !out->logw || !out->w_ceil ||
       !out->y_lengths) { h->err = "bv2_encode_durations: null tensor pointer"; return -1; }
+  for (int f = 0; f < 3; ++f)
+    if (in->bert_index[f] && (in->bert_cols[f] < 1 || in->bert_cols[f] > in->T)) {
+      h->err = "bv2_encode_durations: bert_cols must be in [1, T] for a word-level feature"; return -1;
+    }
   return run_encode(h, static_cast<hipStream_t>(stream), *in, *out, ws, wsb);
   BV2_CATCH(h)
 }

@@ -322,7 +322,7 @@ PlanA plan_a(Arena& A, const Model& m, int B, int T) {
 }
 
 struct PlanB {
-  float *gv, *zp, *z, *h, *xin, *acts, *rs, *outacc, *pre, *ymask;
+  float *gv, *zp, *z, *h, *acts, *outacc, *pre, *ymask;
   int* fidx;
   EncBufs enc;
   float* set[2][7];
@@ -358,9 +358,7 @@ PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
     p.enc.qkv = A.get<float>((int64_t)B * qkv_rows(m.coupling[0].enc) * attn_ld(Ty));
     p.enc.f1 = A.get<float>(BT * c.filter_channels);
   } else {
-    p.xin = A.get<float>(BT * 2 * H);
     p.acts = A.get<float>(BT * H);
-    p.rs = A.get<float>(BT * 2 * H);
     p.outacc = A.get<float>(BT * H);
   }
   p.pre = A.get<float>(BT * c.upsample_initial_channel);
@@ -403,7 +401,8 @@ static void run_front(Ctx& c, const int64_t* sid, const float* g_in, float* g_ou
 // TextEncoder (reference models.py:377-400).  dp0/dp_c: the DurationPredictor's `x + cond(g)` input rides on the last LayerNorm.
 static void enc_p_core(Ctx& c, PlanA& P, const int64_t* x, const int64_t* tone, const int64_t* lang, const float* const* berts,
                        const float* mask, const float* spk, int spk_stride, int B, int T, float* out_x, float* out_m,
-                       float* out_logs, float* dp0, const float* dp_c) {
+                       float* out_logs, float* dp0, const float* dp_c, const int32_t* const* bert_index = nullptr,
+                       const int32_t* bert_cols = nullptr) {
   const Model& m = c.m;
   const bv2_config& cf = m.cfg;
   const int H = cf.hidden_channels;
@@ -414,7 +413,15 @@ static void enc_p_core(Ctx& c, PlanA& P, const int64_t* x, const int64_t* tone, 
     ConvLaunch cl;
     cl.nprob = 3; cl.B = B; cl.L = T;
     cl.ksplit = 1; cl.slab_stride = P.slab;
-    for (int i = 0; i < 3; ++i) cl.p[i] = c.prob(m.bert[i], berts[i], P.bsum, T);
+    for (int i = 0; i < 3; ++i) {
+      cl.p[i] = c.prob(m.bert[i], berts[i], P.bsum, T);
+      if (bert_index && bert_index[i]) {
+        // word-level feature [B, 1024, S]: the projection runs over its S columns (reads past S are the conv's zero padding);
+        // the embed kernel gathers column bert_index[b][t] of the result for symbol t
+        const int S = bert_cols[i];
+        cl.p[i].x_bstride = (int64_t)m.bert[i].cin * S; cl.p[i].x_rstride = S; cl.p[i].Lin = S;
+      }
+    }
     const int ks = conv_use_splitk(cl) ? conv_pick_ksplit(cl, kSlabs / 2) : 1;
     for (int i = 0; i < 3; ++i) cl.p[i].out = P.bsum + (int64_t)i * ks * P.slab;
     c.conv(cl, "enc_p.bert_proj", ks > 1 ? ks : 1, P.slab);
@@ -428,6 +435,7 @@ static void enc_p_core(Ctx& c, PlanA& P, const int64_t* x, const int64_t* tone, 
     e.n_vocab = cf.n_vocab; e.n_tones = cf.n_tones; e.n_langs = cf.n_languages;
     e.bsum = P.bsum; e.nslab = bert_slabs; e.slab_stride = P.slab;
     e.mask = mask; e.out = out_x; e.scale = (float)std::sqrt((double)H); e.B = B; e.C = H; e.T = T;
+    for (int i = 0; i < 3; ++i) e.idx[i] = bert_index ? bert_index[i] : nullptr;
     c.chk(launch_embed(c.s, e), "embed");
   }
   c.tap("enc.x0", out_x, (int64_t)B * H * T);
@@ -541,7 +549,8 @@ int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_
     run_front(c, in.sid, nullptr, out.g, gw, go, 3, 3 * H, in.x_lengths, out.x_mask, B, T, in.noise_w, P.z, in.noise_scale_w);
   }
   const float* berts[3] = {in.bert, in.ja_bert, in.en_bert};
-  enc_p_core(c, P, in.x, in.tone, in.language, berts, mask, spk, 3 * H, B, T, out.x, out.m_p, out.logs_p, P.dp0, dp_c);
+  enc_p_core(c, P, in.x, in.tone, in.language, berts, mask, spk, 3 * H, B, T, out.x, out.m_p, out.logs_p, P.dp0, dp_c,
+             in.bert_index, in.bert_cols);
   float* logw_dp = out.logw_dp ? out.logw_dp : P.logw_dp;
   dp_core(c, P, P.dp0, mask, B, T, logw_dp);
   sdp_core(c, P, out.x, mask, sdp_c, 3 * H, B, T);
@@ -628,14 +637,26 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
     } else {
       const int nl = K.wn_layers;
       const float* gl = gv_flow + (int64_t)a * 2 * H * nl;
+      // WN.forward (modules.py:185-210), 2 launches per layer: in_layer + g_l + gate (ACT_GATE epilogue), then res_skip as two
+      // problems of one launch — x = (x + rs[:H]) * mask in place, output += rs[H:] (first layer: =; last layer: all H rows, * mask)
       for (int i = 0; i < nl; ++i) {
-        p = c.prob(K.wn_in[i], P.h, P.xin, Ty);
+        const bool last = i == nl - 1;
+        p = c.prob(K.wn_in[i], P.h, P.acts, Ty);
         p.bias2 = gl + (int64_t)i * 2 * H; p.bias2_bstride = P.gv_stride;
-        c.conv1(p, B, Ty, "wn.in");
-        c.chk(launch_wn_gate(c.s, P.xin, P.acts, B, H, Ty), "wn.gate");
-        p = c.prob(K.wn_rs[i], P.acts, P.rs, Ty);
-        c.conv1(p, B, Ty, "wn.res_skip");
-        c.chk(launch_wn_res_skip(c.s, P.rs, P.h, P.outacc, ymask, B, H, Ty, i == nl - 1, i == 0), "wn.rs");
+        p.act = ACT_GATE; p.out_bstride = (int64_t)H * Ty;
+        c.conv1(p, B, Ty, "wn.in+gate");
+        ConvLaunch cl;
+        cl.B = B; cl.L = Ty; cl.nprob = 0;
+        if (!last) {
+          ConvProb r = c.prob(K.wn_res[i], P.acts, P.h, Ty);
+          r.res = P.h; r.res_mode = RES_ADD; r.out_mask = ymask; r.mask_post = 1;
+          cl.p[cl.nprob++] = r;
+        }
+        ConvProb sk = c.prob(K.wn_skip[i], P.acts, P.outacc, Ty);
+        if (i > 0) { sk.res = P.outacc; sk.res_mode = RES_ADD; }
+        if (last) { sk.out_mask = ymask; sk.mask_post = 1; }
+        cl.p[cl.nprob++] = sk;
+        c.conv(cl, "wn.res_skip");
       }
       hres = P.outacc;
     }

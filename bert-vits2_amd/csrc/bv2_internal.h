@@ -54,7 +54,8 @@ struct CouplingW {
   ConvW pre, post;
   EncoderW enc;                      // transformer flow
   GemvW wn_cond;                     // residual (WN) flow
-  ConvW wn_in[kMaxLayers], wn_rs[kMaxLayers];
+  ConvW wn_in[kMaxLayers];             // rows in gate order (ACT_GATE): per 32-row tile 16 tanh rows then their 16 sigmoid rows
+  ConvW wn_res[kMaxLayers], wn_skip[kMaxLayers];   // res_skip_layers split into its x-update rows and its output rows
   int wn_layers = 0;
 };
 

@@ -23,7 +23,10 @@ namespace bv2 {
 // (blockIdx.z) that share B and L: the three ResBlock branches of a Generator stage, the u polyphase branches of a
 // ConvTranspose1d, or the m_p / logs_p halves of enc_p.proj.
 enum { PRE_NONE = 0, PRE_LRELU = 1 };
-enum { ACT_NONE = 0, ACT_RELU = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GATE = 2 };
+// ACT_GATE (WN, reference commons.py:98-105): the GEMM rows come packed so that rows [0,16) of every 32-row tile are the tanh half and
+// rows [16,32) the sigmoid half of the same 16 channels (bv2_model.cpp wn_gate_row); the epilogue writes
+// out[16*mt + j] = tanh(v[j]) * sigmoid(v[j+16]) — `out` has cout/2 rows.  No residual / masks with it.
 enum { RES_NONE = 0, RES_ADD = 1, RES_RSUB = 2 };   // v += res  |  v = res - v
 
 struct ConvProb {
@@ -287,6 +290,9 @@ struct EmbedArgs {
   int n_vocab, n_tones, n_langs;
   const float* bsum; int nslab; int64_t slab_stride;   // bsum = sum of nslab partial slabs of the BERT projections
   const float* mask; float* out; float scale; int B, C, T;
+  // word-level features: slab s belongs to feature s / (nslab/3); with idx[f] set, symbol t reads column idx[f][b*T + t] of that
+  // feature's slabs (the word2ph repeat of text/chinese_bert.py:48-58 as a gather); null = column t
+  const int32_t* idx[3];
 };
 int launch_embed(hipStream_t stream, const EmbedArgs& a);
 
@@ -351,13 +357,6 @@ struct ExpandArgs {
   int B, C, T, Ty;
 };
 int launch_expand(hipStream_t stream, const ExpandArgs& a);
-
-// --- WN gate / res-skip (reference commons.py:98-105, modules.py:192-210) ---
-// acts[b][c][t] = tanh(xin[b][c][t]) * sigmoid(xin[b][c+H][t])        (g_l already added by the conv's bias2)
-int launch_wn_gate(hipStream_t stream, const float* xin, float* acts, int B, int H, int T);
-// not last: x = (x + rs[:, :H]) * mask ; outacc (+)= rs[:, H:]   | last: outacc (+)= rs ; finally outacc *= mask
-int launch_wn_res_skip(hipStream_t stream, const float* rs, float* x, float* outacc, const float* mask,
-                       int B, int H, int T, int last, int first);
 
 // --- 16-bit PCM of the valid samples, peak-normalised per utterance (gradio convert_to_16_bit_wav, reference webui.py:86) ---
 int launch_pcm16(hipStream_t stream, const float* wave, int64_t bstride, const int64_t* y_lengths, int hop, int B, int64_t S,

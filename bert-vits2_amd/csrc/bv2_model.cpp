@@ -164,7 +164,7 @@ struct Packer {
 
   // plain nn.Conv1d `p` ([cout][cin][k] + bias), optional row range / channel permutations
   ConvW conv1d(const std::string& p, int cout, int cin, int k, bool bias = true, bool wn = false, int row0 = 0,
-               int rows = -1, bool rev_in = false, bool rev_out = false) {
+               int rows = -1, bool rev_in = false, bool rev_out = false, const std::function<int(int)>* rowmap = nullptr) {
     if (rows < 0) rows = cout;
     std::vector<float> w;
     const HostTensor* wt = nullptr;
@@ -177,15 +177,16 @@ struct Packer {
     const HostTensor* bt = bias ? get(p + ".bias", {cout}) : nullptr;
     if (bias && fill() && !bt) ok = false;
     auto src = [&](int co, int ci, int j) {
-      const int sco = row0 + (rev_out ? rows - 1 - co : co);
+      const int sco = rowmap ? (*rowmap)(co) : row0 + (rev_out ? rows - 1 - co : co);
       const int sci = rev_in ? cin - 1 - ci : ci;
       return wd[((int64_t)sco * cin + sci) * k + j];
     };
-    auto bsrc = [&](int co) { return bt->data[row0 + (rev_out ? rows - 1 - co : co)]; };
+    auto bsrc = [&](int co) { return bt->data[rowmap ? (*rowmap)(co) : row0 + (rev_out ? rows - 1 - co : co)]; };
     return conv(rows, cin, k, bias, src, bsrc, ok);
   }
 
-  GemvW gemv(const std::string& p, int cout, int cin, bool conv_shape, bool wn = false) {
+  GemvW gemv(const std::string& p, int cout, int cin, bool conv_shape, bool wn = false,
+             const std::function<int(int)>* rowmap = nullptr) {      // rowmap: packed row r is source row (*rowmap)(r)
     GemvW g; g.cout = cout; g.cin = cin;
     g.w_off = alloc((int64_t)cout * cin);
     g.b_off = alloc(cout);
@@ -195,8 +196,12 @@ struct Packer {
       if (wn) { if (folded(p, cout, cin, 1, w)) wd = w.data(); }
       else if (conv_shape) { if (auto* t = get(p + ".weight", {cout, cin, 1})) wd = t->data.data(); }
       else { if (auto* t = get(p + ".weight", {cout, cin})) wd = t->data.data(); }
-      if (wd) std::memcpy(blob + g.w_off, wd, sizeof(float) * (size_t)cout * cin);
-      if (auto* b = get(p + ".bias", {cout})) std::memcpy(blob + g.b_off, b->data.data(), sizeof(float) * cout);
+      const HostTensor* b = get(p + ".bias", {cout});
+      for (int r = 0; r < cout; ++r) {
+        const int sr = rowmap ? (*rowmap)(r) : r;
+        if (wd) std::memcpy(blob + g.w_off + (int64_t)r * cin, wd + (int64_t)sr * cin, sizeof(float) * (size_t)cin);
+        if (b) blob[g.b_off + r] = b->data[sr];
+      }
     }
     return g;
   }
@@ -333,11 +338,23 @@ int pack_all(Model& m, Packer& P) {
     } else {
       const int nl = c.n_flow_layer;
       C.wn_layers = nl;
-      C.wn_cond = P.gemv(p + ".enc.cond_layer", 2 * hid * nl, gin, true, /*wn=*/true);
+      // WN gate (commons.py:98-105: tanh(first half) * sigmoid(second half)) fused into in_layer's epilogue (ACT_GATE): rows are
+      // packed so that every 32-row tile holds the tanh rows of 16 channels followed by their sigmoid rows; the conditioning
+      // slice g_l (cond_layer rows [2H*i, 2H*(i+1)), modules.py:189-197) is permuted the same way
+      const std::function<int(int)> gate_row = [hid](int n) { const int mt = n / 32, j = n % 32; return j < 16 ? 16 * mt + j : hid + 16 * mt + (j - 16); };
+      const std::function<int(int)> cond_row = [hid, &gate_row](int n) { return (n / (2 * hid)) * 2 * hid + gate_row(n % (2 * hid)); };
+      C.wn_cond = P.gemv(p + ".enc.cond_layer", 2 * hid * nl, gin, true, /*wn=*/true, &cond_row);
       for (int i = 0; i < nl; ++i) {
-        C.wn_in[i] = P.conv1d(p + ".enc.in_layers." + std::to_string(i), 2 * hid, hid, kFlowKernel, true, true);
-        const int rs = i < nl - 1 ? 2 * hid : hid;
-        C.wn_rs[i] = P.conv1d(p + ".enc.res_skip_layers." + std::to_string(i), rs, hid, 1, true, true);
+        const std::string rsn = p + ".enc.res_skip_layers." + std::to_string(i);
+        C.wn_in[i] = P.conv1d(p + ".enc.in_layers." + std::to_string(i), 2 * hid, hid, kFlowKernel, true, true, 0, -1, false, false, &gate_row);
+        // res_skip (modules.py:203-210): rows [0,H) update x, rows [H,2H) accumulate into the output; the last layer has H rows,
+        // all of them output.  Two problems of ONE launch, each with its own residual target (no separate res/skip kernel).
+        if (i < nl - 1) {
+          C.wn_res[i] = P.conv1d(rsn, 2 * hid, hid, 1, true, true, 0, hid);
+          C.wn_skip[i] = P.conv1d(rsn, 2 * hid, hid, 1, true, true, hid, hid);
+        } else {
+          C.wn_skip[i] = P.conv1d(rsn, hid, hid, 1, true, true);
+        }
       }
     }
     C.post = P.conv1d(p + ".post", half, hid, 1, true, false, 0, -1, false, /*rev_out=*/C.flipped);

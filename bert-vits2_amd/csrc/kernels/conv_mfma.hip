@@ -297,6 +297,17 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
         const bool colok = col < Lout;
         const int colc = colok ? col : Lout - 1;
         const float om = omaskp ? omaskp[colc] : 1.f;
+        if (act == ACT_GATE) {                     // fused_add_tanh_sigmoid_multiply: rows r and r + 8 of a lane are a (tanh, sigmoid) pair
+          const unsigned goff0 = (unsigned)((row0 - 4 * lh) / 2 + 4 * lh) * o_rs + (unsigned)colc * o_ts + o_to;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const float a = acc[mi][ni][r] + bs[r], sg = acc[mi][ni][r + 8] + bs[r + 8];
+            const float v = tanhf(a) * (1.f / (1.f + expf(-sg)));
+            if (colok && row0 + dr + 16 < cout) outb[goff0 + (unsigned)dr * o_rs] = v;
+          }
+          continue;
+        }
         const unsigned off0 = (unsigned)row0 * o_rs + (unsigned)colc * o_ts + o_to;
         float rv[16];
         if (resb) {
@@ -550,6 +561,26 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
       bsv[i] = bsum;
       rvv[i] = resb ? ld_off(resb, 4u * ((unsigned)row * o_rs + coff)) : 0.f;
     }
+    if (act == ACT_GATE) {                          // rows rl and rl + 16 are a (tanh, sigmoid) pair: passes i and i + 16/RPP of this thread
+      if constexpr (RPP <= 16) {
+        float vs[32 / RPP];
+#pragma unroll
+        for (int i = 0; i < 32 / RPP; ++i) {
+          const int rl = (tid >> 5) + RPP * i;
+          float vv = 0.f;
+#pragma unroll
+          for (int w = 0; w < NWV; w += 4)
+            vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
+          vs[i] = vv + bsv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16 / RPP; ++i) {
+          const int rl = (tid >> 5) + RPP * i;
+          const float v = tanhf(vs[i]) * (1.f / (1.f + expf(-vs[i + 16 / RPP])));
+          if (colok && m0 + rl + 16 < cout) outb[(unsigned)(m0 / 2 + rl) * o_rs + coff] = v;
+        }
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < 32 / RPP; ++i) {
       const int rl = (tid >> 5) + RPP * i;
@@ -720,7 +751,9 @@ static int launch_splitk(hipStream_t stream, const ConvLaunch& L0, int max_cout_
     if (L.p[i].in_mask) any_mask = true; else all_mask = false;
   }
   if (any_mask != all_mask) return -2;            // one launch = one mask mode
-  const int nw = splitk_waves(L);
+  int nw = splitk_waves(L);
+  for (int i = 0; i < L.nprob; ++i)
+    if (L.p[i].act == ACT_GATE && nw == 16) nw = 8;   // the gate pairs rows inside one thread: at most 16 rows per pass
   if (variant_name) *variant_name = nw == 16 ? "conv1d_splitk<32x32,16w>" : (nw == 8 ? "conv1d_splitk<32x32,8w>" : "conv1d_splitk<32x32,4w>");
   const dim3 grid(per_xcd * 8);
   // LDSX form: every problem has taps to re-use (k > 1), the staged tile fits (32 + (k-1)*dil <= SK_XP columns, <= SK_RPW rows

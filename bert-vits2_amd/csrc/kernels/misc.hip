@@ -1,6 +1,6 @@
 // misc.hip — the small, HBM/latency-bound kernels of the path: conv_post+tanh, speaker GEMVs, embeddings, masks,
 // the stochastic-duration-predictor glue (ConvFlow pre, inverse rational-quadratic spline, ElementwiseAffine^-1),
-// duration -> length regulation, WN gate / res-skip.  All fp32, all coalesced along time.
+// duration -> length regulation.  All fp32, all coalesced along time.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <cmath>
@@ -171,8 +171,17 @@ __global__ void embed_kernel(const EmbedArgs A) {
   const int64_t off = ((int64_t)b * A.C + c) * A.T + t;
   float v = A.emb[xi * A.C + c] + A.tone_emb[ti * A.C + c];
   v += A.lang_emb[li * A.C + c];
-  float bs = A.bsum[off];
-  for (int sl = 1; sl < A.nslab; ++sl) bs += A.bsum[(int64_t)sl * A.slab_stride + off];
+  float bs = 0.f;
+  const int per = A.nslab / 3;                    // slabs per feature (the three projections write nslab/3 slabs each)
+  for (int f = 0; f < 3; ++f) {
+    int tc = t;
+    if (A.idx[f]) {
+      tc = A.idx[f][bt];
+      tc = tc < 0 ? 0 : (tc >= A.T ? A.T - 1 : tc);
+    }
+    const int64_t offf = ((int64_t)b * A.C + c) * A.T + tc;
+    for (int sl = f * per; sl < (f + 1) * per; ++sl) bs += A.bsum[(int64_t)sl * A.slab_stride + offf];
+  }
   v += bs;
   A.out[off] = v * A.scale * A.mask[bt];
 }
@@ -367,45 +376,6 @@ int launch_expand(hipStream_t stream, const ExpandArgs& a0) {
   if (a.attn)
     hipLaunchKernelGGL(attn_path_kernel, dim3((a.T + 255) / 256, a.Ty, a.B), dim3(256), 0, stream, a.frame_idx, a.attn,
                        a.T, a.Ty);
-  return BV2_CHECK_LAUNCH();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// WN gated activation and res/skip bookkeeping (reference commons.py:98-105, modules.py:192-210)
-__global__ void wn_gate_kernel(const float* xin, float* acts, int H, int T) {
-  const int b = blockIdx.z, c = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
-  const float a = xin[((int64_t)b * 2 * H + c) * T + t];
-  const float s = xin[((int64_t)b * 2 * H + H + c) * T + t];
-  acts[((int64_t)b * H + c) * T + t] = tanhf(a) * (1.f / (1.f + expf(-s)));
-}
-int launch_wn_gate(hipStream_t stream, const float* xin, float* acts, int B, int H, int T) {
-  hipLaunchKernelGGL(wn_gate_kernel, dim3((T + 255) / 256, H, B), dim3(256), 0, stream, xin, acts, H, T);
-  return BV2_CHECK_LAUNCH();
-}
-
-__global__ void wn_res_skip_kernel(const float* rs, float* x, float* outacc, const float* mask, int H, int T, int last,
-                                   int first) {
-  const int b = blockIdx.z, c = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
-  const int64_t off = ((int64_t)b * H + c) * T + t;
-  const float mk = mask[(int64_t)b * T + t];
-  if (!last) {
-    const int64_t r0 = ((int64_t)b * 2 * H + c) * T + t;
-    x[off] = (x[off] + rs[r0]) * mk;
-    const float sk = rs[r0 + (int64_t)H * T];
-    outacc[off] = first ? sk : outacc[off] + sk;
-  } else {
-    const float sk = rs[off];
-    outacc[off] = ((first ? 0.f : outacc[off]) + sk) * mk;
-  }
-}
-int launch_wn_res_skip(hipStream_t stream, const float* rs, float* x, float* outacc, const float* mask, int B, int H, int T,
-                       int last, int first) {
-  hipLaunchKernelGGL(wn_res_skip_kernel, dim3((T + 255) / 256, H, B), dim3(256), 0, stream, rs, x, outacc, mask, H, T,
-                     last, first);
   return BV2_CHECK_LAUNCH();
 }
 

@@ -44,6 +44,7 @@ class EncodeIn(C.Structure):
         ("x", C.c_void_p), ("x_lengths", C.c_void_p), ("sid", C.c_void_p), ("tone", C.c_void_p), ("language", C.c_void_p),
         ("bert", C.c_void_p), ("ja_bert", C.c_void_p), ("en_bert", C.c_void_p), ("noise_w", C.c_void_p),
         ("noise_scale_w", C.c_float), ("sdp_ratio", C.c_float), ("length_scale", C.c_float),
+        ("bert_index", C.c_void_p * 3), ("bert_cols", C.c_int32 * 3),
     ]
 
 

@@ -290,8 +290,13 @@ class SynthesizerTrn(nn.Module):
     # ------------------------------------------------------------------ the two phases
     @torch.no_grad()
     def encode_durations(self, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_w, noise_scale_w=0.8,
-                         sdp_ratio=0.0, length_scale=1.0) -> Dict[str, torch.Tensor]:
-        """Phase A = reference models.py:1045-1057.  ``noise_w`` [B,2,T] is the draw of models.py:248-251."""
+                         sdp_ratio=0.0, length_scale=1.0, bert_index=None) -> Dict[str, torch.Tensor]:
+        """Phase A = reference models.py:1045-1057.  ``noise_w`` [B,2,T] is the draw of models.py:248-251.
+
+        ``bert_index`` (optional, a 3-tuple aligned with bert / ja_bert / en_bert; entries may be None): a feature with an index is
+        WORD-level — [B, 1024, S] as the BERT model emitted it, still on the device — and symbol t reads column index[b, t]; the
+        word2ph repeat of reference text/chinese_bert.py:48-58 happens as a gather inside the TextEncoder front
+        (``bert_features.word_level_feature`` builds the pair)."""
         if self._blob is None:
             self.repack()
         dev = self.device
@@ -300,8 +305,18 @@ class SynthesizerTrn(nn.Module):
         f32 = lambda t: t.to(dev, torch.float32).contiguous()
         x, x_lengths, sid, tone, language = i64(x), i64(x_lengths), i64(sid), i64(tone), i64(language)
         bert, ja_bert, en_bert, noise_w = f32(bert), f32(ja_bert), f32(en_bert), f32(noise_w)
-        if bert.shape != (B, H.BERT_DIM, T) or ja_bert.shape != bert.shape or en_bert.shape != bert.shape:
-            raise ValueError(f"bert features must be [B,{H.BERT_DIM},T] (reference infer.py:124)")
+        bidx = [None, None, None] if bert_index is None else [None if t is None else t.to(dev, torch.int32).contiguous() for t in bert_index]
+        for feat, ix in zip((bert, ja_bert, en_bert), bidx):
+            want = (B, H.BERT_DIM, T) if ix is None else (B, H.BERT_DIM, feat.shape[2])
+            if tuple(feat.shape) != want or (ix is not None and (tuple(ix.shape) != (B, T) or not 1 <= feat.shape[2] <= T)):
+                raise ValueError(f"bert features must be [B,{H.BERT_DIM},T] (reference infer.py:124), or [B,{H.BERT_DIM},S<=T] with a [B,T] index")
+        cols = [0 if ix is None else int(f.shape[2]) for f, ix in zip((bert, ja_bert, en_bert), bidx)]
+
+        def with_index(ein, ptr_of):
+            for i in range(3):
+                ein.bert_index[i] = None if bidx[i] is None else ptr_of(i)
+                ein.bert_cols[i] = cols[i]
+            return ein
         if noise_w.shape != (B, 2, T):
             raise ValueError("noise_w must be [B,2,T]")
         hp = self.hp
@@ -314,6 +329,9 @@ class SynthesizerTrn(nn.Module):
             ws = self._workspace(B, T, 1)
             ins = dict(x=x, x_lengths=x_lengths, sid=sid, tone=tone, language=language, bert=bert, ja_bert=ja_bert,
                        en_bert=en_bert, noise_w=noise_w)
+            for i in range(3):
+                if bidx[i] is not None:
+                    ins[f"bert_index{i}"] = bidx[i]
 
             static = self._graphs_static
             staged = ("noise_w",) if static else tuple(ins)     # static_io: everything but the noise is read in place
@@ -324,6 +342,7 @@ class SynthesizerTrn(nn.Module):
                 ein = L.EncodeIn(B, T, *[_ptr(sin[k]) for k in ("x", "x_lengths", "sid", "tone", "language", "bert", "ja_bert",
                                                                 "en_bert", "noise_w")],
                                  float(noise_scale_w), float(sdp_ratio), float(length_scale))
+                with_index(ein, lambda i: sin[f"bert_index{i}"].data_ptr())
                 eout = L.EncodeOut(*[_ptr(sout[k]) for k in okeys])
                 with torch.cuda.device(dev):
                     g = self._capture(self._lib.bv2_graph_capture_encode, C.byref(ein), C.byref(eout),
@@ -331,7 +350,7 @@ class SynthesizerTrn(nn.Module):
                 return dict(graph=g, sin=sin, sout=sout)
 
             ptrs = tuple(ins[k].data_ptr() for k in ins if k not in staged)
-            ent = self._graph_entry(("A", B, T, float(noise_scale_w), float(sdp_ratio), float(length_scale), ptrs), build)
+            ent = self._graph_entry(("A", B, T, float(noise_scale_w), float(sdp_ratio), float(length_scale), ptrs, tuple(cols)), build)
             for k in staged:
                 ent["sin"][k].copy_(ins[k], non_blocking=True)
             with torch.cuda.device(dev):
@@ -343,6 +362,7 @@ class SynthesizerTrn(nn.Module):
         out = mk_out()
         ein = L.EncodeIn(B, T, _ptr(x), _ptr(x_lengths), _ptr(sid), _ptr(tone), _ptr(language), _ptr(bert), _ptr(ja_bert),
                          _ptr(en_bert), _ptr(noise_w), float(noise_scale_w), float(sdp_ratio), float(length_scale))
+        with_index(ein, lambda i: bidx[i].data_ptr())
         eout = L.EncodeOut(*[_ptr(out[k]) for k in okeys])
         ws = self._workspace(B, T, 1)
         with torch.cuda.device(dev):
@@ -424,12 +444,13 @@ class SynthesizerTrn(nn.Module):
     @torch.no_grad()
     def infer(self, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_scale=0.667, length_scale=1,
               noise_scale_w=0.8, max_len=None, sdp_ratio=0, y=None, *, noise_w=None, noise_z=None, w_ceil=None,
-              want_attn=True, exact_lengths=False):
+              want_attn=True, exact_lengths=False, bert_index=None):
         """reference models.py:1026-1074.  Keyword-only extras (not in the reference): ``noise_w`` [B,2,T] and
         ``noise_z`` [B,inter,>=T_y] inject the two N(0,1) draws (parity tests; the reference's ONNX export externalises
         them the same way), ``w_ceil`` substitutes the durations, ``want_attn=False`` skips materialising the path,
         ``exact_lengths=True`` makes every utterance of a ragged batch come out exactly as if it had been run alone (the
-        reference's unmasked decoder lets the padding bleed into an utterance's last ~40 ms; bv2.h ``exact_lengths``)."""
+        reference's unmasked decoder lets the padding bleed into an utterance's last ~40 ms; bv2.h ``exact_lengths``),
+        ``bert_index`` hands BERT features over at word level (see ``encode_durations``)."""
         if self.device.type != "cuda":
             raise RuntimeError("bert_vits2_amd.SynthesizerTrn.infer needs a GPU: no CPU fallback exists by design")
         dev = self.device
@@ -437,7 +458,8 @@ class SynthesizerTrn(nn.Module):
         if noise_w is None:
             noise_w = draw_noise_w(B, T, dev)
         enc = self.encode_durations(x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_w,
-                                    noise_scale_w=noise_scale_w, sdp_ratio=sdp_ratio, length_scale=length_scale)
+                                    noise_scale_w=noise_scale_w, sdp_ratio=sdp_ratio, length_scale=length_scale,
+                                    bert_index=bert_index)
         if w_ceil is not None:
             wc = w_ceil.to(dev, torch.float32).reshape(B, T).contiguous()
             enc["w_ceil"] = wc

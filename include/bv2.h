@@ -120,6 +120,14 @@ typedef struct bv2_encode_in {
   const float* en_bert;      /* [B,bert_dim,T] */
   const float* noise_w;      /* [B,2,T]  N(0,1): the torch.randn of models.py:248-251, drawn by the caller */
   float noise_scale_w, sdp_ratio, length_scale;
+  /* Optional WORD-level BERT features.  The reference runs the BERT model, copies hidden_states[-3] to the host,
+   * repeats word i's row word2ph[i] times (text/chinese_bert.py:37, 48-58) and uploads [1024, T] again.  With
+   * bert_index[f] != NULL feature f (0 = bert, 1 = ja_bert, 2 = en_bert) is handed over as the BERT model emitted it,
+   * [B, bert_dim, bert_cols[f]] — one column per word, still on the device — and symbol t of utterance b takes column
+   * bert_index[f][b*T + t] (the word2ph repeat as a gather inside the TextEncoder front: the repeated matrix never exists).
+   * NULL: the feature is [B, bert_dim, T], one column per symbol, as in the reference. */
+  const int32_t* bert_index[3];
+  int32_t bert_cols[3];
 } bv2_encode_in;
 
 typedef struct bv2_encode_out {   /* all DEVICE, caller-allocated */
