@@ -104,7 +104,8 @@ struct FusedProb {
   const float* w2; const float* b2;               // ... of convs2[d]
   int k, dil;
 };
-struct FusedLaunch { FusedProb p[3]; int nprob, B, C, L; float slope; const int64_t* lens = nullptr; int len_mul = 1; };
+struct FusedLaunch { FusedProb p[3]; int nprob, B, C, L; float slope; const int64_t* lens = nullptr; int len_mul = 1;
+                     unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
 bool resblock_fused_supported(int C, int k, int dil);
 int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F);
 double resblock_fused_flops(const FusedLaunch& F);
@@ -258,6 +259,7 @@ struct AttnArgs {
   float* out;               // [B][H*D][T]
   int B, H, D, T, W;
   int f16;                  // 1: QK^T and PV on the fp16 matrix core (operands rounded in registers, everything else fp32)
+  unsigned long long* dbg = nullptr;   // tools/timeline.py only
 };
 int launch_attention(hipStream_t stream, const AttnArgs& a);
 double attention_flops(const AttnArgs& a);

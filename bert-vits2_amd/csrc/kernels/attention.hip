@@ -49,7 +49,7 @@ constexpr int ANS = 4;          // merge slots
 //                             staging loop stores in LDS as fp16 in exactly that order (one ds_read_b128 per step);
 //   O^T step s (16 keys):     B = the lane's S registers 8s .. 8s+7 (its own D-layout rows), A = vreg[m][2s], vreg[m][2s+1]
 //                             (the float4s that hold exactly those keys).
-template <int DT, int NW, bool F16>       // D = 32*DT head channels, NW waves
+template <int DT, int NW, bool F16, bool ONE>   // D = 32*DT head channels, NW waves; ONE: at most one key tile per wave (no loop)
 __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   constexpr int D = 32 * DT;
   constexpr int NT = 64 * NW;
@@ -58,6 +58,8 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
   const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AQ;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;  // timeline stamps (tools/timeline.py; A.dbg is null in the product)
+  if (A.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int T = A.T, W = A.W, NR = 2 * W + 1, ld = A.ld;
   const int HD = A.H * D;
   const int R = 3 * HD + A.H * NR;
@@ -107,18 +109,33 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   // query tile and Ev -> LDS (all threads)
   constexpr int QP = D + 8;                         // fp16 row pitch of the transposed query tile (odd multiple of 16 B)
   _Float16* Qh = reinterpret_cast<_Float16*>(Qs);   // F16: [AQ][QP], row i holds Q[2(8t+e)+lh][i] at t*16 + lh*8 + e
-  for (int e = tid; e < D * AQ; e += NT) {
-    const int c = e >> 5, i = e & 31;
-    const float qv = qp[c * ld + i0 + i];           // columns beyond T: finite-or-not garbage, dead columns below
-    if (F16) {
-      const int h2 = c & 1, u = c >> 1;             // c = 2u + lh, u = 8t + e
-      Qh[i * QP + (u >> 3) * 16 + h2 * 8 + (u & 7)] = (_Float16)((i0 + i < T) ? qv : 0.f);
-    } else {
-      Qs[e] = qv;
+  {
+    // all of a thread's query loads in flight at once (the piece-per-iteration loop took D*AQ/NT serial L2 round trips: 9-12k
+    // cycles before the first MFMA, tools/timeline.py)
+    constexpr int QPT = (D * AQ + NT - 1) / NT;
+    float qv[QPT];
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+      int e = tid + q * NT;
+      e = e < D * AQ ? e : D * AQ - 1;
+      qv[q] = qp[(e >> 5) * ld + i0 + (e & 31)];    // columns beyond T: finite-or-not garbage, dead columns below
+    }
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+      const int e = tid + q * NT;
+      if (e >= D * AQ) continue;
+      const int c = e >> 5, i = e & 31;
+      if (F16) {
+        const int h2 = c & 1, u = c >> 1;           // c = 2u + lh, u = 8t + e
+        Qh[i * QP + (u >> 3) * 16 + h2 * 8 + (u & 7)] = (_Float16)((i0 + i < T) ? qv[q] : 0.f);
+      } else {
+        Qs[e] = qv[q];
+      }
     }
   }
   for (int e = tid; e < NR * D; e += NT) Ev[e] = A.erv[e];
   __syncthreads();
+  if (A.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
   f32x16 O[DT];
 #pragma unroll
@@ -128,9 +145,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   float m_run = -INFINITY, l_run = 0.f;
 
 #pragma unroll 1
-  for (int kt = wid; kt < ntiles; kt += NW) {
+  for (int kt = wid; kt < ntiles; kt += (ONE ? (1 << 20) : NW)) {    // ONE: the body runs at most once (ntiles <= NW)
     const int j0 = kt * AK;
-    if (kt >= NW) issue_k(j0);
+    if (!ONE && kt >= NW) issue_k(j0);
     // ---- S^T = K^T Q   (rows beyond T hold garbage: replaced below, never accumulated)
     f32x16 S;
 #pragma unroll
@@ -197,7 +214,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     m_run = m_new;
-    if (kt >= NW) {
+    if (!ONE && kt >= NW) {
 #pragma unroll
       for (int m = 0; m < DT; ++m)
 #pragma unroll
@@ -246,6 +263,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     }
   }
 
+  if (A.dbg) ts2 = __builtin_amdgcn_s_memtime();
   // ---- merge the waves' partials: (max, sum) first, then the rescaled O tiles through ANS slots in fixed order
   if (lh == 0) { Mw[wid * AQ + l31] = m_run; Lw[wid * AQ + l31] = l_run; }
   __syncthreads();
@@ -274,6 +292,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     }
     Sb[e] = (j >= 0 && j < T && i0 + i < T) ? __expf(Sb[e] - mt) / lt : 0.f;
   }
+  if (A.dbg) ts3 = __builtin_amdgcn_s_memtime();
   constexpr int ROUNDS = (NW + ANS - 1) / ANS;
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -291,6 +310,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     __syncthreads();
   }
   constexpr int NSLOT = NW < ANS ? NW : ANS;
+  if (A.dbg) ts4 = __builtin_amdgcn_s_memtime();
 
   // ---- normalise, add relative-value term, store (coalesced over queries)
   float* op = A.out + (int64_t)b * HD * T + (int64_t)(h * D) * T;
@@ -305,31 +325,43 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       op[(int64_t)c * T + ig] = o;
     }
   }
+  if (A.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* d = A.dbg + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+    d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    d[5] = ts3; d[6] = ts4; d[7] = 1;
+  }
 }
 
 static size_t attn_lds_bytes(int D, int NW) {
   return sizeof(float) * (size_t)(ANS * D * AQ + D * AQ + (2 * AMAXW + 1) * D + (2 * AMAXW + 1) * AQ + 2 * NW * AQ);
 }
 
-template <int DT, int NW, bool F16>
+template <int DT, int NW, bool F16, bool ONE>
 static int launch_attn_variant2(hipStream_t stream, const AttnArgs& a, dim3 grid) {
   const size_t lds = attn_lds_bytes(32 * DT, NW);
-  auto kern = attention_kernel<DT, NW, F16>;
+  auto kern = attention_kernel<DT, NW, F16, ONE>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, a);
+  AttnArgs at = a;
+  at.dbg = timeline_slice(grid.x, grid.y, grid.z, 77000 + 10 * DT + NW, 0, a.D, a.T);    // tile id 77xxx: attention
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, at);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int DT, int NW>
+template <int DT, int NW, bool ONE>
 static int launch_attn_variant(hipStream_t stream, const AttnArgs& a, dim3 grid) {
-  return a.f16 ? launch_attn_variant2<DT, NW, true>(stream, a, grid) : launch_attn_variant2<DT, NW, false>(stream, a, grid);
+  return a.f16 ? launch_attn_variant2<DT, NW, true, ONE>(stream, a, grid) : launch_attn_variant2<DT, NW, false, ONE>(stream, a, grid);
 }
 
 template <int DT>
 static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int ntiles) {
-  // 8 waves is the most the register file holds without spilling (K tile + O + S per wave, 2 waves per SIMD)
-  if (ntiles <= 4) return launch_attn_variant<DT, 4>(stream, a, grid);
-  return launch_attn_variant<DT, 8>(stream, a, grid);
+  // Up to 8 key tiles: one per wave, no loop (T = 128: 19.4 -> 16.9 us).  More: 8 waves round-robin.  Measured at T_y = 384
+  // (12 tiles) and NOT kept: 12 waves with one tile each (53 spilled registers: 27 -> 41 us) and 6 waves with two tiles each
+  // (balanced, but 27 -> 31 us: the merge wait that tools/timeline.py shows is not the 1-vs-2-tile imbalance).
+  if (ntiles <= 4) return launch_attn_variant<DT, 4, true>(stream, a, grid);
+  if (ntiles <= 8) return launch_attn_variant<DT, 8, true>(stream, a, grid);
+  return launch_attn_variant<DT, 8, false>(stream, a, grid);
 }
 
 int launch_attention(hipStream_t stream, const AttnArgs& a) {

@@ -94,6 +94,8 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
   float* Xs = smem;                               // [C][RF_XP]   lrelu(x), zero outside [0, L)
   float* Tm = smem + 32 * RF_XP;                  // [C][RF_TP]   lrelu(conv1 + b1), zero outside [0, L)
   const FusedProb& P = F.p[blockIdx.z];
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; F.dbg is null in the product)
+  if (F.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -142,6 +144,7 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
       }
   }
   __syncthreads();
+  if (F.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 1: intermediate columns [32*wid, 32*wid + 32)
   {
@@ -162,6 +165,7 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
     }
   }
   __syncthreads();
+  if (F.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 2: output columns [32*wid, 32*wid + 32) of the tile, waves 0..6
   if (wid < RF_BN / 32) {
@@ -190,6 +194,14 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
       }
     }
   }
+  if (F.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* d = F.dbg + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+    d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    d[6] = (unsigned long long)k; d[7] = 1;
+  }
 }
 
 bool resblock_fused_supported(int C, int k, int dil) {
@@ -206,7 +218,13 @@ int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F) {
   const size_t lds = sizeof(float) * (size_t)(32 * RF_XP + 32 * RF_TP);
   auto kern = resblock_fused_kernel;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, F);
+  FusedLaunch Ft = F;
+  {
+    int ks = 0;
+    for (int i = 0; i < F.nprob; ++i) ks |= (F.p[i].k & 255) << (8 * i);
+    Ft.dbg = timeline_slice(grid.x, grid.y, grid.z, 88000 + F.C, ks, F.C, F.L);       // tile id 88xxx: fused ResBlock pair
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, Ft);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

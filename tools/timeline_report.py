@@ -41,6 +41,18 @@ def main():
         bm, bn = tile // 1000, tile % 1000
         kk = [(ks >> (8 * j)) & 255 for j in range(3) if (ks >> (8 * j)) & 255]
         line = f"#{i:3d} {bm}x{bn} k={kk} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU), span {span:9.0f} (per-XCD {min(spans)}..{max(spans)})"
+        if 77000 <= tile < 78000 or 88000 <= tile < 89000:
+            what = "attention" if tile < 78000 else "resblock_fused"
+            print(f"#{i:3d} {what} id {tile} k={kk} D/C {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU): phase1 {np.mean(v[:, 1] - v[:, 0]):7.0f} "
+                  f"phase2 {np.mean(v[:, 2] - v[:, 1]):8.0f} phase3 {np.mean(v[:, 3] - v[:, 2]):7.0f} life {np.mean(v[:, 3] - v[:, 0]):8.0f}")
+            if what == "attention":
+                print(f"      merge: wait+stats {np.mean(v[:, 5] - v[:, 2]):7.0f}  slot rounds {np.mean(v[:, 6] - v[:, 5]):7.0f}  normalise+store {np.mean(v[:, 3] - v[:, 6]):7.0f}")
+            if what == "resblock_fused":
+                for k in kk:
+                    m = v[:, 6] == k
+                    if m.any():
+                        print(f"      k{k}: n {m.sum()} stage {np.mean(v[m, 1] - v[m, 0]):7.0f} conv1 {np.mean(v[m, 2] - v[m, 1]):8.0f} conv2+store {np.mean(v[m, 3] - v[m, 2]):8.0f}")
+            continue
         if tile < 0:
             # bf16 channels-last conv: tile id -(WN*1000 + WM*100 + MI*10 + NI); MFMA cycles per wave = (cin/16)*k units * MI*NI * 32
             t = -tile
