@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   float* Sb = Ev + (2 * AMAXW + 1) * D;             // [NR][AQ] raw band logits -> band probabilities
   float* Mw = Sb + (2 * AMAXW + 1) * AQ;            // [NW][AQ]
   float* Lw = Mw + NW * AQ;                         // [NW][AQ]
+  float* Qe = Lw + NW * AQ;                         // [NR][AQ] relative-key logits q_i.Ek[r]/sqrt(d) of this query tile
 
   const float* base = A.qkv + (int64_t)b * R * ld;
   const float* qp = base + (int64_t)(h * D) * ld;
@@ -134,6 +135,13 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     }
   }
   for (int e = tid; e < NR * D; e += NT) Ev[e] = A.erv[e];
+  // the 2W+1 relative-key logit rows of the tile's queries: staged once.  (Read from global inside the softmax loop they were a
+  // dependent load per in-band element — up to 9 serial round trips in the wave that owns the diagonal tile, which every other
+  // wave of the workgroup then waited for at the merge barrier: tools/timeline.py, 12-16k cycles of a 62k-cycle workgroup.)
+  for (int e = tid; e < NR * AQ; e += NT) {
+    const int r = e >> 5, i = e & 31;
+    Qe[e] = (i0 + i < T) ? qe[r * ld + i0 + i] : 0.f;
+  }
   __syncthreads();
   if (A.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       if (near_band) {
         const int rel = j - iq;
         const bool inband = (rel >= -W) && (rel <= W) && iok && j < T;
-        if (inband) sv += qe[(rel + W) * ld + iq];
+        if (inband) sv += Qe[(rel + W) * AQ + l31];
         if (!(mi != 0.f && mj != 0.f)) sv = -1e4f;              // masked_fill(mask == 0, -1e4), attentions.py:297
         if (inband) Sb[(rel + W) * AQ + l31] = sv;
       } else {
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 }
 
 static size_t attn_lds_bytes(int D, int NW) {
-  return sizeof(float) * (size_t)(ANS * D * AQ + D * AQ + (2 * AMAXW + 1) * D + (2 * AMAXW + 1) * AQ + 2 * NW * AQ);
+  return sizeof(float) * (size_t)(ANS * D * AQ + D * AQ + (2 * AMAXW + 1) * D + 2 * (2 * AMAXW + 1) * AQ + 2 * NW * AQ);
 }
 
 template <int DT, int NW, bool F16, bool ONE>

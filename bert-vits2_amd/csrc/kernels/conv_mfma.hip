@@ -446,6 +446,32 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
     if (++lj == k) { lj = 0; joff = 0; ++lg; goff = group_off(lg); woff = weight_off(lg); }
   };
 
+  // ---- epilogue operands first: every ConvProb field into a register (reading P.* after the first global store re-loads it
+  // from the kernarg segment per row, see conv1d_mfma_kernel's epilogue), 32-bit element offsets from wave-uniform bases, and
+  // the bias / residual values of this thread's output elements in flight BEFORE the main loop — loaded after the LDS reduction
+  // they were one more exposed memory round trip in every one of the ~130 split-K launches of a batch-1 step
+  const int col = t0 + (tid & 31);
+  const bool colok = col < L.L;
+  const int cout = P.cout, act = P.act, mask_pre = P.mask_pre, mask_post = P.mask_post, res_mode = P.res_mode;
+  const unsigned o_rs = (unsigned)P.out_rstride, o_ts = (unsigned)P.out_tstride, o_to = (unsigned)P.out_toff;
+  float* const outb = P.out + (int64_t)z * L.slab_stride + (int64_t)b * P.out_bstride;
+  const float* const resb = (res_mode != RES_NONE && z == 0) ? P.res + (int64_t)b * P.res_bstride : nullptr;
+  const float* const biasp = z == 0 ? P.bias : nullptr;
+  const float* const bias2p = (z == 0 && P.bias2) ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
+  const float om = (P.out_mask && colok) ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
+  const unsigned coff = (unsigned)(colok ? col : 0) * o_ts + o_to;
+  constexpr int RPP = 2 * NWV;                      // rows per pass (one element per thread per pass)
+  float rvv[32 / RPP], bsv[32 / RPP];
+#pragma unroll
+  for (int i = 0; i < 32 / RPP; ++i) {
+    const int rl = (tid >> 5) + RPP * i;
+    int row = m0 + rl;
+    row = row < cout ? row : cout - 1;
+    float bsum = biasp ? biasp[row] : 0.f;
+    if (bias2p) bsum += bias2p[row];
+    bsv[i] = bsum;
+    rvv[i] = resb ? ld_off(resb, 4u * ((unsigned)row * o_rs + coff)) : 0.f;
+  }
   // ---- LDSX: stage the workgroup's X tile.  Row rr = wid + NWV*i of the tile is channel 8*G0 + rr; lane = column.
   const int G0 = (int)(((int64_t)groups * (z * NWV)) / nsl);
   float* const Xs = red_raw;
@@ -536,31 +562,8 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r] + acc2[r];
   __syncthreads();
-  // epilogue: every ConvProb field into a register first (see conv1d_mfma_kernel's epilogue: reading P.* after the first
-  // global store re-loads it from the kernarg segment per row), 32-bit element offsets from wave-uniform bases
-  const int col = t0 + (tid & 31);
-  const bool colok = col < L.L;
+  // epilogue (its operands — ConvProb fields, bias, residual — were loaded before the main loop: "epilogue operands first" above)
   {
-    const int cout = P.cout, act = P.act, mask_pre = P.mask_pre, mask_post = P.mask_post, res_mode = P.res_mode;
-    const unsigned o_rs = (unsigned)P.out_rstride, o_ts = (unsigned)P.out_tstride, o_to = (unsigned)P.out_toff;
-    float* const outb = P.out + (int64_t)z * L.slab_stride + (int64_t)b * P.out_bstride;
-    const float* const resb = (res_mode != RES_NONE && z == 0) ? P.res + (int64_t)b * P.res_bstride : nullptr;
-    const float* const biasp = z == 0 ? P.bias : nullptr;
-    const float* const bias2p = (z == 0 && P.bias2) ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
-    const float om = (P.out_mask && colok) ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
-    const unsigned coff = (unsigned)(colok ? col : 0) * o_ts + o_to;
-    constexpr int RPP = 2 * NWV;                    // rows per pass (one element per thread per pass)
-    float rvv[32 / RPP], bsv[32 / RPP];
-#pragma unroll
-    for (int i = 0; i < 32 / RPP; ++i) {
-      const int rl = (tid >> 5) + RPP * i;
-      int row = m0 + rl;
-      row = row < cout ? row : cout - 1;
-      float bsum = biasp ? biasp[row] : 0.f;
-      if (bias2p) bsum += bias2p[row];
-      bsv[i] = bsum;
-      rvv[i] = resb ? ld_off(resb, 4u * ((unsigned)row * o_rs + coff)) : 0.f;
-    }
     if (act == ACT_GATE) {                          // rows rl and rl + 16 are a (tanh, sigmoid) pair: passes i and i + 16/RPP of this thread
       if constexpr (RPP <= 16) {
         float vs[32 / RPP];

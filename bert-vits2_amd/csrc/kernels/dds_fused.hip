@@ -71,6 +71,15 @@ __global__ void __launch_bounds__(64 * NU) dds_layer_kernel(const DdsArgs A) {
   // ---- phase 1: depthwise conv + LN1 + GELU on thread (tl = time step, cg = channel group)
   const int tl = tid & 15, cg = tid >> 4;
   const float* maskb = A.mask + (int64_t)b * T;
+  // per-channel parameters of BOTH LayerNorms and the conv bias: in flight from the start (behind the barriers, where the
+  // compiler would otherwise issue them, each group is an exposed L2 round trip)
+  float pg1[4], pb1[4], pg2[4], pb2[4], pbias[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pg1[i] = A.g1[cg + CG * i]; pb1[i] = A.b1[cg + CG * i];
+    const int row = 16 * wv + 4 * (lane >> 4) + i;               // this lane's rows of the MFMA output (phase 3)
+    pg2[i] = A.g2[row]; pb2[i] = A.b2[row]; pbias[i] = A.bias[row];
+  }
   float v[4], xc[4];
   {
     const int t = t0 + tl;
@@ -136,7 +145,7 @@ __global__ void __launch_bounds__(64 * NU) dds_layer_kernel(const DdsArgs A) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = cg + CG * i;
-      const float y = (v[i] - mean) * rstd * A.g1[c] + A.b1[c];
+      const float y = (v[i] - mean) * rstd * pg1[i] + pb1[i];
       ys[c * DDS_NT + tl] = gelu_erf(y);
       xres[c * DDS_NT + tl] = xc[i];
     }
@@ -160,7 +169,7 @@ __global__ void __launch_bounds__(64 * NU) dds_layer_kernel(const DdsArgs A) {
   float o[4];
   {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = acc[r] + A.bias[16 * wv + 4 * rg + r];
+    for (int r = 0; r < 4; ++r) o[r] = acc[r] + pbias[r];
     float s = (o[0] + o[1]) + (o[2] + o[3]);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
@@ -184,7 +193,7 @@ __global__ void __launch_bounds__(64 * NU) dds_layer_kernel(const DdsArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * wv + 4 * rg + r;
-      const float y = gelu_erf((o[r] - mean) * rstd * A.g2[row] + A.b2[row]);
+      const float y = gelu_erf((o[r] - mean) * rstd * pg2[r] + pb2[r]);
       float val = xres[row * DDS_NT + n] + y;
       if (A.last_mask) val *= mkc;
       o[r] = val;

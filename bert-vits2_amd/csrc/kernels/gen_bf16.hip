@@ -219,7 +219,7 @@ __device__ __forceinline__ void cl_gemm_tm(f32x16 (&acc)[MI][NI], const uint16_t
 // allows it): the second launch-bounds argument (waves per SIMD) keeps the register allocation at <= 168 — without it the
 // staging batch below pushed the kernel to 178 registers and one workgroup per CU was lost
 template <int WN, int WM, int MI, int NI, int G>   // G > 0: C_in = 16*G for every problem of the launch (tap-major GEMM)
-__global__ void __launch_bounds__(64 * WN * WM, (WN * WM == 4 && MI * NI <= 4) ? 3 : 1)
+__global__ void __launch_bounds__(64 * WN * WM, (WN * WM == 4 && MI * NI <= 2) ? 5 : ((WN * WM == 4 && MI * NI <= 4) ? 3 : 1))
 conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
   constexpr int NT = 64 * WN * WM;
   constexpr int WT = 32 * NI;
@@ -442,7 +442,7 @@ int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** vari
   if (v < 0) v = nt >= 8 ? 0 : (nt >= 3 ? 1 : (nt == 2 ? (cin == 64 ? 9 : 2) : 3));
   static const char* names[] = {"conv_cl_bf16<8x1>", "conv_cl_bf16<4x1>", "conv_cl_bf16<2x2>", "conv_cl_bf16<1x4>",
                                 "conv_cl_bf16<4x1,2x4>", "conv_cl_bf16<2x2,2x4>", "conv_cl_bf16<2x4,2x2>", "conv_cl_bf16<1x4,2x4>",
-                                "conv_cl_bf16<4x2,2x2>", "conv_cl_bf16<1x8,2x2>"};
+                                "conv_cl_bf16<4x2,2x2>", "conv_cl_bf16<1x8,2x2>", "conv_cl_bf16<4x1,t64>", "conv_cl_bf16<8x1,t64>"};
   static const bool generic = getenv("BV2_CL_GENERIC") != nullptr;
   int r = -1;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -467,6 +467,11 @@ int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** vari
                                            : launch_cl_variant<4, 2, 2, 2>(stream, L, nt, extra, cin); break;
       case 9: r = (cin == 64 && !generic) ? launch_cl_variant<1, 8, 2, 2, 4>(stream, L, nt, extra, cin)
                                           : launch_cl_variant<1, 8, 2, 2>(stream, L, nt, extra, cin); break;
+      // 64-step time tiles: half the MFMA work per workgroup but 31 KB of LDS and <= 96 registers -> five workgroups per CU
+      case 10: r = (cin == 128 && !generic) ? launch_cl_variant<4, 1, 1, 2, 8>(stream, L, nt, extra, cin)
+                                            : launch_cl_variant<4, 1, 1, 2>(stream, L, nt, extra, cin); break;
+      case 11: r = (cin == 256 && !generic) ? launch_cl_variant<8, 1, 1, 2, 16>(stream, L, nt, extra, cin)
+                                            : launch_cl_variant<8, 1, 1, 2>(stream, L, nt, extra, cin); break;
       default: return -1;
     }
     if (variant_name) *variant_name = names[v];

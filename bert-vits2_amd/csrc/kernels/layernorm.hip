@@ -74,6 +74,20 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
       v[i] = x;
     }
   }
+  // ---- everything the epilogue needs goes in flight NOW, under the reductions: loaded after the second barrier (where the
+  // compiler leaves them) gamma / beta / residual / speaker vector / mask were a second exposed memory round trip per launch
+  float gm[CPT], bt[CPT], rr[CPT], vc[CPT], vc2[CPT];
+  const float mk = (A.mask && tok) ? A.mask[(int64_t)b * T + t] : 1.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    int c = ty + i * LN_G;
+    if (GUARD) c = c < C ? c : C - 1;
+    gm[i] = A.gamma[c];
+    bt[i] = A.beta[c];
+    rr[i] = A.res ? A.res[base + c * T + tcl] : 0.f;
+    vc[i] = A.vec ? A.vec[(int64_t)b * A.vec_bstride + c] : 0.f;
+    vc2[i] = A.out2 ? A.vec2[(int64_t)b * A.vec2_bstride + c] : 0.f;
+  }
   // ---- wave-level reduction over the channel groups (lanes tx + 8*cg), then across the 4 waves
   const int wv = threadIdx.x >> 6;
   float s = 0.f;
@@ -100,24 +114,19 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
   __syncthreads();
   const float rstd = 1.0f / sqrtf(((red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx])) / (float)C + A.eps);
   if (!tok) return;
-  const float mk = A.mask ? A.mask[(int64_t)b * T + t] : 1.f;
-  float rr[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    int c = ty + i * LN_G;
-    if (GUARD) c = c < C ? c : C - 1;
-    rr[i] = A.res ? A.res[base + c * T + t] : 0.f;
-  }
+  const bool gelu = A.post_gelu != 0;
+  float* const outp = A.out;
+  float* const out2p = A.out2;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = ty + i * LN_G;
     if (!GUARD || c < C) {
-      float y = (v[i] - mean) * rstd * A.gamma[c] + A.beta[c];
-      if (A.post_gelu) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+      float y = (v[i] - mean) * rstd * gm[i] + bt[i];
+      if (gelu) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
       y += rr[i];
-      if (A.vec) y += A.vec[(int64_t)b * A.vec_bstride + c];
-      A.out[base + c * T + t] = y * mk;
-      if (A.out2) A.out2[base + c * T + t] = (y + A.vec2[(int64_t)b * A.vec2_bstride + c]) * mk;
+      y += vc[i];
+      outp[base + c * T + t] = y * mk;
+      if (out2p) out2p[base + c * T + t] = (y + vc2[i]) * mk;
     }
   }
 }

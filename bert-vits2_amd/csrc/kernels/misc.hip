@@ -14,39 +14,50 @@ namespace bv2 {
 // ---------------------------------------------------------------------------------------------------------------
 // conv_post (C -> 1, k taps, no bias) + tanh, fed by leaky_relu(mean of the three ResBlock branches)
 // reference models.py:553-555 (NOTE slope 0.01 = F.leaky_relu default, not LRELU_SLOPE).
+// One workgroup = 256 consecutive samples: the activated input tile lrelu(mean of the branches) [C][256 + k - 1] is staged in LDS
+// ONCE (each element is read from HBM once instead of k times per branch, and the branch mean / leaky-ReLU are computed once per
+// element instead of once per tap), then every thread runs its C*k FMAs out of LDS.
 __global__ void __launch_bounds__(256) conv_post_kernel(const ConvPostArgs A) {
-  extern __shared__ float ws[];                     // [C*k]
-  for (int i = threadIdx.x; i < A.C * A.k; i += 256) ws[i] = A.w[i];
-  __syncthreads();
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= A.L) return;
+  extern __shared__ float ws[];                     // [C*k] weights, then [C][256 + k - 1] activated inputs
+  const int C = A.C, k = A.k, pad = (k - 1) / 2, W = 256 + k - 1;
+  float* xs = ws + C * k;
+  const int b = blockIdx.y, t0 = blockIdx.x * 256;
   int Lv = A.L;
   if (A.lens) {
     const int64_t lv = A.lens[b] * A.len_mul;
     Lv = lv < Lv ? (int)lv : Lv;
   }
-  const int pad = (A.k - 1) / 2;
-  float acc = 0.f;
-  for (int c = 0; c < A.C; ++c) {
-    const int64_t roff = (int64_t)b * A.x_bstride + (int64_t)c * A.x_rstride;
-    for (int j = 0; j < A.k; ++j) {
-      const int tt = t - pad + j;
-      if (tt < 0 || tt >= Lv) continue;
-      float v = A.x[0][roff + tt];
-      if (A.nsrc > 1) v += A.x[1][roff + tt];
-      if (A.nsrc > 2) v += A.x[2][roff + tt];
-      v *= A.in_scale;
-      v = v > 0.f ? v : v * A.slope;
-      acc += ws[c * A.k + j] * v;
+  for (int i = threadIdx.x; i < C * k; i += 256) ws[i] = A.w[i];
+  const float* x0 = A.x[0] + (int64_t)b * A.x_bstride;
+  const float* x1 = A.nsrc > 1 ? A.x[1] + (int64_t)b * A.x_bstride : nullptr;
+  const float* x2 = A.nsrc > 2 ? A.x[2] + (int64_t)b * A.x_bstride : nullptr;
+  const float in_scale = A.in_scale, slope = A.slope;
+  for (int e = threadIdx.x; e < C * W; e += 256) {
+    const int c = e / W, j = e - c * W;
+    const int tt = t0 - pad + j;
+    float v = 0.f;
+    if (tt >= 0 && tt < Lv) {
+      const int64_t o = (int64_t)c * A.x_rstride + tt;
+      v = x0[o];
+      if (x1) v += x1[o];
+      if (x2) v += x2[o];
+      v *= in_scale;
+      v = v > 0.f ? v : v * slope;
     }
+    xs[e] = v;
   }
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t >= A.L) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c)
+    for (int j = 0; j < k; ++j) acc += ws[c * k + j] * xs[c * W + threadIdx.x + j];
   A.out[(int64_t)b * A.out_bstride + t] = tanhf(acc);
 }
 
 int launch_conv_post(hipStream_t stream, const ConvPostArgs& a) {
   dim3 grid((a.L + 255) / 256, a.B);
-  hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), sizeof(float) * a.C * a.k, stream, a);
+  hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), sizeof(float) * (size_t)(a.C * a.k + a.C * (256 + a.k - 1)), stream, a);
   return BV2_CHECK_LAUNCH();
 }
 
