@@ -80,7 +80,7 @@ int conv_timeline_report(long long* meta, int max_launches);
 unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int tile, int ks, int cin, int L);   // per launch: {offset_u64, gx, gy, gz, tile id, nprob k0 | k1<<8 | k2<<16, cin, L}
 
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
-enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6 };
+enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6, TILE_128x64 = 7 };
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 // true when TILE_AUTO will pick the split-K kernel for this launch (small-N regime); only then may ksplit exceed 1
 bool conv_use_splitk(const ConvLaunch& L);
@@ -208,7 +208,7 @@ struct HcProb {
   int mask_pre, mask_post, act;
   int cin, cout, cout_pad, k, dil, pad_left;
 };
-struct HcLaunch { HcProb p; int B, L; };
+struct HcLaunch { HcProb p; int B, L; unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
 int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name);
 bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl);
 double conv_f16_flops(const HcLaunch& L);

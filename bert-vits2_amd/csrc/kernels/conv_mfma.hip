@@ -623,6 +623,8 @@ static const TileCfg kTiles[] = {
     {TILE_32x256, 32, 256, 5, "conv1d_mfma<32x256>"},    {TILE_64x64, 64, 64, 2, "conv1d_mfma<64x64>"},
     {TILE_32x128, 32, 128, 3, "conv1d_mfma<32x128>"},
 };
+// 128x64 (each wave 64 rows x 32 columns: every B fragment feeds two MFMAs): only reachable through the tuning hook, see below
+static const TileCfg kTile128x64 = {TILE_128x64, 128, 64, 2, "conv1d_mfma<128x64>"};
 
 // tuning experiments (tools/kbench.py drive these through bv2_test_set_tuning; 0 = the shipped heuristics)
 static int g_tune_splitk_waves = 0, g_tune_force_ck = 0, g_tune_no_ldsx = 0;
@@ -828,6 +830,10 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     // dispatcher balances them only if there are several times more workgroups than slots; per-tile prologue/epilogue
     // latency is also hidden by the co-resident workgroups.  conv_set_tuning overrides (tuning experiments).
     const long target = g_tune_tile_target > 0 ? g_tune_tile_target : 1536L;
+    if (g_tune_tile_target == -7 && max_cout_pad % 128 == 0 && 64 + max_extra <= 128) {     // tuning: force the 128x64 tile
+      if (variant_name) *variant_name = kTile128x64.name;
+      return launch_variant<2, 2, 2, 1, 2>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    }
     tile = TILE_32x128;
     double best_score = -1.0;
     bool reached = false;
@@ -854,6 +860,7 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     case TILE_64x64:   return launch_variant<2, 2, 1, 1, 2>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
     case TILE_32x128:  return launch_variant<1, 4, 1, 1, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
     case TILE_32x256:  return launch_variant<1, 4, 1, 2, 5>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    case TILE_128x64:  return launch_variant<2, 2, 2, 1, 2>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
   }
   return -1;
 }

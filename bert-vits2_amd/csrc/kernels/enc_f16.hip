@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
+  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int b = blockIdx.y / ngrp;
   const int cg = blockIdx.y - b * ngrp;
   const int mt = cg * WN + wid;
@@ -233,6 +235,7 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
       hc_stage_cl<NT>(xs, pitch, static_cast<const uint16_t*>(P.x) + (int64_t)b * P.x_bstride, cin, t0 - P.pad_left, rows,
                       c0, ck, P.Lin, tid);
     __syncthreads();
+    if (L.dbg && c0 == 0) ts1 = __builtin_amdgcn_s_memtime();
     if (active) {
       if constexpr (G > 0)
         hc_gemm_tm<NI, G>(acc, P.w + ((int64_t)mt * Utot + (int64_t)(c0 >> 4) * k) * 512, 16u * (unsigned)lane, k,
@@ -242,30 +245,60 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
                     xs + l31 * pitch + lh * 8, pitch, dil);
     }
   }
+  if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
   if (!active) return;
 
   const int cout = P.cout;
   if (OUT_CT) {
-    float* outp = static_cast<float*>(P.out) + (int64_t)b * P.out_bstride;
-    const float* resp = P.res ? P.res + (int64_t)b * P.res_bstride : nullptr;
+    // fp32 [C][T] epilogue.  The residual may alias the output (in-place updates), so a loop that loads a residual element,
+    // then stores an output element, is SERIALISED by the compiler — 16 x NI dependent L2 round trips (tools/timeline.py:
+    // 38-43k cycles, more than the whole rest of the workgroup).  All residual / bias loads of the tile are issued first (each
+    // thread only ever reads elements it writes itself, and reads them before), then the arithmetic, then the stores;
+    // 32-bit offsets from wave-uniform bases.
+    float* const outp = static_cast<float*>(P.out) + (int64_t)b * P.out_bstride;
+    const int res_mode = P.res_mode, act = P.act, mask_pre = P.mask_pre, mask_post = P.mask_post;
+    const float* const resp = res_mode != RES_NONE ? P.res + (int64_t)b * P.res_bstride : nullptr;
+    const float* const biasp = P.bias;
+    const float* const omp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : nullptr;
+    const unsigned o_rs = (unsigned)P.out_rstride;
+    const int Lout = L.L;
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      co = co < cout ? co : cout - 1;
+      bs[r] = biasp ? biasp[co] : 0.f;
+    }
+    float rv[NI][16], om[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int t = t0 + ni * 32 + l31;
-      if (t >= L.L) continue;
-      const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + t] : 1.f;
+      const int tc = t < Lout ? t : Lout - 1;
+      om[ni] = omp ? omp[tc] : 1.f;
+      if (resp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          co = co < cout ? co : cout - 1;
+          rv[ni][r] = resp[(unsigned)co * o_rs + (unsigned)tc];
+        }
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int t = t0 + ni * 32 + l31;
+      if (t >= Lout) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (co >= cout) continue;
-        float v = acc[ni][r];
-        if (P.bias) v += P.bias[co];
-        if (P.act == ACT_RELU) v = fmaxf(v, 0.f);
-        if (P.mask_pre) v *= om;
-        const int64_t oidx = (int64_t)co * P.out_rstride + t;
-        if (P.res_mode == RES_ADD) v += resp[oidx];
-        else if (P.res_mode == RES_RSUB) v = resp[oidx] - v;
-        if (P.mask_post) v *= om;
-        outp[oidx] = v;
+        float v = acc[ni][r] + bs[r];
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        if (mask_pre) v *= om[ni];
+        if (res_mode == RES_ADD) v += rv[ni][r];
+        else if (res_mode == RES_RSUB) v = rv[ni][r] - v;
+        if (mask_post) v *= om[ni];
+        outp[(unsigned)co * o_rs + (unsigned)t] = v;
       }
     }
   } else {
@@ -292,6 +325,14 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
       }
     }
   }
+  if (L.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* d = L.dbg + 8ull * ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x);
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+    d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    d[6] = (unsigned long long)k; d[7] = 1;
+  }
 }
 
 bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl) {
@@ -312,7 +353,9 @@ static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, 1);
   auto kern = conv_f16_kernel<WN, NI, IN_CT, OUT_CT, G>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WN), lds, stream, L, ngrp);
+  HcLaunch Lt = L;
+  Lt.dbg = timeline_slice(grid.x, grid.y, 1, 99000 + WN * 100 + NI * 10 + (IN_CT ? 2 : 0) + (OUT_CT ? 1 : 0), p.k, p.cin, L.L);   // 99xxx: fp16 conv
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WN), lds, stream, Lt, ngrp);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -41,6 +41,14 @@ def main():
         bm, bn = tile // 1000, tile % 1000
         kk = [(ks >> (8 * j)) & 255 for j in range(3) if (ks >> (8 * j)) & 255]
         line = f"#{i:3d} {bm}x{bn} k={kk} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU), span {span:9.0f} (per-XCD {min(spans)}..{max(spans)})"
+        if 99000 <= tile < 100000:
+            t = tile - 99000
+            wn, ni, io = t // 100, (t // 10) % 10, t % 10
+            k = int(ks & 255)
+            cyc = (cin / 16) * k * ni * 32
+            print(f"#{i:3d} fp16 conv {wn}w NI{ni} in_ct={io >> 1} out_ct={io & 1} k={k} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.1f}/CU): first stage {np.mean(v[:, 1] - v[:, 0]):7.0f} "
+                  f"rest (gemm + later chunks) {np.mean(v[:, 2] - v[:, 1]):8.0f} (MFMA-only {cyc:7.0f}) epilogue {np.mean(v[:, 3] - v[:, 2]):7.0f} life {np.mean(v[:, 3] - v[:, 0]):8.0f}")
+            continue
         if 77000 <= tile < 78000 or 88000 <= tile < 89000:
             what = "attention" if tile < 78000 else "resblock_fused"
             print(f"#{i:3d} {what} id {tile} k={kk} D/C {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU): phase1 {np.mean(v[:, 1] - v[:, 0]):7.0f} "
