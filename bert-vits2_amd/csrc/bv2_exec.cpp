@@ -154,6 +154,7 @@ constexpr int kSlabs = BV2_MAX_KSPLIT;
 inline int attn_ld(int T) { return (T + 31) / 32 * 32; }
 inline int qkv_rows(const EncoderW& e) { return 3 * e.hidden + e.heads * (2 * kAttnWindow + 1); }
 
+inline int n_slabs(int B, int T);
 void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask, const float* spk, int spk_bstride,
                  int B, int T, const char* tapname, bool f16 = false, float* out2 = nullptr, const float* vec2 = nullptr,
                  int vec2_bstride = 0) {
@@ -173,6 +174,12 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     AttnArgs a;
     a.qkv = b.qkv; a.ld = ld; a.mask = mask; a.erv = c.W(L.erv.off); a.out = b.att;
     a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow; a.f16 = f16 ? 1 : 0;
+    // small-N regime (the one where `s` holds partial slabs): conv_o runs inside the attention kernel, head h -> slab h
+    const bool fuse_o = !f16 && !c.h->no_fused_attn_o && n_slabs(B, T) >= e.heads && L.o.k == 1 && L.o.cin == H;
+    if (fuse_o) {
+      a.wo = c.W(L.o.w_off); a.bo = c.W(L.o.b_off); a.res = b.x; a.o_out = b.s; a.o_slab_stride = b.slab;
+      a.Co = L.o.cout; a.wo_groups = L.o.cin_pad / 8;
+    }
     if (!c.rc) {
       const int pi = c.prof_begin("attention");
       const int r = launch_attention(c.s, a);
@@ -180,7 +187,9 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       if (r) c.fail("attention", r);
     }
     int ns = 1;
-    if (f16) {
+    if (fuse_o) {
+      ns = e.heads;
+    } else if (f16) {
       HcProb q = c.hprob(L.o, b.att, true, b.s, true, T);
       q.res = b.x; q.res_mode = RES_ADD;
       c.conv_h(q, B, T, "enc.o");

@@ -123,6 +123,7 @@ struct bv2_handle {
   int flow_dtype = BV2_F32;          // transformer-flow Encoder convs: BV2_F32 (conv_mfma.hip) or BV2_F16 (enc_f16.hip)
   // bv2_set_option switches (tests compare the fused kernels with the layer-wise ones)
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
+  bool no_fused_attn_o = false;      // "fused_attn_o" = 0: conv_o as its own launch after the attention kernel
   bool no_fused_dds = false;         // "fused_dds" = 0: DDSConv layers as 3 launches each
   // profiling
   bool prof_on = false;

@@ -259,6 +259,11 @@ struct AttnArgs {
   float* out;               // [B][H*D][T]
   int B, H, D, T, W;
   int f16;                  // 1: QK^T and PV on the fp16 matrix core (operands rounded in registers, everything else fp32)
+  // fused output projection (fp32 form only; wo == nullptr: plain attention output in `out`): each head's workgroup multiplies its
+  // tile by its K-slice of the packed 1x1 weight `wo` (conv_w_index order, wo_groups = cin_pad / 8) and writes partial slab h of
+  // o_out [B][Co][T] (slab h at o_out + h * o_slab_stride; head 0 adds bias `bo` and residual `res` [B][Co][T])
+  const float* wo = nullptr; const float* bo = nullptr; const float* res = nullptr;
+  float* o_out = nullptr; int64_t o_slab_stride = 0; int Co = 0, wo_groups = 0;
   unsigned long long* dbg = nullptr;   // tools/timeline.py only
 };
 int launch_attention(hipStream_t stream, const AttnArgs& a);

@@ -323,7 +323,63 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   // ---- normalise, add relative-value term, store (coalesced over queries)
   float* op = A.out + (int64_t)b * HD * T + (int64_t)(h * D) * T;
   const int i = tid & 31, ig = i0 + i;
-  if (ig < T) {
+  if (A.wo) {
+    // Fused output projection (conv_o, attentions.py:269): the head's normalised [D][32 queries] tile goes to LDS (the query tile's
+    // region: every wave is past the main loop) and the workgroup multiplies it by ITS K-slice of W_o — columns [hD, hD + D) of
+    // the fragment-ordered 1x1 weight — on the fp32 matrix core: one 32-row tile per wave, D/2 MFMAs.  Head h writes partial slab
+    // h of the [B][C_out][T] output (head 0 adds the bias and the residual); the LayerNorm that follows sums the H slabs exactly as
+    // it sums split-K slabs.  Removes the conv_o launch (and its HBM round trip of the attention output) from every layer.
+    float* Of = Qs;
+    for (int c = tid >> 5; c < D; c += 2 * NW) {
+      float o = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl) o += Os[sl * (D * AQ) + c * AQ + i];
+      o *= il;
+      for (int r = 0; r < NR; ++r) o += Sb[r * AQ + i] * Ev[r * D + c];
+      Of[c * AQ + i] = ig < T ? o : 0.f;
+    }
+    const int Co = A.Co, G = A.wo_groups;
+    const float* const wo = A.wo;
+    const float* const bo = h == 0 ? A.bo : nullptr;
+    const float* const resp = h == 0 && A.res ? A.res + (int64_t)b * Co * T : nullptr;
+    float* const ob = A.o_out + (int64_t)h * A.o_slab_stride + (int64_t)b * Co * T;
+    __syncthreads();
+    for (int mt = wid; mt * 32 < Co; mt += NW) {
+      f32x4 wr[D / 8];
+      const f32x4* wp = reinterpret_cast<const f32x4*>(wo) + ((int64_t)mt * G + h * (D / 8)) * 64 + lh * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < D / 8; ++g) wr[g] = wp[g * 64];
+      // epilogue operands in flight under the MFMAs
+      float bs[16], rv[16];
+      const int row0 = mt * 32 + 4 * lh;
+      const int igc = iok ? iq : T - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = row0 + (r & 3) + 8 * (r >> 2);
+        row = row < Co ? row : Co - 1;
+        bs[r] = bo ? bo[row] : 0.f;
+        rv[r] = resp ? resp[(int64_t)row * T + igc] : 0.f;
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < D / 8; ++g) {
+        const float* ob4 = Of + (8 * g + lh) * AQ + l31;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[g].x, ob4[0 * AQ], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[g].y, ob4[2 * AQ], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[g].z, ob4[4 * AQ], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[g].w, ob4[6 * AQ], acc, 0, 0, 0);
+      }
+      if (iok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2);
+          if (row < Co) ob[(int64_t)row * T + iq] = (acc[r] + bs[r]) + rv[r];
+        }
+      }
+    }
+  } else if (ig < T) {
     for (int c = tid >> 5; c < D; c += 2 * NW) {
       float o = 0.f;
 #pragma unroll
@@ -374,6 +430,7 @@ static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int n
 
 int launch_attention(hipStream_t stream, const AttnArgs& a) {
   if (a.W > AMAXW || a.W < 0 || a.T < 1 || a.B < 1 || a.H < 1 || a.ld % 32 || a.ld < a.T) return -1;
+  if (a.wo && (a.f16 || !a.o_out || a.Co < 1 || a.wo_groups * 8 < a.H * a.D)) return -1;   // fused conv_o: fp32 form only
   dim3 grid((a.T + AQ - 1) / AQ, a.H, a.B);
   const int ntiles = (a.T + AK - 1) / AK;
   switch (a.D) {

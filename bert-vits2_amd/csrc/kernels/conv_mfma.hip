@@ -57,7 +57,7 @@ __device__ __forceinline__ f32x4 ld_off4(const float* base, unsigned byte_off) {
 // (Measured and not kept: __launch_bounds__(256, 5) for the 64x64 tile — 96 registers, five workgroups per CU instead of four,
 // 6 spilled registers: the Generator at batch 1 went 2.819 -> 2.856 ms.)
 template <int WM, int WN, int MI, int NI, int CK, int XS>
-__global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles, const int per_xcd) {
+__global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
   constexpr int XP = XS * 64;
@@ -66,7 +66,27 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   static_assert(WM * WN == 4, "4 waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const ConvProb& P = L.p[blockIdx.z];
+  // Placement.  Default: grid (time tiles, m-tiles x batch, problems) — dispatch order = problems in launch order (the host puts
+  // the most expensive first), so when there are several times more workgroups than slots the long ones start first.
+  // snake_n > 0 (every workgroup of the launch is resident at once, <= 4 per CU): dispatch is a plain round-robin — workgroup
+  // p of an XCD lands on CU p % 32 — so WHICH problems meet on a CU is decided by the order alone.  With the problems sorted by
+  // cost, round r takes its 32 workgroups in ascending order for even r and descending for odd r ("snake"): the CU that got an
+  // expensive tile in one round gets a cheap one in the next (C2 stage 0, k = 11/7/3 on 576 workgroups: worst CU 21 -> 18 cost
+  // units at a mean of 15.75; tools/timeline.py).
+  int pz = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
+  if (snake_n > 0) {
+    const int xcd = blockIdx.x & 7, pp = blockIdx.x >> 3;
+    if (pp >= snake_n) return;
+    const int r = pp >> 5, cc = pp & 31;
+    const int rem = snake_n - (r << 5) < 32 ? snake_n - (r << 5) : 32;
+    const int sidx = (r << 5) + ((r & 1) ? rem - 1 - cc : cc);
+    const int per_prob = per_xcd * mtiles * L.B;
+    pz = sidx / per_prob;
+    const int rest = sidx - pz * per_prob;
+    by = rest / per_xcd;
+    bx = ((rest - by * per_xcd) << 3) | xcd;                    // decoded below exactly like the default form
+  }
+  const ConvProb& P = L.p[pz];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,9 +94,9 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   const int wm = wid / WN, wn = wid % WN;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
   if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
-  const int b = blockIdx.y / mtiles;
-  const int m0 = (blockIdx.y - b * mtiles) * BM;
-  const int vt = per_xcd ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const int b = by / mtiles;
+  const int m0 = (by - b * mtiles) * BM;
+  const int vt = per_xcd ? (bx & 7) * per_xcd + (bx >> 3) : bx;
   const int t0 = vt * BN;
   if (t0 >= L.L) return;
   if (m0 >= P.cout_pad) return;
@@ -334,7 +354,8 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
   }
   if (L.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);                                  // the epilogue's stores have been issued and acknowledged
-    unsigned long long* d = L.dbg + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    unsigned long long* d = L.dbg + 8ull * (snake_n > 0 ? (unsigned long long)blockIdx.x
+                                                        : ((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
     d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
     d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);               // HW_ID
     d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);              // XCC_ID
@@ -627,11 +648,12 @@ static const TileCfg kTiles[] = {
 static const TileCfg kTile128x64 = {TILE_128x64, 128, 64, 2, "conv1d_mfma<128x64>"};
 
 // tuning experiments (tools/kbench.py drive these through bv2_test_set_tuning; 0 = the shipped heuristics)
-static int g_tune_splitk_waves = 0, g_tune_force_ck = 0, g_tune_no_ldsx = 0;
+static int g_tune_splitk_waves = 0, g_tune_force_ck = 0, g_tune_no_ldsx = 0, g_tune_no_snake = 0;
 static long g_tune_tile_target = 0;
 void conv_set_tuning(int splitk_waves, int force_ck, long tile_target) {
   g_tune_no_ldsx = splitk_waves >= 100 ? 1 : 0;                     // +100: the non-staged split-K form (A/B comparisons)
-  g_tune_splitk_waves = splitk_waves % 100; g_tune_force_ck = force_ck; g_tune_tile_target = tile_target;
+  g_tune_splitk_waves = splitk_waves % 100; g_tune_force_ck = force_ck % 100; g_tune_tile_target = tile_target;
+  g_tune_no_snake = force_ck >= 100 ? 1 : 0;                        // force_ck + 100: plain z-major placement (A/B comparisons)
 }
 
 static unsigned long long* g_tl_buf = nullptr;
@@ -675,18 +697,36 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L0, int ck, int 
   const int ntx = (L0.L + BN - 1) / BN;
   const int per_xcd = (ntx % 8 == 0 || ntx >= 64) ? (ntx + 7) / 8 : 0;      // contiguous per-XCD ranges only if they balance
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, mtiles * L0.B, L0.nprob);
-  const ConvLaunch L = with_timeline(L0, grid, BM * 1000 + BN);
+  // cost-balanced ("snake") placement: problems of different cost, and the whole launch resident at once (<= 4 workgroups per
+  // CU) so that dispatch is a plain round-robin over the CUs — see the kernel
+  ConvLaunch Ls = L0;
+  int snake_n = 0;
+  if (per_xcd && L0.nprob > 1 && !g_tune_no_snake) {
+    const long total = (long)per_xcd * 8 * mtiles * L0.B * L0.nprob;
+    bool differ = false;
+    for (int i = 1; i < L0.nprob; ++i)
+      if (L0.p[i].k * L0.p[i].cin_pad != L0.p[0].k * L0.p[0].cin_pad) differ = true;
+    if (differ && total > 256 && total <= 1024) {
+      for (int i = 0; i < Ls.nprob; ++i)                 // most expensive problem first (insertion sort, <= 3 entries)
+        for (int j = i; j > 0 && Ls.p[j].k * Ls.p[j].cin_pad > Ls.p[j - 1].k * Ls.p[j - 1].cin_pad; --j) {
+          const ConvProb t = Ls.p[j]; Ls.p[j] = Ls.p[j - 1]; Ls.p[j - 1] = t;
+        }
+      snake_n = per_xcd * mtiles * L0.B * L0.nprob;
+      grid = dim3(snake_n * 8, 1, 1);
+    }
+  }
+  const ConvLaunch L = with_timeline(Ls, grid, BM * 1000 + BN);
   const int nxbuf = max_chunks > 1 ? 2 : 1;     // a single-chunk problem never re-stages its X tile
   // weights go global -> registers; LDS holds only the (double-buffered) X chunk
   if (ck == 32) {
     const size_t lds = sizeof(float) * (size_t)(nxbuf * 32 * XS * 64);
     auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 32, XS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd, snake_n);
   } else {
     const size_t lds = sizeof(float) * (size_t)(nxbuf * 16 * XS * 64);
     auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 16, XS>;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd, snake_n);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -830,9 +870,19 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     // dispatcher balances them only if there are several times more workgroups than slots; per-tile prologue/epilogue
     // latency is also hidden by the co-resident workgroups.  conv_set_tuning overrides (tuning experiments).
     const long target = g_tune_tile_target > 0 ? g_tune_tile_target : 1536L;
-    if (g_tune_tile_target == -7 && max_cout_pad % 128 == 0 && 64 + max_extra <= 128) {     // tuning: force the 128x64 tile
+    // tuning experiments (tools/tune_tiles.py): negative targets force one tile for one stage shape
+    if (((g_tune_tile_target == -7 && max_cout_pad % 128 == 0) || (g_tune_tile_target == -8 && max_cout_pad == 128)) &&
+        64 + max_extra <= 128) {
       if (variant_name) *variant_name = kTile128x64.name;
       return launch_variant<2, 2, 2, 1, 2>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    }
+    if ((g_tune_tile_target == -9 && max_cout_pad == 64) || (g_tune_tile_target == -10 && max_cout_pad == 128)) {
+      if (variant_name) *variant_name = "conv1d_mfma<64x128>";
+      return launch_variant<2, 2, 1, 2, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    }
+    if (g_tune_tile_target == -11 && max_cout_pad == 128) {
+      if (variant_name) *variant_name = "conv1d_mfma<128x128>";
+      return launch_variant<2, 2, 2, 2, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
     }
     tile = TILE_32x128;
     double best_score = -1.0;

@@ -89,6 +89,55 @@ __device__ __forceinline__ void rf_gemm(f32x16& acc, const float* wp, unsigned w
   for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 }
 
+// C = 16: the 32-row MFMA would spend half of its rows on zero weights.  v_mfma_f32_16x16x4_f32 instead (16 rows x 16 columns, K = 4,
+// 8 passes): a wave's 32 columns are two 16-column blocks (two independent accumulator chains), and ONE float4 per lane per tap
+// feeds the tap's four K steps — lane (m = l & 15, kk = l >> 4) takes rows 0..15 of the (group kk >> 1, tap j, half kk & 1) piece of
+// the ordinary fragment-ordered stream, i.e. channels 8(kk >> 1) + 2q + (kk & 1) for q = 0..3; MFMA q therefore pairs it with row
+// 8(kk >> 1) + (kk & 1) + 2q of the LDS tile (any K-index <-> channel assignment works as long as A and B agree).  Half the MFMA
+// cycles per tap of the 32x32x2 form, same number of LDS reads.   D layout: lane (n = l & 15, rg = l >> 4), register r -> row 4 rg + r.
+__device__ __forceinline__ void rf_gemm16(f32x4 (&acc)[2], const float* wp, int k, const float* bs, int bp, int col0, int tstep,
+                                          int lane) {
+  const int n = lane & 15, kk = lane >> 4;
+  const unsigned w_lane = 16u * (unsigned)(((kk >> 1) * k * 2 + (kk & 1)) * 32 + n);     // + tap j * 1 KB
+  const float* b0 = bs + (8 * (kk >> 1) + (kk & 1)) * bp + col0 + n;
+  f32x4 ar[RF_PD];
+  int lu = 0;
+  auto load_tap = [&](int slot) __attribute__((always_inline)) {
+    const int uc = lu < k ? lu : k - 1;                             // past the end: re-read the last tap, result unused
+    ar[slot] = rf_ld4(wp, w_lane + (unsigned)uc * 1024u);
+    ++lu;
+  };
+#pragma unroll
+  for (int i = 0; i < RF_PD; ++i) { load_tap(i); __builtin_amdgcn_sched_barrier(0); }
+  float bq[2][4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { bq[0][q][0] = b0[2 * q * bp]; bq[0][q][1] = b0[2 * q * bp + 16]; }
+  for (int u0 = 0; u0 < k; u0 += RF_PD) {
+#pragma unroll
+    for (int i = 0; i < RF_PD; ++i) {
+      if (u0 + i < k) {
+        const float* b = b0 + (u0 + i + 1 < k ? u0 + i + 1 : u0 + i) * tstep;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bq[(i & 1) ^ 1][q][0] = b[2 * q * bp]; bq[(i & 1) ^ 1][q][1] = b[2 * q * bp + 16]; }
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].x, bq[i & 1][0][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].x, bq[i & 1][0][1], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].y, bq[i & 1][1][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].y, bq[i & 1][1][1], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].z, bq[i & 1][2][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].z, bq[i & 1][2][1], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].w, bq[i & 1][3][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i].w, bq[i & 1][3][1], acc[1], 0, 0, 0);
+      }
+      load_tap(i);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <bool C16>
 __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                               // [C][RF_XP]   lrelu(x), zero outside [0, L)
@@ -147,7 +196,26 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
   if (F.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 1: intermediate columns [32*wid, 32*wid + 32)
-  {
+  if constexpr (C16) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    rf_gemm16(acc, P.w1, k, Xs, RF_XP, 32 * wid, dil, lane);
+    const int n = lane & 15, rg = lane >> 4;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = P.b1[4 * rg + r];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int col = 32 * wid + 16 * nb + n;
+      const int t = t0 - RF_LEAD + col;
+      const bool tin = t >= 0 && t < Lv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[nb][r] + bv[r];
+        v = v < 0.f ? v * slope : v;
+        Tm[(4 * rg + r) * RF_TP + col] = tin ? v : 0.f;
+      }
+    }
+  } else {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -168,7 +236,30 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
   if (F.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 2: output columns [32*wid, 32*wid + 32) of the tile, waves 0..6
-  if (wid < RF_BN / 32) {
+  if (C16 && wid < RF_BN / 32) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    rf_gemm16(acc, P.w2, k, Tm, RF_TP, RF_LEAD + 32 * wid - h2, 1, lane);
+    const int n = lane & 15, rg = lane >> 4;
+    float* const op = P.out + (int64_t)b * C * L;
+    const float* const b2p = P.b2;
+    float bv[4], xv[2][4];
+    int tt[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = b2p[4 * rg + r];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      tt[nb] = t0 + 32 * wid + 16 * nb + n;
+      const int tc = tt[nb] < L ? tt[nb] : L - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[nb][r] = rf_ld(xp, 4u * ((unsigned)(4 * rg + r) * (unsigned)L + (unsigned)tc));
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (tt[nb] < L) op[(unsigned)(4 * rg + r) * (unsigned)L + (unsigned)tt[nb]] = (acc[nb][r] + bv[r]) + xv[nb][r];
+  }
+  if (!C16 && wid < RF_BN / 32) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -216,7 +307,7 @@ int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F) {
   if ((int64_t)F.C * F.L >= (1ll << 29)) return -2;              // 32-bit byte offsets inside one batch item
   dim3 grid((F.L + RF_BN - 1) / RF_BN, F.B, F.nprob);
   const size_t lds = sizeof(float) * (size_t)(32 * RF_XP + 32 * RF_TP);
-  auto kern = resblock_fused_kernel;
+  auto kern = F.C == 16 ? resblock_fused_kernel<true> : resblock_fused_kernel<false>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   FusedLaunch Ft = F;
   {

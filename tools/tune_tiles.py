@@ -25,10 +25,13 @@ def main():
     z = torch.randn(B, hp.inter_channels, Ty, device="cuda")
     yl = torch.full((B,), Ty, dtype=torch.int64, device="cuda")
     g = torch.randn(B, hp.gin_channels, device="cuda")
-    for occ, target in ((0, 0), (0, -7)):
+    names = {0: "default tile picker, cost-balanced placement", -7: "128x64 tile where C_out % 128 == 0", -8: "128x64 tile at C = 128 only",
+             -9: "64x128 tile at C = 64", -10: "64x128 tile at C = 128", -11: "128x128 tile at C = 128"}
+    for occ, target in ((0, 0), (100, 0), (0, -7), (0, -8), (0, -9), (0, -10), (0, -11)):
         lib.bv2_test_set_tuning(0, occ, target)
         for _ in range(3):
             m.stage_generator(z, yl, g)
+        torch.cuda.synchronize()
         ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,7 +42,7 @@ def main():
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 10)
         ts.sort()
-        print(f"{'128x64 tile forced where C_out % 128 == 0' if target == -7 else 'default tile picker'}: generator {ts[2]:.4f} ms/pass (min {ts[0]:.4f})")
+        print(f"{'plain z-major placement (no snake)' if occ == 100 else names[target]}: generator {ts[2]:.4f} ms/pass (min {ts[0]:.4f})", flush=True)
     lib.bv2_test_set_tuning(0, 0, 0)
 
 
