@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the secondary configs 3 / 4 / 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=0|1",
+                    help="bv2_set_option switch for A/B runs (fused_attn_o, overlap_dp, fused_dds, fused_resblock)")
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
     return ap.parse_args()
 
@@ -365,6 +367,10 @@ def main():
     log(f"rank {rank}/{world}: packing / distributing weights")
     t_bcast = sharding.distribute_weights(model, dev, src=0)
     log("weights attached")
+    for kv in args.option:
+        key, val = kv.split("=")
+        model.set_option(key, int(val))
+        log(f"option {key} = {val}")
 
     res = run_config(primary, model, hp, dev, rank, world, args.steps, args.warmup, overrides, args.full_profile)
     log(f"config {primary}: timed region {res['dt']:.3f}s for {args.steps} steps")

@@ -54,6 +54,9 @@ int bv2_create(const bv2_config* cfg, bv2_handle** out) {
 void bv2_destroy(bv2_handle* h) {
   if (!h) return;
   for (auto& r : h->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
   delete h;
 }
 
@@ -384,6 +387,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   if (k == "fused_resblock") h->no_fused_resblock = value == 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;
   else if (k == "fused_attn_o") h->no_fused_attn_o = value == 0;
+  else if (k == "overlap_dp") h->no_overlap_dp = value == 0;
   else { h->err = "bv2_set_option: unknown key '" + k + "'"; return -1; }
   return 0;
   BV2_CATCH(h)

@@ -561,8 +561,31 @@ int run_encode(bv2_handle* h, hipStream_t s, const bv2_encode_in& in, const bv2_
   enc_p_core(c, P, in.x, in.tone, in.language, berts, mask, spk, 3 * H, B, T, out.x, out.m_p, out.logs_p, P.dp0, dp_c,
              in.bert_index, in.bert_cols);
   float* logw_dp = out.logw_dp ? out.logw_dp : P.logw_dp;
-  dp_core(c, P, P.dp0, mask, B, T, logw_dp);
+  // The two duration predictors only share their input (the encoder output).  Optional ("overlap_dp", default off — measured
+  // slower, see bv2_internal.h): the deterministic one (5 short launches) on the handle's side stream beside the stochastic one
+  // (17 launches), joined before the durations kernel.  Disjoint workspace.
+  bool forked = false;
+  if (!h->no_overlap_dp && !c.rc) {
+    if (!h->side_stream) {
+      if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        h->no_overlap_dp = true;                   // no side stream on this system: stay on the caller's stream
+      }
+    }
+    if (!h->no_overlap_dp && hipEventRecord(h->ev_fork, s) == hipSuccess &&
+        hipStreamWaitEvent(h->side_stream, h->ev_fork, 0) == hipSuccess) {
+      Ctx c2{h, h->side_stream, m, h->blob};
+      dp_core(c2, P, P.dp0, mask, B, T, logw_dp);
+      if (c2.rc && !c.rc) c.rc = c2.rc;
+      if (hipEventRecord(h->ev_join, h->side_stream) != hipSuccess) c.fail("dp join", -6);
+      forked = true;
+    }
+  }
+  if (!forked) dp_core(c, P, P.dp0, mask, B, T, logw_dp);
   sdp_core(c, P, out.x, mask, sdp_c, 3 * H, B, T);
+  if (forked && hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess) c.fail("dp join", -6);
   run_durations(c, P, logw_dp, mask, in.sdp_ratio, in.length_scale, out.logw_sdp ? out.logw_sdp : P.logw_sdp, out.logw,
                 out.w_ceil, out.y_lengths, B, T);
   return c.rc;

@@ -125,6 +125,11 @@ struct bv2_handle {
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
   bool no_fused_attn_o = false;      // "fused_attn_o" = 0: conv_o as its own launch after the attention kernel
   bool no_fused_dds = false;         // "fused_dds" = 0: DDSConv layers as 3 launches each
+  bool no_overlap_dp = true;         // "overlap_dp" = 1: the (independent) DurationPredictor on an internal side stream, forked from and
+  // joined back into the caller's stream with events (created on first use; capturable).  OFF by default: measured on MI355X at
+  // batch 1 the fork/join costs more than the 5 short launches it hides (4.70 -> 4.82 ms per step eager, 4.75 -> 4.78 replayed).
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling
   bool prof_on = false;
   int prof_mode = 1;                 // 1: every MFMA kernel launch, 2: Generator (dec.*) launches only

@@ -249,6 +249,10 @@ void bv2_graph_destroy(bv2_graph* graph);
 /* Kernel-selection switches, for tests that hold the fused kernels to the layer-wise ones (default 1 = fused):
  *   "fused_resblock"  the narrow Generator stages as whole-ResBlock / fused-pair kernels (0: one conv per launch)
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
+ *   "fused_attn_o"    MultiHeadAttention.conv_o inside the attention kernel in the small-batch fp32 regime: head h writes partial
+ *                     slab h, the LayerNorm sums the slabs (0: conv_o as its own launch)
+ *   "overlap_dp"      default 0: 1 runs the DurationPredictor on an internal side stream beside the stochastic one (fork / join
+ *                     with events on the caller's stream; measured slower at batch 1, kept for experiments)
  * Captured graphs keep whatever was selected when they were recorded. */
 int bv2_set_option(bv2_handle* h, const char* key, int value);
 
