@@ -707,6 +707,10 @@ void bv2_test_conv_timeline(void* dev_buf, long long capacity_u64) {
 int bv2_test_conv_timeline_report(long long* meta, int max_launches) { return conv_timeline_report(meta, max_launches); }
 
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target) { conv_set_tuning(splitk_waves, force_ck, tile_target); }
+void bv2_test_set_variants(const char* cl_spec, int cl_generic, int hc_generic) {
+  conv_cl_set_tuning(cl_spec, cl_generic);
+  conv_f16_set_tuning(hc_generic);
+}
 
 int64_t bv2_test_dds_pack_floats(int C) {
   // [dww 3C][dwb C][g1 C][b1 C][g2 C][b2 C][pre_w C][pre_b C] + conv pack (1x1 C->C) + post conv pack (1x1 C->C rows max)

@@ -143,6 +143,7 @@ struct ClProb {
 struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; const int64_t* lens = nullptr; int len_mul = 1;
                   unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
 int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** variant_name);
+void conv_cl_set_tuning(const char* spec, int generic);      // tests / tuning only (bv2_test_set_variants)
 bool conv_cl_bf16_supported(int cin, int cout, int k, int dil);
 // element index (bf16 units) of weight (tap j, input channel ci, output channel co) in the packed stream
 inline int64_t cl_w_index(int j, int ci, int co, int cin, int k) {
@@ -210,6 +211,7 @@ struct HcProb {
 };
 struct HcLaunch { HcProb p; int B, L; unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
 int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name);
+void conv_f16_set_tuning(int generic);                       // tests / tuning only (bv2_test_set_variants)
 bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl);
 double conv_f16_flops(const HcLaunch& L);
 double conv_f16_bytes(const HcLaunch& L);

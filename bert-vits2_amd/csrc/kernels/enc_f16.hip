@@ -359,9 +359,12 @@ static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+static bool g_hc_generic = false;     // tests / tuning only (bv2_test_set_variants): the generic GEMM loop instead of the C_in-specialised one
+void conv_f16_set_tuning(int generic) { g_hc_generic = generic != 0; }
+
 template <int WN, int NI, bool IN_CT, bool OUT_CT>
 static int launch_hc(hipStream_t stream, const HcLaunch& L, int nt) {
-  static const bool generic = getenv("BV2_HC_GENERIC") != nullptr;
+  const bool generic = g_hc_generic;
   if (!generic && L.p.cin == 192) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 12>(stream, L, nt);
   if (!generic && L.p.cin % 256 == 0) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 16>(stream, L, nt);
   return launch_hc_g<WN, NI, IN_CT, OUT_CT, 0>(stream, L, nt);

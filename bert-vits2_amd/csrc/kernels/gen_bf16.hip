@@ -406,10 +406,18 @@ static int launch_cl_variant(hipStream_t stream, const ClLaunch& L, int nt, size
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// tuning experiments: BV2_CL_VARIANT=<nt>:<id>[,<nt>:<id>...] forces variant <id> for launches with <nt> 32-channel tiles
+// tuning experiments (bv2_test_set_variants, include/bv2_testing.h — no environment variables in the product path):
+// spec "<nt>:<id>[,<nt>:<id>...]" forces variant <id> for launches with <nt> 32-channel tiles; generic = 1 forces the generic GEMM loop
+static char g_cl_spec[128] = "";
+static bool g_cl_generic = false;
+void conv_cl_set_tuning(const char* spec, int generic) {
+  std::strncpy(g_cl_spec, spec ? spec : "", sizeof(g_cl_spec) - 1);
+  g_cl_spec[sizeof(g_cl_spec) - 1] = 0;
+  g_cl_generic = generic != 0;
+}
 static int forced_variant(int nt) {
-  static const char* e = getenv("BV2_CL_VARIANT");
-  if (!e) return -1;
+  const char* e = g_cl_spec;
+  if (!*e) return -1;
   for (const char* p = e; *p;) {
     const int a = atoi(p);
     const char* c = strchr(p, ':');
@@ -443,11 +451,11 @@ int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** vari
   static const char* names[] = {"conv_cl_bf16<8x1>", "conv_cl_bf16<4x1>", "conv_cl_bf16<2x2>", "conv_cl_bf16<1x4>",
                                 "conv_cl_bf16<4x1,2x4>", "conv_cl_bf16<2x2,2x4>", "conv_cl_bf16<2x4,2x2>", "conv_cl_bf16<1x4,2x4>",
                                 "conv_cl_bf16<4x2,2x2>", "conv_cl_bf16<1x8,2x2>", "conv_cl_bf16<4x1,t64>", "conv_cl_bf16<8x1,t64>"};
-  static const bool generic = getenv("BV2_CL_GENERIC") != nullptr;
+  const bool generic = g_cl_generic;
   int r = -1;
   for (int attempt = 0; attempt < 2; ++attempt) {
     switch (v) {
-      // C_in known at compile time for the ResBlock widths: tap-major GEMM (BV2_CL_GENERIC forces the generic loop)
+      // C_in known at compile time for the ResBlock widths: tap-major GEMM (conv_cl_set_tuning can force the generic loop)
       case 0: r = (cin == 256 && !generic) ? launch_cl_variant<8, 1, 1, 4, 16>(stream, L, nt, extra, cin)
                                            : launch_cl_variant<8, 1, 1, 4>(stream, L, nt, extra, cin); break;
       case 1: r = (cin == 128 && !generic) ? launch_cl_variant<4, 1, 1, 4, 8>(stream, L, nt, extra, cin)

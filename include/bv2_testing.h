@@ -84,6 +84,9 @@ int bv2_test_dds_layer(void* stream, const float* x, const float* pre_w_host, co
 
 /* tuning experiments (tools/kbench.py): force the split-K wave count / C_in chunk / tile-count target of the fp32 conv; 0 = default */
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target);
+/* bf16 / fp16 conv variants: cl_spec "<nt>:<id>[,...]" forces bf16 variant <id> for launches with <nt> 32-channel tiles ("" = the
+ * shipped choice), cl_generic / hc_generic = 1 force the generic GEMM loop instead of the C_in-specialised tap-major one */
+void bv2_test_set_variants(const char* cl_spec, int cl_generic, int hc_generic);
 
 /* tools/timeline.py: while dev_buf (capacity_u64 zeroed uint64 on the DEVICE) is set, every fp32 conv launch records 8 uint64 per
  * workgroup {s_memtime at start, after the prologue, after the main loop, at the end, HW_ID, XCC_ID, k or units, valid} into its own
