@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--option", action="append", default=[], metavar="KEY=0|1",
                     help="bv2_set_option switch for A/B runs (fused_attn_o, overlap_dp, fused_dds, fused_resblock)")
+    ap.add_argument("--variants", default=None, metavar="SPEC,CL,HC",
+                    help="bv2_test_set_variants(spec, cl_generic, hc_generic) before the run (tuning A/B only)")
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
     return ap.parse_args()
 
@@ -367,6 +369,14 @@ def main():
     log(f"rank {rank}/{world}: packing / distributing weights")
     t_bcast = sharding.distribute_weights(model, dev, src=0)
     log("weights attached")
+    if args.variants is not None:
+        import ctypes
+        spec, clg, hcg = args.variants.split(",")
+        lib = model._lib
+        lib.bv2_test_set_variants.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        lib.bv2_test_set_variants.restype = None
+        lib.bv2_test_set_variants(spec.encode(), int(clg), int(hcg))
+        log(f"variants {args.variants}")
     for kv in args.option:
         key, val = kv.split("=")
         model.set_option(key, int(val))

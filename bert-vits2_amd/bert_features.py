@@ -10,8 +10,9 @@ Python loop (:48-58), transposes, and ``infer.get_text`` uploads the ``[1024, T]
   utterance 1024*S*4 bytes cross HBM instead of 1024*T*4 (T ~ 2.5 S with blanks interspersed), and no repeat kernel runs;
 * ``style_text`` mixing (chinese_bert.py:38-47, 52-56) is applied at word level on the device — mixing and repeating commute.
 
-The BERT encoder itself is the HF model under PyTorch-ROCm (library kernels): it is OUTSIDE the hand-written hot path of this
-round; what this module fixes is the host round trip and the materialised repeat between it and the hot path.
+The BERT encoder itself: ``bert_encoder.BertEncoder`` runs the Chinese extractor (a HuggingFace ``BertModel``) with libbv2's own
+kernels and hands back ``[1024, S]`` directly (``get_bert_feature`` below takes it as ``model``); any HF model object works as
+well (PyTorch-ROCm library kernels) — the Japanese / English extractors are DeBERTa-v2 models and go that way.
 """
 from __future__ import annotations
 
@@ -41,6 +42,18 @@ def word_level_feature(hidden: torch.Tensor, word2ph: Sequence[int], style_hidde
     return res.t().contiguous(), word_to_symbol_index(word2ph, hidden.device)
 
 
+def word_level_feature_cs(feature_cs: torch.Tensor, word2ph: Sequence[int], style_cs: Optional[torch.Tensor] = None,
+                          style_weight: float = 0.7) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Same as ``word_level_feature`` for a hidden state that already is channels-first ``[1024, S]`` (``BertEncoder``'s output):
+    no transpose at all."""
+    if feature_cs.dim() != 2 or feature_cs.shape[1] != len(word2ph):
+        raise ValueError(f"feature must be [C, len(word2ph)={len(word2ph)}], got {tuple(feature_cs.shape)}")
+    res = feature_cs.float()
+    if style_cs is not None:
+        res = res * (1 - style_weight) + style_cs.float().mean(1, keepdim=True) * style_weight
+    return res.contiguous(), word_to_symbol_index(word2ph, feature_cs.device)
+
+
 def expand(feature: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     """What the reference's ``get_bert_feature`` returns: the symbol-level ``[1024, T]`` matrix (tests / callers that want it)."""
     return feature.index_select(1, index.long())
@@ -51,6 +64,10 @@ def get_bert_feature(text: str, word2ph: Sequence[int], tokenizer, model, device
                      style_weight: float = 0.7) -> Tuple[torch.Tensor, torch.Tensor]:
     """reference text/chinese_bert.py:15-60 (same arguments plus the tokenizer / model the reference keeps in module globals), on
     ``device``, returning the word-level pair instead of the repeated matrix."""
+    from .bert_encoder import BertEncoder
+    if isinstance(model, BertEncoder):                # libbv2's own BERT: [1024, S] on the device, nothing to transpose
+        run_cs = lambda t: model(**{k: v.to(device) for k, v in tokenizer(t, return_tensors="pt").items()})[0]
+        return word_level_feature_cs(run_cs(text), word2ph, run_cs(style_text) if style_text else None, style_weight)
     run = lambda t: model(**{k: v.to(device) for k, v in tokenizer(t, return_tensors="pt").items()},
                           output_hidden_states=True)["hidden_states"][-3][0]
     res = run(text)

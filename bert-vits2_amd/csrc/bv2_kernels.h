@@ -23,7 +23,7 @@ namespace bv2 {
 // (blockIdx.z) that share B and L: the three ResBlock branches of a Generator stage, the u polyphase branches of a
 // ConvTranspose1d, or the m_p / logs_p halves of enc_p.proj.
 enum { PRE_NONE = 0, PRE_LRELU = 1 };
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GATE = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GATE = 2, ACT_GELU = 3 };   // ACT_GELU: exact erf GELU (BERT intermediate, bv2_bert.cpp)
 // ACT_GATE (WN, reference commons.py:98-105): the GEMM rows come packed so that rows [0,16) of every 32-row tile are the tanh half and
 // rows [16,32) the sigmoid half of the same 16 channels (bv2_model.cpp wn_gate_row); the epilogue writes
 // out[16*mt + j] = tanh(v[j]) * sigmoid(v[j+16]) — `out` has cout/2 rows.  No residual / masks with it.
@@ -247,6 +247,24 @@ struct LnArgs {
   float* out2; const float* vec2; int vec2_bstride;
 };
 int launch_layernorm(hipStream_t stream, const LnArgs& a);
+
+// --------------------------------------------------------------------------------------------------------------
+// BERT feature extractor (kernels/bert.hip; include/bv2_bert.h)
+struct BertEmbedArgs {
+  const int64_t* input_ids; const int64_t* token_type_ids;     // [B][S]; token_type_ids may be null (all 0)
+  const float* word; const float* pos; const float* type;      // [vocab][C], [max_pos][C], [type_vocab][C]
+  const float* gamma; const float* beta; float eps;
+  float* out;                                                  // [B][C][S]
+  int B, S, C, vocab, max_pos, type_vocab;
+};
+int launch_bert_embed_ln(hipStream_t stream, const BertEmbedArgs& a);
+struct BertLnArgs {
+  const float* a; int nslab; int64_t slab_stride;              // sum of nslab slabs [B][C][T]
+  const float* gamma; const float* beta; float eps;
+  float* out;
+  int B, C, T;
+};
+int launch_bert_ln(hipStream_t stream, const BertLnArgs& a);
 
 // --------------------------------------------------------------------------------------------------------------
 // windowed relative-position multi-head attention (kernels/attention.hip), reference attentions.py:273-322

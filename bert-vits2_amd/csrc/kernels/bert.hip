@@ -1,0 +1,152 @@
+// bert.hip — the two kernels of the BERT feature extractor (bv2_bert.cpp, include/bv2_bert.h) that are not convolutions or
+// attention: the embedding sum + LayerNorm (transformers BertEmbeddings.forward: word + token-type + position embeddings,
+// LayerNorm(eps), dropout = identity at inference) and the residual LayerNorm behind every attention / feed-forward block
+// (BertSelfOutput / BertOutput: LayerNorm(dense(h) + input)).  Reference call site: text/chinese_bert.py:34-37.
+//
+// Activations are fp32 [B][C][S] (channels-first, S contiguous) like everything else in libbv2 — the layout the split-K GEMM
+// kernel reads as its B operand and the TextEncoder front consumes at word level, so the final hidden state needs no transpose.
+#include <hip/hip_runtime.h>
+#include "../bv2_kernels.h"
+
+namespace bv2 {
+
+// ---------------------------------------------------------------------------------------------------------------
+// One workgroup (256 threads) per token: x[c] = word[id][c] + pos[s][c] + type[tt][c]; two-pass LayerNorm over C; written to column s.
+// C <= 2048 (8 channels per thread).
+__global__ void __launch_bounds__(256) bert_embed_ln_kernel(const BertEmbedArgs A) {
+  __shared__ float red[2][4];
+  const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int C = A.C, S = A.S;
+  int64_t id = A.input_ids[(int64_t)b * S + s];
+  id = id < 0 ? 0 : (id >= A.vocab ? A.vocab - 1 : id);             // clamped like every gather in libbv2 (a bad id must not fault)
+  int64_t tt = A.token_type_ids ? A.token_type_ids[(int64_t)b * S + s] : 0;
+  tt = tt < 0 ? 0 : (tt >= A.type_vocab ? A.type_vocab - 1 : tt);
+  const int ps = s < A.max_pos ? s : A.max_pos - 1;
+  const float* wrow = A.word + id * C;
+  const float* prow = A.pos + (int64_t)ps * C;
+  const float* trow = A.type + tt * C;
+  float v[8], gm[8], bt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int c = tid + 256 * i;
+    c = c < C ? c : C - 1;
+    v[i] = (wrow[c] + trow[c]) + prow[c];            // BertEmbeddings: inputs_embeds + token_type_embeddings, then + position_embeddings
+    gm[i] = A.gamma[c];
+    bt[i] = A.beta[c];
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (tid + 256 * i < C) sum += v[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((tid & 63) == 0) red[0][tid >> 6] = sum;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (tid + 256 * i < C) { const float d = v[i] - mean; q += d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if ((tid & 63) == 0) red[1][tid >> 6] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)C + A.eps);
+  float* op = A.out + (int64_t)b * C * S + s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    if (c < C) op[(int64_t)c * S] = (v[i] - mean) * rstd * gm[i] + bt[i];
+  }
+}
+
+int launch_bert_embed_ln(hipStream_t stream, const BertEmbedArgs& a) {
+  if (a.C < 1 || a.C > 2048 || a.S < 1 || a.B < 1) return -1;
+  hipLaunchKernelGGL(bert_embed_ln_kernel, dim3(a.S, a.B), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// out = LayerNorm_C(sum of `nslab` partial slabs of a split-K GEMM) — slab 0 already carries the GEMM's bias and the residual
+// (conv_mfma.hip's split-K epilogue), so this is BertSelfOutput / BertOutput's LayerNorm(dense(h) + input).
+// A workgroup owns 8 consecutive tokens x all C channels: 1024 threads = (tx = token, ty = one of 128 channel groups), CPT = C/128
+// values per thread in registers, every load in flight at once.  Wave = 8 tokens x 8 channel groups, so each pass of the exact
+// two-pass variance is three __shfl_xor butterflies + one exchange between the 16 waves through LDS (layernorm.hip's scheme at
+// 4x the width).
+constexpr int BLN_TT = 8, BLN_G = 128;
+
+template <int CPT>
+__global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
+  __shared__ float red[2][16][BLN_TT];
+  const int tx = threadIdx.x & (BLN_TT - 1), ty = threadIdx.x >> 3;
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * BLN_TT + tx;
+  const int C = A.C, T = A.T;
+  const bool tok = t < T;
+  const int tcl = tok ? t : T - 1;
+  const int64_t base = (int64_t)b * C * T;
+  const float* ap = A.a + base;
+  const int nslab = A.nslab;
+  float v[CPT], gm[CPT], bt[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = ty + i * BLN_G;
+    const int off = c * T + tcl;
+    float x = ap[off];
+    for (int sl = 1; sl < nslab; ++sl) x += ap[(int64_t)sl * A.slab_stride + off];
+    v[i] = x;
+    gm[i] = A.gamma[c];
+    bt[i] = A.beta[c];
+  }
+  const int wv = threadIdx.x >> 6;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) s += v[i];
+  s += __shfl_xor(s, 8);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if ((threadIdx.x & 63) < BLN_TT) red[0][wv][tx] = s;
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) m += red[0][w][tx];
+  const float mean = m / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) { const float d = v[i] - mean; q += d * d; }
+  q += __shfl_xor(q, 8);
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  if ((threadIdx.x & 63) < BLN_TT) red[1][wv][tx] = q;
+  __syncthreads();
+  float qq = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) qq += red[1][w][tx];
+  const float rstd = 1.0f / sqrtf(qq / (float)C + A.eps);
+  if (!tok) return;
+  float* const outp = A.out + base;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = ty + i * BLN_G;
+    outp[c * T + t] = (v[i] - mean) * rstd * gm[i] + bt[i];
+  }
+}
+
+int launch_bert_ln(hipStream_t stream, const BertLnArgs& a) {
+  if (a.C < BLN_G || a.C % BLN_G || a.C > 8 * BLN_G || a.T < 1 || a.B < 1 || a.nslab < 1) return -1;
+  if ((int64_t)a.C * a.T >= (1ll << 31)) return -1;
+  dim3 grid((a.T + BLN_TT - 1) / BLN_TT, a.B);
+  switch (a.C / BLN_G) {
+    case 1: hipLaunchKernelGGL(bert_ln_kernel<1>, grid, dim3(1024), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(bert_ln_kernel<2>, grid, dim3(1024), 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(bert_ln_kernel<3>, grid, dim3(1024), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(bert_ln_kernel<4>, grid, dim3(1024), 0, stream, a); break;
+    case 5: hipLaunchKernelGGL(bert_ln_kernel<5>, grid, dim3(1024), 0, stream, a); break;
+    case 6: hipLaunchKernelGGL(bert_ln_kernel<6>, grid, dim3(1024), 0, stream, a); break;
+    case 7: hipLaunchKernelGGL(bert_ln_kernel<7>, grid, dim3(1024), 0, stream, a); break;
+    default: hipLaunchKernelGGL(bert_ln_kernel<8>, grid, dim3(1024), 0, stream, a); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace bv2

@@ -343,6 +343,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
           const int dr = (r & 3) + 8 * (r >> 2);
           float v = acc[mi][ni][r] + bs[r];
           if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
           if (mask_pre) v *= om;
           if (res_mode == RES_ADD) v += rv[r];
           else if (res_mode == RES_RSUB) v = rv[r] - v;
@@ -615,6 +616,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
         vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
       vv += bsv[i];
       if (act == ACT_RELU) vv = fmaxf(vv, 0.f);             // host guarantees act == NONE when ksplit > 1
+      else if (act == ACT_GELU) vv = 0.5f * vv * (1.0f + erff(vv * 0.70710678118654752440f));
       if (mask_pre) vv *= om;
       if (z == 0) {
         if (res_mode == RES_ADD) vv += rvv[i];

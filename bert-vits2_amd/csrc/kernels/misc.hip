@@ -227,7 +227,7 @@ int launch_gather_rows(hipStream_t stream, const float* table, const int64_t* id
 __global__ void seq_mask_kernel(const int64_t* lengths, float* mask, int T) {
   const int b = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < T) mask[(int64_t)b * T + t] = (int64_t)t < lengths[b] ? 1.f : 0.f;
+  if (t < T) mask[(int64_t)b * T + t] = (!lengths || (int64_t)t < lengths[b]) ? 1.f : 0.f;      // lengths == null: all valid
 }
 int launch_seq_mask(hipStream_t stream, const int64_t* lengths, float* mask, int B, int T) {
   hipLaunchKernelGGL(seq_mask_kernel, dim3((T + 255) / 256, B), dim3(256), 0, stream, lengths, mask, T);

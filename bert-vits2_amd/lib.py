@@ -38,6 +38,13 @@ class Config(C.Structure):
     ]
 
 
+class BertConfig(C.Structure):
+    """include/bv2_bert.h bv2_bert_config"""
+    _fields_ = [("struct_bytes", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_heads", C.c_int32),
+                ("intermediate_size", C.c_int32), ("max_position", C.c_int32), ("type_vocab_size", C.c_int32),
+                ("num_layers_run", C.c_int32), ("layer_norm_eps", C.c_float)]
+
+
 class EncodeIn(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T", C.c_int32),
@@ -108,6 +115,16 @@ SYMBOLS = [
     ("bv2_profile_enable", C.c_int, [_P, C.c_int]),
     ("bv2_profile_reset", C.c_int, [_P]),
     ("bv2_profile_report", C.c_int, [_P, C.POINTER(ProfileRow), C.c_int]),
+    # include/bv2_bert.h — BERT feature extractor (reference text/chinese_bert.py:15-37)
+    ("bv2_bert_create", C.c_int, [_P, C.POINTER(_P)]),
+    ("bv2_bert_destroy", None, [_P]),
+    ("bv2_bert_last_error", C.c_char_p, [_P]),
+    ("bv2_bert_packed_bytes", C.c_int64, [_P]),
+    ("bv2_bert_pack_tensor", C.c_int, [_P, _P, C.c_int64, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
+    ("bv2_bert_missing", C.c_int, [_P]),
+    ("bv2_bert_attach_weights", C.c_int, [_P, _P, C.c_int64]),
+    ("bv2_bert_workspace_bytes", C.c_int64, [_P, C.c_int, C.c_int]),
+    ("bv2_bert_forward", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
 ]
 
 _lib: Optional[C.CDLL] = None

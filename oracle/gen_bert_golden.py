@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — writes tests/golden/bert_*.npz with the REAL ``transformers.BertModel`` (run in the build container, where
+``transformers`` is installed; the GPU box never needs it).  For each case: seeded synthetic weights (oracle/bert_oracle.py) are
+loaded into ``BertModel(BertConfig(**cfg), add_pooling_layer=False)``, the model runs exactly as the reference calls it
+(text/chinese_bert.py:34-37: tokenizer output -> ``model(**inputs, output_hidden_states=True)`` -> ``hidden_states[-3]``) and the
+hidden state is stored together with the inputs and a checksum of the weights.
+
+    python oracle/gen_bert_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import bert_oracle as BO  # noqa: E402
+
+CASES = {  # name: (config, lengths, weight seed, token types)
+    "tiny_b1_s19": (BO.TINY, [19], 0, False),
+    "tiny_b3_ragged": (BO.TINY, [33, 7, 40], 1, True),
+    "mid_b2_s70": (BO.MID, [70, 52], 2, False),
+}
+
+
+def main():
+    from transformers import BertConfig, BertModel
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, (cfg, lengths, seed, use_tt) in CASES.items():
+        sd = BO.synthetic_state_dict(cfg, seed)
+        m = BertModel(BertConfig(**cfg), add_pooling_layer=False).eval()
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all("position_ids" in k or "token_type_ids" in k for k in missing), (missing, unexpected)
+        ids, ln = BO.synthetic_inputs(cfg, lengths, seed)
+        S = ids.shape[1]
+        am = (torch.arange(S)[None, :] < ln[:, None]).long()
+        tt = ((torch.arange(S)[None, :] >= (ln[:, None] // 2)) & (am > 0)).long() if use_tt else torch.zeros_like(ids)
+        with torch.no_grad():
+            res = m(input_ids=ids, token_type_ids=tt, attention_mask=am, output_hidden_states=True)
+        hs = res["hidden_states"]
+        assert len(hs) == cfg["num_hidden_layers"] + 1
+        h3 = hs[-3]
+        digest = hashlib.sha256(b"".join(sd[k].numpy().tobytes() for k in sorted(sd))).hexdigest()
+        np.savez_compressed(os.path.join(out_dir, f"bert_{name}.npz"), input_ids=ids.numpy(), token_type_ids=tt.numpy(),
+                            lengths=ln.numpy(), hidden_m3=h3.numpy().astype(np.float32), hidden_0=hs[0].numpy().astype(np.float32),
+                            weights_sha256=np.array(digest), seed=np.array(seed), cfg_hidden=np.array(cfg["hidden_size"]))
+        print(name, tuple(h3.shape), float(h3.abs().mean()), digest[:12])
+
+
+if __name__ == "__main__":
+    main()

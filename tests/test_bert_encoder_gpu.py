@@ -1,0 +1,72 @@
+"""GPU: the device BERT feature extractor (bv2_bert_forward through bert_encoder.BertEncoder) against
+ (a) the committed goldens of the REAL transformers.BertModel (tests/golden/bert_*.npz, oracle/gen_bert_golden.py), and
+ (b) the oracle restatement (oracle/bert_oracle.py, fp64) on seeded inputs — including one run at the full size of the reference's
+     chinese-roberta-wwm-ext-large (24 layers x 1024, hidden_states[-3]) and a padded batch.
+Bar: fp32 round-off — max-abs error <= 2e-4 on O(1) LayerNorm outputs (summation order differs: split-K slabs, flash softmax)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bert_oracle as BO
+from oracle.gen_bert_golden import CASES
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _encoder(cfg, sd):
+    from bert_vits2_amd.bert_encoder import BertEncoder
+    return BertEncoder(**cfg).load_state_dict(sd, device="cuda")
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_bert_matches_the_real_bertmodel_golden(name):
+    cfg, lengths, seed, use_tt = CASES[name]
+    g = np.load(os.path.join(GOLD, f"bert_{name}.npz"))
+    enc = _encoder(cfg, {"bert." + k: v for k, v in BO.synthetic_state_dict(cfg, seed).items()})   # BertForMaskedLM-style keys
+    ids, tt, ln = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["token_type_ids"]), torch.from_numpy(g["lengths"])
+    am = (torch.arange(ids.shape[1])[None, :] < ln[:, None]).long()
+    out = enc(ids.cuda(), token_type_ids=tt.cuda(), attention_mask=am.cuda())
+    torch.cuda.synchronize()
+    assert out.shape == (ids.shape[0], cfg["hidden_size"], ids.shape[1])
+    got = out.cpu().transpose(1, 2)                                # [B, S, C] like hidden_states
+    ref = torch.from_numpy(g["hidden_m3"])
+    valid = am.bool()[..., None]
+    err = ((got - ref).abs() * valid).max().item()
+    assert torch.isfinite(got).all() and err < 2e-4, err
+
+
+def test_full_size_chinese_roberta_large_shape_vs_oracle():
+    cfg = BO.LARGE
+    sd = BO.synthetic_state_dict(cfg, 3, layers=22)              # only the 22 layers hidden_states[-3] needs
+    enc = _encoder(cfg, sd)
+    assert enc.layers_run == 22
+    ids, ln = BO.synthetic_inputs(cfg, [52], 5)                  # a 50-character sentence + [CLS] / [SEP]
+    out = enc(ids.cuda())
+    torch.cuda.synchronize()
+    ref = BO.hidden_state(sd, cfg, ids, 22, dtype=torch.float64).float()
+    err = (out.cpu().transpose(1, 2) - ref).abs().max().item()
+    print(f"BERT-large S=52: max-abs error vs fp64 oracle {err:.2e} (output scale {ref.abs().max().item():.2f})")
+    assert err < 5e-4, err
+    # padded batch of three sentences = the three sentences run alone (valid positions)
+    ids3, ln3 = BO.synthetic_inputs(cfg, [52, 17, 33], 6)
+    out3 = enc(ids3.cuda(), lengths=ln3.cuda()).cpu()
+    for b, n in enumerate(ln3.tolist()):
+        alone = enc(ids3[b:b + 1, :n].cuda()).cpu()
+        assert (out3[b, :, :n] - alone[0]).abs().max().item() < 2e-4, b
+
+
+def test_word_level_feature_path_feeds_the_text_encoder_unchanged():
+    """BertEncoder output [1024, S] + word2ph index == the reference's repeated [1024, T] matrix (chinese_bert.py:48-60)."""
+    from bert_vits2_amd import bert_features as BF
+    cfg = BO.MID
+    sd = BO.synthetic_state_dict(cfg, 2)
+    enc = _encoder(cfg, sd)
+    ids, _ = BO.synthetic_inputs(cfg, [12], 9)
+    word2ph = [1, 2, 2, 3, 1, 2, 2, 2, 4, 2, 2, 1]
+    feat, index = BF.word_level_feature_cs(enc(ids.cuda())[0], word2ph)
+    ref = BO.hidden_state(sd, cfg, ids, cfg["num_hidden_layers"] - 2)[0]             # [S, C]
+    rep = torch.cat([ref[i].repeat(word2ph[i], 1) for i in range(len(word2ph))], 0).T   # the reference's loop
+    assert (BF.expand(feat, index).cpu() - rep).abs().max().item() < 2e-4
