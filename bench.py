@@ -302,6 +302,61 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     return res
 
 
+def bench_bert(dev, with_cpu):
+    """SURVEY 8f-2 leg (secondary, N=1 only): hidden_states[-3] of a chinese-roberta-wwm-ext-large-shaped BertModel for ONE sentence
+    of config 2's size (128 symbols with blanks interspersed = ~51 characters + [CLS]/[SEP] = 53 tokens) through bv2_bert_forward,
+    seeded synthetic weights.  HBM-side roofline: every forward streams the 22 layers' fp32 weights once (algorithmic bytes)."""
+    from bert_vits2_amd.bert_encoder import BertEncoder
+    from oracle import bert_oracle as BO
+    cfg, S, layers = BO.LARGE, 53, 22
+    sd = BO.synthetic_state_dict(cfg, 0, layers=layers)
+    enc = BertEncoder(**cfg).load_state_dict(sd, device=dev)
+    ids, _ = BO.synthetic_inputs(cfg, [S], 0)
+    ids = ids.to(dev)
+    for _ in range(3):
+        enc(ids)
+    torch.cuda.synchronize()
+    n = 30
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = enc(ids)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    C, I = cfg["hidden_size"], cfg["intermediate_size"]
+    wbytes = 4.0 * layers * (4 * C * C + 2 * C * I + 9 * C + I)                     # weights + biases + LayerNorm vectors, once
+    abytes = 4.0 * S * (layers * (3 * C + 2 * C + 2 * C + I + I + 2 * C) + 4 * C)   # activations written + read once per GEMM / LN
+    flops = 2.0 * S * layers * (4 * C * C + 2 * C * I) + 4.0 * layers * S * S * C
+    res = dict(workload=f"BertModel 24x1024 (chinese-roberta-wwm-ext-large shape), hidden_states[-3] = {layers} layers, B=1 x S={S} tokens, "
+                        f"fp32, seeded synthetic weights; reference call site text/chinese_bert.py:34-37",
+               ms_per_sentence=round(ms, 4), sentences_per_sec=round(1e3 / ms, 2), dtype="f32", launches=1 + 1 + 7 * layers,
+               roofline=dict(bound="hbm", achieved=round((wbytes + abytes) / (ms * 1e-3) / 1e9, 1), peak=8000.0, unit="GB/s",
+                             frac=round((wbytes + abytes) / (ms * 1e-3) / 8e12, 4), alg_bytes_per_forward=int(wbytes + abytes),
+                             tflops=round(flops / (ms * 1e-3) / 1e12, 2), traffic=None,
+                             note="latency-bound at batch 1: 156 dependent launches of ~10 us; the weights (1.1 GB fp32) are the algorithmic bytes"))
+    # the same model over a padded batch of 8 sentences (a request split into sentences, infer.py:268-332): the weights are
+    # streamed once per batch instead of once per sentence
+    ids8, ln8 = BO.synthetic_inputs(cfg, [53, 41, 37, 53, 29, 48, 33, 53], 1)
+    ids8, ln8 = ids8.to(dev), ln8.to(dev)
+    for _ in range(2):
+        enc(ids8, lengths=ln8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        enc(ids8, lengths=ln8)
+    torch.cuda.synchronize()
+    ms8 = (time.perf_counter() - t0) / 10 * 1e3
+    res["batch8"] = dict(ms_per_batch=round(ms8, 4), sentences_per_sec=round(8e3 / ms8, 1), tokens=int(ln8.sum().item()),
+                         tflops=round(flops / S * 8 * 53 / (ms8 * 1e-3) / 1e12, 2))
+    if with_cpu:
+        t1 = time.perf_counter()
+        ref = BO.hidden_state(sd, cfg, ids.cpu(), layers)
+        cpu_ms = (time.perf_counter() - t1) * 1e3
+        res["cpu_baseline"] = dict(value=round(1e3 / cpu_ms, 3), unit="sentences/sec", ms_per_sentence=round(cpu_ms, 1), cores=torch.get_num_threads(),
+                                   kind="port", sample="1 run of the same sentence, torch CPU fp32, oracle restatement of BertModel")
+        res["max_abs_err_vs_oracle"] = float((out.cpu().transpose(1, 2) - ref).abs().max())
+    return res
+
+
 def describe(res, hp, world):
     gd, fd = res["gen_dtype"], res["flow_dtype"]
     ragged = CONFIGS[res["config"]]["ragged"]
@@ -403,6 +458,12 @@ def main():
                 log(f"secondary config {num}: {secondary[f'config{num}']['value']} audio-s/s ({secondary[f'config{num}']['ms_per_step']} ms/step)")
             except Exception as e:          # a secondary workload must never take the primary line down
                 secondary[f"config{num}"] = dict(error=repr(e)[:300])
+
+        try:
+            secondary["bert_zh_features"] = bench_bert(dev, not args.no_cpu_baseline)
+            log(f"secondary BERT feature extraction: {secondary['bert_zh_features']['ms_per_sentence']} ms per sentence")
+        except Exception as e:
+            secondary["bert_zh_features"] = dict(error=repr(e)[:300])
 
     if rank == 0:
         cpu = None

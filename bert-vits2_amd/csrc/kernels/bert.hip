@@ -75,7 +75,7 @@ int launch_bert_embed_ln(hipStream_t stream, const BertEmbedArgs& a) {
 // 4x the width).
 constexpr int BLN_TT = 8, BLN_G = 128;
 
-template <int CPT>
+template <int CPT, int NSLAB>   // NSLAB > 0: compile-time slab count (every load of a thread in flight at once); 0: runtime loop
 __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   __shared__ float red[2][16][BLN_TT];
   const int tx = threadIdx.x & (BLN_TT - 1), ty = threadIdx.x >> 3;
@@ -93,7 +93,17 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
     const int c = ty + i * BLN_G;
     const int off = c * T + tcl;
     float x = ap[off];
-    for (int sl = 1; sl < nslab; ++sl) x += ap[(int64_t)sl * A.slab_stride + off];
+    if constexpr (NSLAB > 0) {
+      // a runtime trip count made the compiler issue the slabs one dependent round trip after the other: 13 us instead of 6
+      // (rocprofv3, profiles/r02_c_kernel_stats_bert.txt) for 1.7 MB of input
+      float part[NSLAB > 1 ? NSLAB - 1 : 1];
+#pragma unroll
+      for (int sl = 1; sl < NSLAB; ++sl) part[sl - 1] = ap[(int64_t)sl * A.slab_stride + off];
+#pragma unroll
+      for (int sl = 1; sl < NSLAB; ++sl) x += part[sl - 1];
+    } else {
+      for (int sl = 1; sl < nslab; ++sl) x += ap[(int64_t)sl * A.slab_stride + off];
+    }
     v[i] = x;
     gm[i] = A.gamma[c];
     bt[i] = A.beta[c];
@@ -136,16 +146,28 @@ int launch_bert_ln(hipStream_t stream, const BertLnArgs& a) {
   if (a.C < BLN_G || a.C % BLN_G || a.C > 8 * BLN_G || a.T < 1 || a.B < 1 || a.nslab < 1) return -1;
   if ((int64_t)a.C * a.T >= (1ll << 31)) return -1;
   dim3 grid((a.T + BLN_TT - 1) / BLN_TT, a.B);
-  switch (a.C / BLN_G) {
-    case 1: hipLaunchKernelGGL(bert_ln_kernel<1>, grid, dim3(1024), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(bert_ln_kernel<2>, grid, dim3(1024), 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(bert_ln_kernel<3>, grid, dim3(1024), 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(bert_ln_kernel<4>, grid, dim3(1024), 0, stream, a); break;
-    case 5: hipLaunchKernelGGL(bert_ln_kernel<5>, grid, dim3(1024), 0, stream, a); break;
-    case 6: hipLaunchKernelGGL(bert_ln_kernel<6>, grid, dim3(1024), 0, stream, a); break;
-    case 7: hipLaunchKernelGGL(bert_ln_kernel<7>, grid, dim3(1024), 0, stream, a); break;
-    default: hipLaunchKernelGGL(bert_ln_kernel<8>, grid, dim3(1024), 0, stream, a); break;
+  const int cpt = a.C / BLN_G;
+#define BLN_LAUNCH(CPT_, NS_) hipLaunchKernelGGL((bert_ln_kernel<CPT_, NS_>), grid, dim3(1024), 0, stream, a)
+#define BLN_CPT(CPT_)                                                                                  \
+  switch (a.nslab) {                                                                                   \
+    case 1: BLN_LAUNCH(CPT_, 1); break;                                                                \
+    case 2: BLN_LAUNCH(CPT_, 2); break;                                                                \
+    case 4: BLN_LAUNCH(CPT_, 4); break;                                                                \
+    case 8: BLN_LAUNCH(CPT_, 8); break;                                                                \
+    default: BLN_LAUNCH(CPT_, 0); break;                                                               \
   }
+  switch (cpt) {
+    case 1: BLN_CPT(1); break;
+    case 2: BLN_CPT(2); break;
+    case 3: BLN_CPT(3); break;
+    case 4: BLN_CPT(4); break;
+    case 5: BLN_CPT(5); break;
+    case 6: BLN_CPT(6); break;
+    case 7: BLN_CPT(7); break;
+    default: BLN_CPT(8); break;
+  }
+#undef BLN_CPT
+#undef BLN_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
