@@ -147,7 +147,7 @@ def file_digest(name):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, config=2):
     """HBM bytes per launch of `kernel` from the PMC passes of tools/collect_traffic.py (rocprofv3 cannot wrap the timed run itself
     without perturbing it, so the counters come from separate passes of this same command, committed under profiles/): FETCH_SIZE
     x2 (gfx950 correction) + WRITE_SIZE.  Only a profile taken with the CURRENT source of that kernel counts: the traffic file
@@ -160,6 +160,13 @@ def pmc_traffic(kernel):
             d = json.load(open(path))
             k = d["kernels"].get(kernel)
             if not k:
+                continue
+            # a family's launches differ between configs (conv1d_mfma<64x64> is the Generator at config 2 and the text encoder's
+            # FFN at config 3): only a profile of THIS config's command counts (configs 4 / 5 fall back to config 3's: same kernels,
+            # same per-launch shapes up to the batch's padding)
+            ba = d.get("_bench_args") or []
+            fcfg = int(ba[ba.index("--config") + 1]) if "--config" in ba else 2
+            if fcfg != (2 if config == 2 else 3):
                 continue
             have = (d.get("source_digests") or {}).get(src)
             if want is None or have != want:
@@ -184,7 +191,7 @@ def make_batch(cfg, B, T, rank):
     return synth.synthetic_batch(lengths, langs, sids, first_index=rank * B), lengths
 
 
-def roofline_block(prof, psteps):
+def roofline_block(prof, psteps, config=2):
     dom = max(prof, key=lambda r: r["total_ms"])
     gen_ms = sum(r["total_ms"] for r in prof) / psteps
     # the roof that binds the dominant kernel: its layer-wise arithmetic intensity against the machine balance
@@ -195,7 +202,7 @@ def roofline_block(prof, psteps):
         ach, peak, unit, bound = dom["flops"] / secs / 1e12, peak_tf, "TFLOP/s", "mfma"
     else:
         ach, peak, unit, bound = dom["bytes"] / secs / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
-    tr = pmc_traffic(dom["name"])
+    tr = pmc_traffic(dom["name"], config)
     return dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 4),
                 arithmetic_intensity_flop_per_byte=round(ai, 1), traffic=tr.get("bytes_per_launch"), traffic_detail=tr,
                 alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]), launches_per_step=dom["launches"] / psteps,
@@ -286,7 +293,7 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     torch.cuda.synchronize()
     prof = model.profile_report()
     model.profile(0)
-    res["roofline"] = roofline_block(prof, psteps) if prof else None
+    res["roofline"] = roofline_block(prof, psteps, num) if prof else None
     if full_profile:
         model.profile(3)               # one row per launch site and shape
         for _ in range(3):

@@ -58,6 +58,11 @@ def one_pass(counters, extra_args):
 def main():
     out = sys.argv[1]
     extra = sys.argv[2:]
+    traffic_out = None
+    if "--traffic" in extra:                      # also write the file bench.py's roofline.traffic reads (tools/collect_traffic.py's format)
+        i = extra.index("--traffic")
+        traffic_out = extra[i + 1]
+        extra = extra[:i] + extra[i + 2:]
     t1, n1, d1 = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], extra)
     t2, n2, d2 = one_pass(["FETCH_SIZE"], extra)
     t3, n3, d3 = one_pass(["WRITE_SIZE"], extra)
@@ -82,6 +87,19 @@ def main():
                     row["effective_clock_GHz"] = round(gui / 8.0 / max(n1[f], 1) / secs / 1e9, 2)
         res["kernels"][f] = row
     json.dump(res, open(out, "w"), indent=1)
+    if traffic_out:
+        import hashlib
+        kdir = os.path.join(ROOT, "bert-vits2_amd", "csrc", "kernels")
+        digests = {f: hashlib.sha256(open(os.path.join(kdir, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(kdir)) if f.endswith(".hip")}
+        tr = {"_method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, the FETCH / WRITE passes of tools/collect_pmc.py) "
+                         "around `bench.py --steps 3 --warmup 1`; KB -> bytes; FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md); "
+                         "WRITE_SIZE uncalibrated",
+              "_bench_args": extra, "source_digests": digests, "kernels": {}}
+        for f, row in res["kernels"].items():
+            if "fetch_bytes_per_launch" in row:
+                tr["kernels"][f] = dict(launches=n2.get(f, 0), fetch_bytes_raw=row["fetch_bytes_per_launch"] / 2, fetch_bytes=row["fetch_bytes_per_launch"],
+                                        write_bytes=row["write_bytes_per_launch"], traffic_bytes=row["fetch_bytes_per_launch"] + row["write_bytes_per_launch"])
+        json.dump(tr, open(traffic_out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
