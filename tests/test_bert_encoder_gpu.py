@@ -70,3 +70,24 @@ def test_word_level_feature_path_feeds_the_text_encoder_unchanged():
     ref = BO.hidden_state(sd, cfg, ids, cfg["num_hidden_layers"] - 2)[0]             # [S, C]
     rep = torch.cat([ref[i].repeat(word2ph[i], 1) for i in range(len(word2ph))], 0).T   # the reference's loop
     assert (BF.expand(feat, index).cpu() - rep).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("lengths", [[1], [2, 1], [129], [300, 257], [80]])
+def test_sequence_length_edges_vs_oracle(lengths):
+    """S = 1 (a single [CLS]), one key tile + 1, > 8 key tiles (the attention kernel's looped form), S = max_position."""
+    cfg = BO.MID
+    cfg2 = dict(cfg, max_position_embeddings=max(cfg["max_position_embeddings"], max(lengths)))
+    sd2 = BO.synthetic_state_dict(cfg2, 4)
+    enc = _encoder(cfg2, sd2)
+    ids, ln = BO.synthetic_inputs(cfg2, lengths, 11)
+    out = enc(ids.cuda(), lengths=ln.cuda()).cpu().transpose(1, 2)
+    ref = BO.hidden_state(sd2, cfg2, ids, cfg2["num_hidden_layers"] - 2, lengths=ln, dtype=torch.float64).float()
+    valid = (torch.arange(ids.shape[1])[None, :] < ln[:, None])[..., None]
+    assert torch.isfinite(out).all()
+    assert ((out - ref).abs() * valid).max().item() < 2e-4
+
+
+def test_rejects_sequences_longer_than_the_position_table():
+    enc = _encoder(BO.TINY, BO.synthetic_state_dict(BO.TINY, 0))
+    with pytest.raises(RuntimeError, match="max_position"):
+        enc(torch.zeros(1, BO.TINY["max_position_embeddings"] + 1, dtype=torch.int64).cuda())
