@@ -15,7 +15,7 @@ memory); there is no CPU / PyTorch fallback.  DeBERTa-v2 checkpoints (the refere
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Mapping, Optional
+from typing import Mapping, Optional
 
 import torch
 
@@ -49,7 +49,7 @@ class BertEncoder:
         if self._lib.bv2_bert_create(C.byref(cfg), C.byref(self._h)) != 0:
             raise RuntimeError(self._lib.bv2_bert_last_error(None).decode())
         self._blob: Optional[torch.Tensor] = None
-        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None         # one workspace, grown to the largest (B, S) seen
         self.device = torch.device("cpu")
 
     def __del__(self):
@@ -106,10 +106,10 @@ class BertEncoder:
                 raise ValueError("attention_mask must be a prefix mask (right padding)")
         ln = None if lengths is None else lengths.to(dev, torch.int64).contiguous()
         out = torch.empty(B, self.hidden_size, S, dtype=torch.float32, device=dev)
-        key = (B, S)
-        if key not in self._ws:
-            self._ws[key] = torch.empty(int(self._lib.bv2_bert_workspace_bytes(self._h, B, S)), dtype=torch.uint8, device=dev)
-        ws = self._ws[key]
+        need = int(self._lib.bv2_bert_workspace_bytes(self._h, B, S))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = self._ws
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             rc = self._lib.bv2_bert_forward(self._h, stream, B, S, _ptr(ids), _ptr(tt), _ptr(ln), _ptr(out), _ptr(ws), ws.numel())
