@@ -73,6 +73,7 @@ def parse():
                     help="bv2_set_option switch for A/B runs (fused_attn_o, overlap_dp, fused_dds, fused_resblock)")
     ap.add_argument("--variants", default=None, metavar="SPEC,CL,HC",
                     help="bv2_test_set_variants(spec, cl_generic, hc_generic) before the run (tuning A/B only)")
+    ap.add_argument("--streams", type=int, default=2, help="requests in flight for the secondary two-stream leg of config 2")
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
     return ap.parse_args()
 
@@ -309,6 +310,45 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     return res
 
 
+def run_two_streams(model, hp, dev, steps, nstreams=2):
+    """Config 2's utterance with TWO requests in flight: two shim instances share the packed weight blob, each owns a HIP stream and
+    its workspace, and the host alternates between them — while one request's phase A / flow (a chain of small kernels that leaves
+    most CUs idle) runs, the other request's Generator fills the machine.  Every launch is still batch 1; a step is still one full
+    infer().  Reported beside the sequential figure (which stays `value`: it is also the per-request latency), never instead of it."""
+    ms = [model]
+    for _ in range(nstreams - 1):
+        m2 = models.from_hparams(hp)
+        m2.attach_blob(model._blob)
+        ms.append(m2)
+    for m in ms:
+        m.enable_graphs(False)
+        m.set_generator_dtype(torch.float32)
+        m.set_flow_dtype(torch.float32)
+    streams = [torch.cuda.Stream(dev) for _ in ms]
+    batch, lengths = make_batch(CONFIGS[2], 1, 128, 0)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    torch.cuda.synchronize()
+
+    def step(i):
+        with torch.cuda.stream(streams[i % nstreams]):
+            return ms[i % nstreams].infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"], **KW)
+
+    for i in range(3 * nstreams):
+        out = step(i)
+    torch.cuda.synchronize()
+    frames = int(out[2].sum().item())
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    audio = frames * hp.total_upsample / hp.sampling_rate
+    return dict(workload="BASELINE config 2's utterance (B=1 x T=128, fp32), two requests in flight on two HIP streams "
+                         f"({nstreams} handles, one weight blob); every launch is batch 1", requests_in_flight=nstreams,
+                value=round(audio * steps / dt, 2), unit="audio-seconds/sec", ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
+                note="throughput of a 2-deep request pipeline; per-request latency is the sequential figure's ms_per_step or more")
+
+
 def bench_bert(dev, with_cpu):
     """SURVEY 8f-2 leg (secondary, N=1 only): hidden_states[-3] of a chinese-roberta-wwm-ext-large-shaped BertModel for ONE sentence
     of config 2's size (128 symbols with blanks interspersed = ~51 characters + [CLS]/[SEP] = 53 tokens) through bv2_bert_forward,
@@ -466,6 +506,13 @@ def main():
             except Exception as e:          # a secondary workload must never take the primary line down
                 secondary[f"config{num}"] = dict(error=repr(e)[:300])
 
+        for ns in sorted({args.streams, 4}):
+            key = f"config2_{ns}_requests_in_flight"
+            try:
+                secondary[key] = run_two_streams(model, hp, dev, max(20, args.steps), ns)
+                log(f"secondary config 2, {ns} requests in flight: {secondary[key]['value']} audio-s/s")
+            except Exception as e:
+                secondary[key] = dict(error=repr(e)[:300])
         try:
             secondary["bert_zh_features"] = bench_bert(dev, not args.no_cpu_baseline)
             log(f"secondary BERT feature extraction: {secondary['bert_zh_features']['ms_per_sentence']} ms per sentence")
