@@ -10,6 +10,7 @@ single device->host copy.  Multi-GPU: ``sharding.shard_indices`` picks this rank
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -93,49 +94,88 @@ def pcm16(model, wave: torch.Tensor, y_lengths: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def replicas(model, n: int) -> list:
+    """``n`` shim instances that share ``model``'s packed weight blob (one copy in HBM), each with its own C handle, workspace and
+    HIP stream: the unit of request-level concurrency.  A request's phase A and flow are chains of small kernels that leave most CUs
+    idle; with a second request in flight on another stream its Generator fills them (batch-1 requests: 938 -> 1 265 audio-s/s with
+    two in flight, 1 510 with four on MI355X, ``bench.py``'s ``config2_*_requests_in_flight``).  Cached on the model."""
+    from . import models as _models
+    if model.device.type != "cuda":
+        raise RuntimeError("bert_vits2_amd.serving needs the model on a GPU: there is no CPU fallback")
+    if model._blob is None:
+        model.repack()
+    reps = getattr(model, "_serving_replicas", None)
+    if reps is None:
+        reps = [(model, torch.cuda.Stream(model.device))]
+    while len(reps) < n:
+        m = _models.from_hparams(model.hp)
+        m.attach_blob(model._blob)
+        reps.append((m, torch.cuda.Stream(model.device)))
+    for m, _ in reps[1:]:                                # replicas follow the weights and precision switches of the model they serve
+        if m._blob is not model._blob:
+            m.attach_blob(model._blob)
+        m.set_generator_dtype(model.generator_dtype)
+        if model.hp.use_transformer_flow:
+            m.set_flow_dtype(model.flow_dtype)
+    model._serving_replicas = reps
+    return reps[:n]
+
+
 @torch.no_grad()
 def synthesize(model, utts: Sequence[Utterance], *, sdp_ratio=0.5, noise_scale=0.6, noise_scale_w=0.9, length_scale=1.0,
                max_batch: int = 32, max_pad_ratio: float = 1.25, as_pcm16: bool = False,
-               noise: Optional[Sequence] = None) -> List[np.ndarray]:
+               noise: Optional[Sequence] = None, requests_in_flight: int = 1) -> List[np.ndarray]:
     """Synthesise every utterance; returns one 1-D array per utterance in input order (float32 like reference
     infer.py:315-319, or int16 with ``as_pcm16``).  Defaults are the reference web UI's (webui.py:443-454).
-    ``noise`` (tests): per utterance a pair ``(noise_w [2,T], noise_z [inter, >= T_y])`` to inject instead of drawing."""
+    ``noise`` (tests): per utterance a pair ``(noise_w [2,T], noise_z [inter, >= T_y])`` to inject instead of drawing.
+    ``requests_in_flight`` > 1: the buckets are dealt round-robin to that many ``replicas`` (own handle + HIP stream, shared
+    weights), so one bucket's small-kernel phases overlap another's Generator; results do not depend on it."""
     if model.device.type != "cuda":
         raise RuntimeError("bert_vits2_amd.serving needs the model on a GPU: there is no CPU fallback")
     dev = model.device
     hop = model.hp.total_upsample
     results: List[Optional[np.ndarray]] = [None] * len(utts)
     pending = []
-    for idx in plan_batches([u.length for u in utts], max_batch, max_pad_ratio):
-        group = [utts[i] for i in idx]
-        batch = collate(group, dev)
-        kw = {}
-        if noise is not None:
-            T = batch["x"].shape[1]
-            Tz = max(int(noise[i][1].shape[1]) for i in idx)
-            nw = torch.zeros(len(idx), 2, T)
-            nz = torch.zeros(len(idx), model.hp.inter_channels, Tz)
-            for r, i in enumerate(idx):
-                nw[r, :, :noise[i][0].shape[1]] = noise[i][0]
-                nz[r, :, :noise[i][1].shape[1]] = noise[i][1]
-            kw = dict(noise_w=nw.to(dev), noise_z=nz.to(dev))
-        o, _attn, y_mask, _ = model.infer(batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"],
-                                          batch["bert"], batch["ja_bert"], batch["en_bert"], sdp_ratio=sdp_ratio,
-                                          noise_scale=noise_scale, noise_scale_w=noise_scale_w, length_scale=length_scale,
-                                          want_attn=False, exact_lengths=True, **kw)
-        y_len = model.last_encode["y_lengths"]             # int64 [B], already on the device (phase A output)
-        audio = pcm16(model, o, y_len) if as_pcm16 else o[:, 0]
-        # one async D2H per bucket into pinned memory (audio AND lengths): nothing here blocks the host, so the next bucket's
-        # kernels are enqueued while this copy runs; the drain loop below waits on the bucket's event
-        host = torch.empty(audio.shape, dtype=audio.dtype, pin_memory=True)
-        host.copy_(audio, non_blocking=True)
-        host_len = torch.empty(y_len.shape, dtype=torch.int64, pin_memory=True)
-        host_len.copy_(y_len, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        pending.append((idx, host, host_len, ev))
+    lanes = replicas(model, requests_in_flight) if requests_in_flight > 1 else [(model, None)]
+    if requests_in_flight > 1:
+        torch.cuda.current_stream(dev).synchronize()       # inputs prepared on the caller's stream are visible to the lanes
+    for bi, idx in enumerate(plan_batches([u.length for u in utts], max_batch, max_pad_ratio)):
+        lane, lane_stream = lanes[bi % len(lanes)]
+        with torch.cuda.stream(lane_stream) if lane_stream is not None else contextlib.nullcontext():
+            _run_bucket(lane, utts, idx, dev, noise, pending, as_pcm16, sdp_ratio, noise_scale, noise_scale_w, length_scale)
     for idx, host, y_len, ev in pending:
         ev.synchronize()
         for r, i in enumerate(idx):
             results[i] = host[r, :int(y_len[r]) * hop].numpy().copy()
     return results
+
+
+def _run_bucket(model, utts, idx, dev, noise, pending, as_pcm16, sdp_ratio, noise_scale, noise_scale_w, length_scale):
+    """One bucket on the CURRENT stream: collate, infer (exact lengths), optional PCM16, async D2H into pinned memory."""
+    group = [utts[i] for i in idx]
+    batch = collate(group, dev)
+    kw = {}
+    if noise is not None:
+        T = batch["x"].shape[1]
+        Tz = max(int(noise[i][1].shape[1]) for i in idx)
+        nw = torch.zeros(len(idx), 2, T)
+        nz = torch.zeros(len(idx), model.hp.inter_channels, Tz)
+        for r, i in enumerate(idx):
+            nw[r, :, :noise[i][0].shape[1]] = noise[i][0]
+            nz[r, :, :noise[i][1].shape[1]] = noise[i][1]
+        kw = dict(noise_w=nw.to(dev), noise_z=nz.to(dev))
+    o, _attn, y_mask, _ = model.infer(batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"],
+                                      batch["bert"], batch["ja_bert"], batch["en_bert"], sdp_ratio=sdp_ratio,
+                                      noise_scale=noise_scale, noise_scale_w=noise_scale_w, length_scale=length_scale,
+                                      want_attn=False, exact_lengths=True, **kw)
+    y_len = model.last_encode["y_lengths"]             # int64 [B], already on the device (phase A output)
+    audio = pcm16(model, o, y_len) if as_pcm16 else o[:, 0]
+    # one async D2H per bucket into pinned memory (audio AND lengths): nothing here blocks the host, so the next bucket's
+    # kernels are enqueued while this copy runs; the drain loop below waits on the bucket's event
+    host = torch.empty(audio.shape, dtype=audio.dtype, pin_memory=True)
+    host.copy_(audio, non_blocking=True)
+    host_len = torch.empty(y_len.shape, dtype=torch.int64, pin_memory=True)
+    host_len.copy_(y_len, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    pending.append((idx, host, host_len, ev))

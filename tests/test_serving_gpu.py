@@ -79,3 +79,28 @@ def test_pcm16_matches_host_conversion():
         assert not pcm[b, n:].any()
     out = serving.synthesize(m, _utts([12, 14]), as_pcm16=True)
     assert all(o.dtype == np.int16 and np.abs(o).max() >= 32766 for o in out)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16+f16"])
+def test_requests_in_flight_do_not_change_the_audio(mode):
+    """Buckets dealt to several replicas (own handle + HIP stream, one weight blob) give bit-identical audio: same kernels, same
+    shapes, only the stream differs."""
+    hp = H.default_v23()
+    m = _model(hp)
+    if mode != "fp32":
+        m.set_generator_dtype(torch.bfloat16)
+        m.set_flow_dtype(torch.float16)
+    lengths = [17, 24, 9, 22, 40, 20, 33, 12]
+    utts = _utts(lengths)
+    g = torch.Generator().manual_seed(6)
+    noise = [(torch.randn(2, T, generator=g), torch.randn(hp.inter_channels, 16 * T, generator=g)) for T in lengths]
+    kw = dict(sdp_ratio=0.5, noise_scale=0.6, noise_scale_w=0.9, length_scale=1.0, max_batch=2, max_pad_ratio=1.5)
+    one = serving.synthesize(m, utts, noise=noise, **kw)
+    for n in (2, 3):
+        many = serving.synthesize(m, utts, noise=noise, requests_in_flight=n, **kw)
+        assert len(serving.replicas(m, n)) == n and serving.replicas(m, n)[1][0]._blob is m._blob
+        for a, b in zip(one, many):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    pcm = serving.synthesize(m, utts, noise=noise, requests_in_flight=2, as_pcm16=True, **kw)
+    ref = serving.synthesize(m, utts, noise=noise, as_pcm16=True, **kw)
+    assert all(np.array_equal(a, b) and a.dtype == np.int16 for a, b in zip(pcm, ref))
