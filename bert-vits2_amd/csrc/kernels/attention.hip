@@ -272,6 +272,16 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   }
 
   if (A.dbg) ts2 = __builtin_amdgcn_s_memtime();
+  // fused conv_o: this wave's first 32-row tile of W_o (12 float4 per lane at D = 96) goes in flight NOW — the K / V registers are
+  // dead — and lands under the merge below; loaded where it is used it was an exposed L2 round trip after the last barrier
+  // (tools/timeline.py: normalise + conv_o + store 16-21k cycles of a 46-59k-cycle workgroup)
+  f32x4 wr0[D / 8];
+  const bool pre_w = A.wo != nullptr && wid * 32 < A.Co;
+  if (pre_w) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(A.wo) + ((int64_t)wid * A.wo_groups + h * (D / 8)) * 64 + lh * 32 + l31;
+#pragma unroll
+    for (int g = 0; g < D / 8; ++g) wr0[g] = wp[g * 64];
+  }
   // ---- merge the waves' partials: (max, sum) first, then the rescaled O tiles through ANS slots in fixed order
   if (lh == 0) { Mw[wid * AQ + l31] = m_run; Lw[wid * AQ + l31] = l_run; }
   __syncthreads();
@@ -346,9 +356,14 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     __syncthreads();
     for (int mt = wid; mt * 32 < Co; mt += NW) {
       f32x4 wr[D / 8];
-      const f32x4* wp = reinterpret_cast<const f32x4*>(wo) + ((int64_t)mt * G + h * (D / 8)) * 64 + lh * 32 + l31;
+      if (mt == wid) {                               // prefetched above
 #pragma unroll
-      for (int g = 0; g < D / 8; ++g) wr[g] = wp[g * 64];
+        for (int g = 0; g < D / 8; ++g) wr[g] = wr0[g];
+      } else {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wo) + ((int64_t)mt * G + h * (D / 8)) * 64 + lh * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) wr[g] = wp[g * 64];
+      }
       // epilogue operands in flight under the MFMAs
       float bs[16], rv[16];
       const int row0 = mt * 32 + 4 * lh;
@@ -423,7 +438,9 @@ static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int n
   // Up to 8 key tiles: one per wave, no loop (T = 128: 19.4 -> 16.9 us).  More: 8 waves round-robin.  Measured at T_y = 384
   // (12 tiles) and NOT kept: 12 waves with one tile each (53 spilled registers: 27 -> 41 us) and 6 waves with two tiles each
   // (balanced, but 27 -> 31 us: the merge wait that tools/timeline.py shows is not the 1-vs-2-tile imbalance).
-  if (ntiles <= 4) return launch_attn_variant<DT, 4, true>(stream, a, grid);
+  // fused conv_o: its C_out / 32 row tiles are dealt to the waves — with more than 4 of them (hidden 192: 6) eight waves finish them
+  // in one round even if only 4 have a key tile
+  if (ntiles <= 4 && !(a.wo && a.Co > 128)) return launch_attn_variant<DT, 4, true>(stream, a, grid);
   if (ntiles <= 8) return launch_attn_variant<DT, 8, true>(stream, a, grid);
   return launch_attn_variant<DT, 8, false>(stream, a, grid);
 }
