@@ -349,6 +349,19 @@ def run_two_streams(model, hp, dev, steps, nstreams=2):
                 note="throughput of a 2-deep request pipeline; per-request latency is the sequential figure's ms_per_step or more")
 
 
+def bert_traffic():
+    """HBM bytes per BERT forward from tools/collect_traffic_bert.py's PMC passes (profiles/*traffic_bert*.json), only if taken with the
+    current kernel sources; None otherwise."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_bert*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if all(file_digest(f) == v for f, v in d["source_digests"].items()):
+                return round(d["traffic_bytes_per_forward"])
+        except Exception:
+            continue
+    return None
+
+
 def bench_bert(dev, with_cpu):
     """SURVEY 8f-2 leg (secondary, N=1 only): hidden_states[-3] of a chinese-roberta-wwm-ext-large-shaped BertModel for ONE sentence
     of config 2's size (128 symbols with blanks interspersed = ~51 characters + [CLS]/[SEP] = 53 tokens) through bv2_bert_forward,
@@ -378,7 +391,7 @@ def bench_bert(dev, with_cpu):
                ms_per_sentence=round(ms, 4), sentences_per_sec=round(1e3 / ms, 2), dtype="f32", launches=1 + 1 + 7 * layers,
                roofline=dict(bound="hbm", achieved=round((wbytes + abytes) / (ms * 1e-3) / 1e9, 1), peak=8000.0, unit="GB/s",
                              frac=round((wbytes + abytes) / (ms * 1e-3) / 8e12, 4), alg_bytes_per_forward=int(wbytes + abytes),
-                             tflops=round(flops / (ms * 1e-3) / 1e12, 2), traffic=None,
+                             tflops=round(flops / (ms * 1e-3) / 1e12, 2), traffic=bert_traffic(),
                              note="latency-bound at batch 1: 156 dependent launches of ~10 us; the weights (1.1 GB fp32) are the algorithmic bytes"))
     # the same model over a padded batch of 8 sentences (a request split into sentences, infer.py:268-332): the weights are
     # streamed once per batch instead of once per sentence
