@@ -349,6 +349,61 @@ def run_two_streams(model, hp, dev, steps, nstreams=2):
                 note="throughput of a 2-deep request pipeline; per-request latency is the sequential figure's ms_per_step or more")
 
 
+def build_bert(dev):
+    from bert_vits2_amd.bert_encoder import BertEncoder
+    from oracle import bert_oracle as BO
+    sd = BO.synthetic_state_dict(BO.LARGE, 0, layers=22)
+    return BertEncoder(**BO.LARGE).load_state_dict(sd, device=dev), sd
+
+
+def run_text_to_audio(model, hp, dev, steps, nstreams, enc0):
+    """SURVEY 8f-2 + the hot path as ONE device-resident request: BertModel forward for the sentence (53 tokens, hidden_states[-3]) ->
+    word-level features handed to infer() through bert_index (no host copy, no repeated matrix) -> config 2's 128-symbol utterance,
+    with `nstreams` requests in flight (a handle + HIP stream each for both models, one copy of each weight blob)."""
+    from bert_vits2_amd import bert_features as BF
+    from oracle import bert_oracle as BO
+    cfg = BO.LARGE
+    encs = [enc0] + [enc0.replica() for _ in range(nstreams - 1)]
+    ms = [model]
+    for _ in range(nstreams - 1):
+        m2 = models.from_hparams(hp)
+        m2.attach_blob(model._blob)
+        ms.append(m2)
+    for m in ms:
+        m.enable_graphs(False)
+        m.set_generator_dtype(torch.float32)
+        m.set_flow_dtype(torch.float32)
+    streams = [torch.cuda.Stream(dev) for _ in ms]
+    batch, _ = make_batch(CONFIGS[2], 1, 128, 0)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    ids, _ = BO.synthetic_inputs(cfg, [53], 0)
+    ids = ids.to(dev)
+    word2ph = [1] + [2, 3] * 24 + [2, 2, 2] + [1]                   # 53 words -> 128 symbols (blanks interspersed)
+    assert len(word2ph) == 53 and sum(word2ph) == 128
+    torch.cuda.synchronize()
+
+    def step(i):
+        k = i % nstreams
+        with torch.cuda.stream(streams[k]):
+            feat, index = BF.word_level_feature_cs(encs[k](ids)[0], word2ph)
+            return ms[k].infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], feat[None], b["ja_bert"], b["en_bert"],
+                               bert_index=(index[None], None, None), **KW)
+
+    for i in range(3 * nstreams):
+        out = step(i)
+    torch.cuda.synchronize()
+    frames = int(out[2].sum().item())
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    audio = frames * hp.total_upsample / hp.sampling_rate
+    return dict(workload=f"BertModel 24x1024 features (53 tokens) + BASELINE config 2's utterance per request, features handed over on the "
+                         f"device at word level, {nstreams} requests in flight", requests_in_flight=nstreams,
+                value=round(audio * steps / dt, 2), unit="audio-seconds/sec", ms_per_request=round(dt / steps * 1e3, 4), steps=steps)
+
+
 def bert_traffic():
     """HBM bytes per BERT forward from tools/collect_traffic_bert.py's PMC passes (profiles/*traffic_bert*.json), only if taken with the
     current kernel sources; None otherwise."""
@@ -362,15 +417,14 @@ def bert_traffic():
     return None
 
 
-def bench_bert(dev, with_cpu):
+def bench_bert(dev, with_cpu, enc=None, sd=None):
     """SURVEY 8f-2 leg (secondary, N=1 only): hidden_states[-3] of a chinese-roberta-wwm-ext-large-shaped BertModel for ONE sentence
     of config 2's size (128 symbols with blanks interspersed = ~51 characters + [CLS]/[SEP] = 53 tokens) through bv2_bert_forward,
     seeded synthetic weights.  HBM-side roofline: every forward streams the 22 layers' fp32 weights once (algorithmic bytes)."""
-    from bert_vits2_amd.bert_encoder import BertEncoder
     from oracle import bert_oracle as BO
     cfg, S, layers = BO.LARGE, 53, 22
-    sd = BO.synthetic_state_dict(cfg, 0, layers=layers)
-    enc = BertEncoder(**cfg).load_state_dict(sd, device=dev)
+    if enc is None:
+        enc, sd = build_bert(dev)
     ids, _ = BO.synthetic_inputs(cfg, [S], 0)
     ids = ids.to(dev)
     for _ in range(3):
@@ -527,7 +581,20 @@ def main():
             except Exception as e:
                 secondary[key] = dict(error=repr(e)[:300])
         try:
-            secondary["bert_zh_features"] = bench_bert(dev, not args.no_cpu_baseline)
+            bert_enc, bert_sd = build_bert(dev)
+        except Exception as e:
+            bert_enc, bert_sd = None, None
+            secondary["bert_zh_features"] = dict(error=repr(e)[:300])
+        for ns in (1, 4) if bert_enc is not None else ():
+            key = f"text_features_plus_config2_{ns}_in_flight"
+            try:
+                secondary[key] = run_text_to_audio(model, hp, dev, max(20, args.steps), ns, bert_enc)
+                log(f"secondary BERT + config 2, {ns} in flight: {secondary[key]['value']} audio-s/s")
+            except Exception as e:
+                secondary[key] = dict(error=repr(e)[:300])
+        try:
+            if bert_enc is not None:
+                secondary["bert_zh_features"] = bench_bert(dev, not args.no_cpu_baseline, bert_enc, bert_sd)
             log(f"secondary BERT feature extraction: {secondary['bert_zh_features']['ms_per_sentence']} ms per sentence")
         except Exception as e:
             secondary["bert_zh_features"] = dict(error=repr(e)[:300])

@@ -45,6 +45,7 @@ class BertEncoder:
         self._lib = L.load()
         cfg = L.BertConfig(C.sizeof(L.BertConfig), vocab_size, hidden_size, num_attention_heads, intermediate_size,
                            max_position_embeddings, type_vocab_size, idx, layer_norm_eps)
+        self._cfg = cfg
         self._h = C.c_void_p()
         if self._lib.bv2_bert_create(C.byref(cfg), C.byref(self._h)) != 0:
             raise RuntimeError(self._lib.bv2_bert_last_error(None).decode())
@@ -85,6 +86,22 @@ class BertEncoder:
             if self._lib.bv2_bert_attach_weights(self._h, _ptr(self._blob), n) != 0:
                 raise RuntimeError(self._err())
         return self
+
+    def replica(self) -> "BertEncoder":
+        """A second handle (own workspace, usable on another HIP stream) on the SAME packed weights: request-level concurrency
+        (``serving.replicas`` does this for the synthesizer)."""
+        if self._blob is None:
+            raise RuntimeError("BertEncoder: load_state_dict first")
+        r = BertEncoder.__new__(BertEncoder)
+        r.layers_run, r.hidden_size, r._lib, r._cfg = self.layers_run, self.hidden_size, self._lib, self._cfg
+        r._h = C.c_void_p()
+        if self._lib.bv2_bert_create(C.byref(self._cfg), C.byref(r._h)) != 0:
+            raise RuntimeError(self._lib.bv2_bert_last_error(None).decode())
+        r._blob, r._ws, r.device = self._blob, None, self.device
+        with torch.cuda.device(self.device):
+            if self._lib.bv2_bert_attach_weights(r._h, _ptr(r._blob), r._blob.numel() * 4) != 0:
+                raise RuntimeError(r._err())
+        return r
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
