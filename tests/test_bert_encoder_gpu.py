@@ -91,3 +91,18 @@ def test_rejects_sequences_longer_than_the_position_table():
     enc = _encoder(BO.TINY, BO.synthetic_state_dict(BO.TINY, 0))
     with pytest.raises(RuntimeError, match="max_position"):
         enc(torch.zeros(1, BO.TINY["max_position_embeddings"] + 1, dtype=torch.int64).cuda())
+
+
+def test_replica_shares_the_weights_and_runs_on_its_own_stream():
+    cfg = BO.MID
+    sd = BO.synthetic_state_dict(cfg, 2)
+    enc = _encoder(cfg, sd)
+    rep = enc.replica()
+    assert rep._blob is enc._blob and rep._h.value != enc._h.value
+    ids, ln = BO.synthetic_inputs(cfg, [40, 23], 3)
+    a = enc(ids.cuda(), lengths=ln.cuda())
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        b = rep(ids.cuda(), lengths=ln.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
