@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE — writes tests/golden/bert_*.npz with the REAL ``transformers.BertModel`` (run in the build container, where
+"""TEST INFRASTRUCTURE — writes tests/golden/bert_*.npz with the REAL ``transformers`` model (run in the build container, where
 ``transformers`` is installed; the GPU box never needs it).  For each case: seeded synthetic weights (oracle/bert_oracle.py) are
-loaded into ``BertModel(BertConfig(**cfg), add_pooling_layer=False)``, the model runs exactly as the reference calls it
+loaded into ``AutoModelForMaskedLM.from_config(BertConfig(**cfg))`` — the class the reference instantiates — and the model runs exactly
+as the reference calls it
 (text/chinese_bert.py:34-37: tokenizer output -> ``model(**inputs, output_hidden_states=True)`` -> ``hidden_states[-3]``) and the
 hidden state is stored together with the inputs and a checksum of the weights.
 
@@ -26,13 +27,16 @@ CASES = {  # name: (config, lengths, weight seed, token types)
 
 
 def main():
-    from transformers import BertConfig, BertModel
+    from transformers import AutoModelForMaskedLM, BertConfig
     out_dir = os.path.join(ROOT, "tests", "golden")
     for name, (cfg, lengths, seed, use_tt) in CASES.items():
         sd = BO.synthetic_state_dict(cfg, seed)
-        m = BertModel(BertConfig(**cfg), add_pooling_layer=False).eval()
-        missing, unexpected = m.load_state_dict(sd, strict=False)
-        assert not unexpected and all("position_ids" in k or "token_type_ids" in k for k in missing), (missing, unexpected)
+        # the class the reference instantiates (text/chinese_bert.py:31): AutoModelForMaskedLM -> BertForMaskedLM; the encoder's
+        # tensors carry the "bert." prefix there, the MLM head (cls.*) keeps its random init — it never touches hidden_states
+        m = AutoModelForMaskedLM.from_config(BertConfig(**cfg)).eval()
+        assert type(m).__name__ == "BertForMaskedLM"
+        missing, unexpected = m.load_state_dict({"bert." + k: v for k, v in sd.items()}, strict=False)
+        assert not unexpected and all(k.startswith("cls.") or "position_ids" in k or "token_type_ids" in k for k in missing), (missing, unexpected)
         ids, ln = BO.synthetic_inputs(cfg, lengths, seed)
         S = ids.shape[1]
         am = (torch.arange(S)[None, :] < ln[:, None]).long()
