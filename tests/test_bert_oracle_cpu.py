@@ -9,8 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import bert_oracle as BO
-from oracle.gen_bert_golden import CASES
+from oracle import bert_oracle as BO, deberta_oracle as DO
+from oracle.gen_bert_golden import CASES, DEBERTA_CASES
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -86,3 +86,52 @@ def test_encoder_wrapper_refuses_deberta_and_cpu():
     assert enc.layers_run == 3
     with pytest.raises(RuntimeError):
         enc.load_state_dict(BO.synthetic_state_dict(BO.TINY, 0), device="cpu")
+
+
+@pytest.mark.parametrize("name", sorted(DEBERTA_CASES))
+def test_deberta_oracle_matches_the_real_transformers_model(name):
+    """oracle/deberta_oracle.py against goldens of DebertaV2Model / AutoModelForMaskedLM (the two classes the reference
+    instantiates): embeddings, the output of layer 1 (which includes the Japanese model's ConvLayer) and hidden_states[-3]."""
+    cfg_name, lengths, seed, _cls = DEBERTA_CASES[name]
+    cfg = getattr(DO, cfg_name)
+    g = np.load(os.path.join(GOLD, f"deberta_{name}.npz"))
+    sd = DO.synthetic_state_dict(cfg, seed)
+    assert hashlib.sha256(b"".join(sd[k].numpy().tobytes() for k in sorted(sd))).hexdigest() == str(g["weights_sha256"])
+    ids, ln = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["lengths"])
+    valid = (torch.arange(ids.shape[1])[None, :] < ln[:, None])[..., None]
+    n = cfg["num_hidden_layers"]
+    for layers, key, tol in ((0, "hidden_0", 2e-6), (1, "hidden_1", 2e-5), (n - 2, "hidden_m3", 5e-5)):
+        got = DO.hidden_state(sd, cfg, ids, layers, lengths=ln)
+        err = ((got - torch.from_numpy(g[key])).abs() * valid).max().item()
+        assert err < tol, (key, err)
+    got64 = DO.hidden_state(sd, cfg, ids, n - 2, lengths=ln, dtype=torch.float64).float()
+    assert ((got64 - torch.from_numpy(g["hidden_m3"])).abs() * valid).max().item() < 5e-5
+
+
+def test_relative_index_table_matches_the_pairwise_formulas():
+    """The ONE index table the device kernel gathers both relative terms with == HF's c2p index and (transposed) p2c index."""
+    for cfg in (DO.TINY_V3, DO.MID_V3, DO.LARGE_V3):
+        S = min(cfg["max_position_embeddings"], 300)
+        span = DO.att_span(cfg)
+        tab = DO.relative_index_table(cfg, S)
+        ids = torch.arange(S)
+        rel = DO.log_bucket_position(ids[:, None] - ids[None, :], cfg["position_buckets"], cfg["max_position_embeddings"]).long()
+        c2p = torch.clamp(rel + span, 0, 2 * span - 1)
+        p2c_t = torch.clamp(-rel + span, 0, 2 * span - 1).T            # p2c is gathered on [k, q] and transposed
+        pair = tab[(ids[:, None] - ids[None, :]) + S - 1]
+        assert torch.equal(pair, c2p) and torch.equal(pair, p2c_t)
+        d = tab[1:] - tab[:-1]
+        assert bool(((d == 0) | (d == 1)).all())                        # monotone with slope <= 1: a 32x32 tile pair needs <= 63 rows
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/bert"), reason="the reference tree (build container only)")
+def test_configs_are_the_ones_the_reference_ships():
+    import json
+    ref = lambda d: json.load(open(f"/root/reference/bert/{d}/config.json"))
+    z = ref("chinese-roberta-wwm-ext-large")
+    assert all(z[k] == v for k, v in BO.LARGE.items()) and z["model_type"] == "bert" and z["hidden_act"] == "gelu"
+    for name, mine in (("deberta-v3-large", DO.LARGE_V3), ("deberta-v2-large-japanese-char-wwm", DO.LARGE_JA)):
+        c = ref(name)
+        norm = lambda v: sorted(v.split("|")) if isinstance(v, str) and "|" in v else (sorted(v) if isinstance(v, list) else v)
+        assert all(norm(c[k]) == norm(v) for k, v in mine.items()), name
+        assert c["model_type"] == "deberta-v2" and c["hidden_act"] == "gelu"
