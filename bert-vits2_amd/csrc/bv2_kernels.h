@@ -252,7 +252,8 @@ int launch_layernorm(hipStream_t stream, const LnArgs& a);
 // BERT feature extractor (kernels/bert.hip; include/bv2_bert.h)
 struct BertEmbedArgs {
   const int64_t* input_ids; const int64_t* token_type_ids;     // [B][S]; token_type_ids may be null (all 0)
-  const float* word; const float* pos; const float* type;      // [vocab][C], [max_pos][C], [type_vocab][C]
+  const float* word; const float* pos; const float* type;      // [vocab][C], [max_pos][C], [type_vocab][C]; pos / type may be null (DeBERTa-v2)
+  const int64_t* lengths;                                      // null, or [B]: the output column of token s >= lengths[b] is multiplied by 0 (DebertaV2Embeddings)
   const float* gamma; const float* beta; float eps;
   float* out;                                                  // [B][C][S]
   int B, S, C, vocab, max_pos, type_vocab;
@@ -261,10 +262,23 @@ int launch_bert_embed_ln(hipStream_t stream, const BertEmbedArgs& a);
 struct BertLnArgs {
   const float* a; int nslab; int64_t slab_stride;              // sum of nslab slabs [B][C][T]
   const float* gamma; const float* beta; float eps;
+  const float* mask;                                           // null, or [B][T] multiplied into the output (DeBERTa-v2 ConvLayer)
   float* out;
   int B, C, T;
 };
 int launch_bert_ln(hipStream_t stream, const BertLnArgs& a);
+// DeBERTa-v2 disentangled attention (kernels/deberta_attn.hip)
+struct DebertaAttnArgs {
+  const float* qkv;         // [B][3*H*D][ld]: q rows (ALREADY divided by sqrt(3 D)), k rows, v rows; ld % 32 == 0, ld >= T
+  int ld;
+  const float* mask;        // [B][T]
+  const float* pk;          // [H][D][2 span]   key_proj(LayerNorm(rel_embeddings)), transposed per head
+  const float* pq;          // [H][D][2 span]   query_proj(LayerNorm(rel_embeddings)) / sqrt(3 D), transposed per head
+  const float* tab;         // [2 P - 1] floats: t(r) = clamp(bucket(r) + span, 0, 2 span - 1) for r = -(P-1) .. P-1
+  float* out;               // [B][H*D][T]
+  int B, H, D, T, P, span;
+};
+int launch_deberta_attn(hipStream_t stream, const DebertaAttnArgs& a);
 
 // --------------------------------------------------------------------------------------------------------------
 // windowed relative-position multi-head attention (kernels/attention.hip), reference attentions.py:273-322

@@ -23,14 +23,16 @@ __global__ void __launch_bounds__(256) bert_embed_ln_kernel(const BertEmbedArgs 
   tt = tt < 0 ? 0 : (tt >= A.type_vocab ? A.type_vocab - 1 : tt);
   const int ps = s < A.max_pos ? s : A.max_pos - 1;
   const float* wrow = A.word + id * C;
-  const float* prow = A.pos + (int64_t)ps * C;
-  const float* trow = A.type + tt * C;
+  const float* prow = A.pos ? A.pos + (int64_t)ps * C : nullptr;
+  const float* trow = A.type ? A.type + tt * C : nullptr;
+  const float mk = (A.lengths && (int64_t)s >= A.lengths[b]) ? 0.f : 1.f;
   float v[8], gm[8], bt[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     int c = tid + 256 * i;
     c = c < C ? c : C - 1;
-    v[i] = (wrow[c] + trow[c]) + prow[c];            // BertEmbeddings: inputs_embeds + token_type_embeddings, then + position_embeddings
+    // BertEmbeddings: inputs_embeds + token_type_embeddings, then + position_embeddings; DebertaV2Embeddings here: inputs_embeds only
+    v[i] = (wrow[c] + (trow ? trow[c] : 0.f)) + (prow ? prow[c] : 0.f);
     gm[i] = A.gamma[c];
     bt[i] = A.beta[c];
   }
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(256) bert_embed_ln_kernel(const BertEmbedArgs 
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = tid + 256 * i;
-    if (c < C) op[(int64_t)c * S] = (v[i] - mean) * rstd * gm[i] + bt[i];
+    if (c < C) op[(int64_t)c * S] = ((v[i] - mean) * rstd * gm[i] + bt[i]) * mk;
   }
 }
 
@@ -135,10 +137,11 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   const float rstd = 1.0f / sqrtf(qq / (float)C + A.eps);
   if (!tok) return;
   float* const outp = A.out + base;
+  const float mk = A.mask ? A.mask[(int64_t)b * T + t] : 1.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = ty + i * BLN_G;
-    outp[c * T + t] = (v[i] - mean) * rstd * gm[i] + bt[i];
+    outp[c * T + t] = ((v[i] - mean) * rstd * gm[i] + bt[i]) * mk;
   }
 }
 

@@ -42,7 +42,8 @@ class BertConfig(C.Structure):
     """include/bv2_bert.h bv2_bert_config"""
     _fields_ = [("struct_bytes", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_heads", C.c_int32),
                 ("intermediate_size", C.c_int32), ("max_position", C.c_int32), ("type_vocab_size", C.c_int32),
-                ("num_layers_run", C.c_int32), ("layer_norm_eps", C.c_float)]
+                ("num_layers_run", C.c_int32), ("layer_norm_eps", C.c_float), ("arch", C.c_int32), ("att_span", C.c_int32),
+                ("conv_kernel_size", C.c_int32)]
 
 
 class EncodeIn(C.Structure):

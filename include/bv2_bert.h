@@ -9,8 +9,9 @@
  * encoder layer 22 — the last two layers and the MLM head never run here.  The algorithm lives in a third-party dependency that
  * is not in /root/reference (`transformers`, unpinned in the reference's requirements.txt:11; 5.15.0 in the build image): the
  * oracle (oracle/bert_oracle.py) restates BertModel's published forward pass and is pinned by goldens that the REAL
- * transformers.BertModel produced (oracle/gen_bert_golden.py).  The Japanese / English extractors (text/japanese_bert.py,
- * english_bert_mock.py) are DeBERTa-v2 models (disentangled attention): not covered by this entry point.
+ * transformers.BertModel produced (oracle/gen_bert_golden.py).  The Japanese / English extractors (text/japanese_bert.py:34-43,
+ * english_bert_mock.py:30-41) are DeBERTa-v2 models (`DebertaV2ForMaskedLM` / `DebertaV2Model`, disentangled attention): the same
+ * entry points run them with bv2_bert_config.arch = BV2_BERT_ARCH_DEBERTA_V2 (oracle/deberta_oracle.py, goldens of the real classes).
  *
  * Same conventions as bv2.h: plain pointers and sizes, every device buffer caller-allocated, launches only on the caller's stream,
  * no allocation, no host sync (capturable), int status + bv2_bert_last_error.  Output layout is the one the TextEncoder front of
@@ -37,8 +38,18 @@ typedef struct bv2_bert_config {
   int32_t max_position;          /* 512 */
   int32_t type_vocab_size;       /* 2 */
   int32_t num_layers_run;        /* encoder layers to execute: num_hidden_layers - 2 = 22 gives hidden_states[-3] */
-  float layer_norm_eps;          /* 1e-12 */
+  float layer_norm_eps;          /* 1e-12 (BERT), 1e-7 (DeBERTa-v2) */
+  /* ---- architecture.  BV2_BERT_ARCH_BERT: the fields above are everything.  BV2_BERT_ARCH_DEBERTA_V2 (the reference's Japanese /
+   * English extractors, text/japanese_bert.py:9, text/english_bert_mock.py:9; configs under /root/reference/bert/): word embeddings
+   * only (position_biased_input = false, type_vocab_size = 0: max_position / type_vocab_size above are then the relative-position
+   * table length and ignored), disentangled attention with relative positions (relative_attention, share_att_key, pos_att_type
+   * c2p|p2c, norm_rel_ebd layer_norm), optional ConvLayer after the first encoder layer. */
+  int32_t arch;
+  int32_t att_span;              /* DeBERTa: position_buckets (256), or max_relative_positions when buckets are off */
+  int32_t conv_kernel_size;      /* DeBERTa: ConvLayer kernel size (3 for deberta-v2-large-japanese-char-wwm), 0 = none; conv_act gelu */
 } bv2_bert_config;
+#define BV2_BERT_ARCH_BERT 0
+#define BV2_BERT_ARCH_DEBERTA_V2 1
 
 int bv2_bert_create(const bv2_bert_config* cfg, bv2_bert** out);
 void bv2_bert_destroy(bv2_bert* h);
@@ -54,6 +65,13 @@ int64_t bv2_bert_packed_bytes(const bv2_bert* h);
  * (pooler, cls head, position_ids, layers >= num_layers_run), < 0 = error (unknown layout / shape mismatch). */
 int bv2_bert_pack_tensor(bv2_bert* h, void* host_blob, int64_t blob_bytes, const char* hf_key, const float* data,
                          const int64_t* shape, int ndim);
+/* DeBERTa-v2 additionally needs three tensors that are functions of the weights only — the caller (bert_encoder.py) derives them
+ * once from the state_dict and packs them like any other tensor:
+ *   "encoder.layer.N.attention.self.pos_key"    fp32 [2*att_span][hidden] = key_proj(LayerNorm(encoder.rel_embeddings.weight))
+ *   "encoder.layer.N.attention.self.pos_query"  fp32 [2*att_span][hidden] = query_proj(LayerNorm(encoder.rel_embeddings.weight))
+ *   "encoder.relative_index"                    fp32 [2*max_position - 1]: clamp(bucket(r) + att_span, 0, 2*att_span - 1) for
+ *                                               r = -(max_position-1) .. max_position-1 (make_log_bucket_position)
+ * (1/sqrt(3*head_dim) is folded into the query rows and into pos_query here, not by the caller.) */
 /* Number of tensors the blob still misses (0 = complete); names via bv2_bert_last_error when > 0. */
 int bv2_bert_missing(bv2_bert* h);
 

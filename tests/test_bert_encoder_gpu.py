@@ -9,16 +9,16 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import bert_oracle as BO
-from oracle.gen_bert_golden import CASES
+from oracle import bert_oracle as BO, deberta_oracle as DO
+from oracle.gen_bert_golden import CASES, DEBERTA_CASES
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _encoder(cfg, sd):
+def _encoder(cfg, sd, model_type="bert"):
     from bert_vits2_amd.bert_encoder import BertEncoder
-    return BertEncoder(**cfg).load_state_dict(sd, device="cuda")
+    return BertEncoder(**cfg, model_type=model_type).load_state_dict(sd, device="cuda")
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -106,3 +106,64 @@ def test_replica_shares_the_weights_and_runs_on_its_own_stream():
         b = rep(ids.cuda(), lengths=ln.cuda())
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# DeBERTa-v2 (the reference's Japanese / English extractors): text/japanese_bert.py:34-43, text/english_bert_mock.py:30-41
+@pytest.mark.parametrize("name", sorted(DEBERTA_CASES))
+def test_device_deberta_matches_the_real_transformers_golden(name):
+    cfg_name, lengths, seed, cls = DEBERTA_CASES[name]
+    cfg = getattr(DO, cfg_name)
+    g = np.load(os.path.join(GOLD, f"deberta_{name}.npz"))
+    sd = DO.synthetic_state_dict(cfg, seed)
+    if cls != "DebertaV2Model":
+        sd = {"deberta." + k: v for k, v in sd.items()}            # DebertaV2ForMaskedLM-style keys (japanese_bert.py loads that class)
+    enc = _encoder(cfg, sd, "deberta-v2")
+    ids, ln = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["lengths"])
+    out = enc(ids.cuda(), lengths=ln.cuda())
+    torch.cuda.synchronize()
+    got = out.cpu().transpose(1, 2)
+    ref = torch.from_numpy(g["hidden_m3"])
+    valid = (torch.arange(ids.shape[1])[None, :] < ln[:, None])[..., None]
+    err = ((got - ref).abs() * valid).max().item()
+    assert torch.isfinite(got).all() and err < 3e-4, err
+
+
+@pytest.mark.parametrize("cfg_name,lengths", [("TINY_V3", [1]), ("TINY_JA", [2, 1]), ("TINY_JA", [33]), ("MID_V3", [160]),
+                                              ("MID_V3", [97, 129, 40])])
+def test_deberta_sequence_length_edges_vs_oracle(cfg_name, lengths):
+    cfg = getattr(DO, cfg_name)
+    sd = DO.synthetic_state_dict(cfg, 7)
+    enc = _encoder(cfg, sd, "deberta-v2")
+    g = torch.Generator().manual_seed(3)
+    ln = torch.tensor(lengths)
+    ids = torch.randint(1, cfg["vocab_size"], (len(lengths), max(lengths)), generator=g)
+    ids = ids * (torch.arange(max(lengths))[None, :] < ln[:, None])
+    out = enc(ids.cuda(), lengths=ln.cuda()).cpu().transpose(1, 2)
+    n = cfg["num_hidden_layers"] - 2
+    ref = DO.hidden_state(sd, cfg, ids, n, lengths=ln, dtype=torch.float64).float()
+    valid = (torch.arange(ids.shape[1])[None, :] < ln[:, None])[..., None]
+    assert torch.isfinite(out).all()
+    assert ((out - ref).abs() * valid).max().item() < 3e-4
+    # the first layers on their own (embeddings -> layer 0 [-> ConvLayer]) localise a failure
+    one = _encoder(dict(cfg, num_hidden_layers=3), sd, "deberta-v2")
+    o1 = one(ids.cuda(), lengths=ln.cuda()).cpu().transpose(1, 2)
+    r1 = DO.hidden_state(sd, cfg, ids, 1, lengths=ln, dtype=torch.float64).float()
+    assert ((o1 - r1).abs() * valid).max().item() < 1e-4
+
+
+@pytest.mark.parametrize("cfg_name", ["LARGE_JA", "LARGE_V3"])
+def test_full_size_deberta_large_vs_oracle(cfg_name):
+    """deberta-v2-large-japanese-char-wwm (ConvLayer) and deberta-v3-large at their real size: 24 x 1024, 256 buckets."""
+    cfg = dict(getattr(DO, cfg_name), vocab_size=2000)            # the vocabulary size only scales the embedding table
+    sd = DO.synthetic_state_dict(cfg, 5, layers=22)
+    enc = _encoder(cfg, sd, "deberta-v2")
+    assert enc.layers_run == 22
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(1, cfg["vocab_size"], (1, 53), generator=g)
+    out = enc(ids.cuda())
+    torch.cuda.synchronize()
+    ref = DO.hidden_state(sd, cfg, ids, 22, dtype=torch.float64).float()
+    err = (out.cpu().transpose(1, 2) - ref).abs().max().item()
+    print(f"{cfg_name} S=53: max-abs error vs fp64 oracle {err:.2e} (output scale {ref.abs().max().item():.2f})")
+    assert err < 1e-3, err

@@ -78,10 +78,36 @@ def test_cabi_config_validation_and_pack_accounting():
     lib.bv2_bert_destroy(h2)
 
 
-def test_encoder_wrapper_refuses_deberta_and_cpu():
-    from bert_vits2_amd.bert_encoder import BertEncoder
+def test_encoder_wrapper_refuses_unsupported_variants_and_cpu():
+    from bert_vits2_amd.bert_encoder import BertEncoder, _relative_index_table
     with pytest.raises(NotImplementedError):
-        BertEncoder(model_type="deberta-v2")
+        BertEncoder(model_type="roberta")
+    with pytest.raises(NotImplementedError):
+        BertEncoder(model_type="deberta-v2")                      # BERT's defaults are not a DeBERTa config
+    with pytest.raises(NotImplementedError):
+        BertEncoder(**dict(DO.TINY_V3, share_att_key=False), model_type="deberta-v2")
+    with pytest.raises(NotImplementedError):
+        BertEncoder(**dict(DO.TINY_JA, conv_act="tanh"), model_type="deberta-v2")
+    d = BertEncoder(**DO.TINY_JA, model_type="deberta-v2")
+    assert d.layers_run == 3 and d.arch == 1
+    # the product's own table builder (no oracle import there) == the oracle's
+    for cfg in (DO.TINY_V3, DO.MID_V3, DO.LARGE_V3):
+        P = cfg["max_position_embeddings"]
+        assert torch.equal(_relative_index_table(cfg["position_buckets"], P, DO.att_span(cfg), P), DO.relative_index_table(cfg, P).float())
+    # packing a DeBERTa state_dict: derived tensors are added, rel_embeddings / encoder.LayerNorm are consumed by the wrapper
+    _, lib = _lib()
+    sd = d._with_deberta_derived({"deberta." + k: v for k, v in DO.synthetic_state_dict(DO.TINY_JA, 1).items()})
+    n = lib.bv2_bert_packed_bytes(d._h)
+    blob = torch.zeros(n // 4)
+    codes = {}
+    for k, v in sd.items():
+        t = v.float().contiguous()
+        shp = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        codes[k] = lib.bv2_bert_pack_tensor(d._h, C.c_void_p(blob.data_ptr()), n, k.encode(), C.c_void_p(t.data_ptr()), shp, t.dim())
+    unused = {k for k, c in codes.items() if c == 1}
+    assert min(codes.values()) >= 0 and lib.bv2_bert_missing(d._h) == 0
+    assert {"encoder.rel_embeddings.weight", "encoder.LayerNorm.weight", "encoder.LayerNorm.bias"} <= unused
+    assert all(k.startswith(("encoder.layer.3.", "encoder.layer.4.", "encoder.rel_embeddings", "encoder.LayerNorm")) for k in unused), unused
     enc = BertEncoder(**BO.TINY)
     assert enc.layers_run == 3
     with pytest.raises(RuntimeError):
