@@ -461,6 +461,31 @@ def bench_bert(dev, with_cpu, enc=None, sd=None):
     ms8 = (time.perf_counter() - t0) / 10 * 1e3
     res["batch8"] = dict(ms_per_batch=round(ms8, 4), sentences_per_sec=round(8e3 / ms8, 1), tokens=int(ln8.sum().item()),
                          tflops=round(flops / S * 8 * 53 / (ms8 * 1e-3) / 1e12, 2))
+    # the reference's Japanese / English extractors (DeBERTa-v2 large; text/japanese_bert.py, english_bert_mock.py) on the same sentence
+    # size: disentangled attention (kernels/deberta_attn.hip), the Japanese model's ConvLayer
+    try:
+        from bert_vits2_amd.bert_encoder import BertEncoder
+        from oracle import deberta_oracle as DO
+        for nm, dcfg in (("deberta_v2_large_japanese", DO.LARGE_JA), ("deberta_v3_large", DO.LARGE_V3)):
+            dcfg = dict(dcfg, vocab_size=min(dcfg["vocab_size"], 32000))        # the embedding table is read one row per token
+            dsd = DO.synthetic_state_dict(dcfg, 0, layers=layers)
+            denc = BertEncoder(**dcfg, model_type="deberta-v2").load_state_dict(dsd, device=dev)
+            dids = torch.randint(1, dcfg["vocab_size"], (1, S), generator=torch.Generator().manual_seed(1)).to(dev)
+            for _ in range(3):
+                denc(dids)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dout = denc(dids)
+            torch.cuda.synchronize()
+            dms = (time.perf_counter() - t0) / 20 * 1e3
+            res[nm] = dict(ms_per_sentence=round(dms, 4), sentences_per_sec=round(1e3 / dms, 2), tokens=S)
+            if with_cpu and nm == "deberta_v2_large_japanese":
+                dref = DO.hidden_state(dsd, dcfg, dids.cpu(), layers)
+                res[nm]["max_abs_err_vs_oracle"] = float((dout.cpu().transpose(1, 2) - dref).abs().max())
+            del denc, dsd
+    except Exception as e:
+        res["deberta_error"] = repr(e)[:300]
     if with_cpu:
         t1 = time.perf_counter()
         ref = BO.hidden_state(sd, cfg, ids.cpu(), layers)
