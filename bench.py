@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — audio-seconds/sec on the SynthesizerTrn.infer() hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without a launcher: bench.py spawns its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one full ``infer()`` (phase A + the reference's one host sync + phase B) over one batch of synthetic utterances already
@@ -46,13 +46,14 @@ CONFIGS = {
     4: dict(batch=32, symbols=128, dtype="bf16", flow="f16", graph=1, ragged=True),
     5: dict(batch=8, symbols=512, dtype="bf16", flow="f16", graph=0, ragged=False),
 }
+WN_FLOW_B32 = "f32"               # flow arithmetic of secondary.config3_residual_flow ("f16" once the fp16 WN convs exist)
 KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
 KERNEL_SOURCES = {"conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
                   "conv_cl_bf16": "gen_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "conv_f16": "enc_f16.hip",
                   "attention": "attention.hip"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -75,7 +76,9 @@ def parse():
                     help="bv2_test_set_variants(spec, cl_generic, hc_generic) before the run (tuning A/B only)")
     ap.add_argument("--streams", type=int, default=2, help="requests in flight for the secondary two-stream leg of config 2")
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="self-launched N>1 runs: rendezvous port on 127.0.0.1 (0 = pick a free one)")
+    ap.add_argument("--seam", default=None, help=argparse.SUPPRESS)   # tests only: module replacing the GPU-touching seam (see Seam)
+    return ap.parse_args(argv)
 
 
 def log(msg):
@@ -103,11 +106,29 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def reference_container():
+    """The REAL reference timed on the build container beside the oracle port (oracle/time_reference.py; the Python reference cannot
+    travel to the GPU box): the newest committed profiles/*reference_container*.json, or None."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*reference_container*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            return dict(ms=d["reference"]["ms"], audio_s_per_s=d["reference"]["audio_s_per_s"], threads=d["threads"], cores=d["cores_usable"],
+                        torch=d["torch"], port_ms_same_box=d["port"]["ms"], reference_over_port=d["reference_over_port"],
+                        waveform_rms_reference_vs_port=d["waveform_rms_reference_vs_port"], source=os.path.relpath(path, ROOT),
+                        note="the reference's own SynthesizerTrn.infer (models.py:1026-1074, unmodified) on the BUILD CONTAINER's host cores, "
+                             "same utterance / checkpoint / noise as the port figure beside it; measured by oracle/time_reference.py")
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(hp, sd, iters, budget_s=40.0):
     """The oracle restatement (same aten CPU kernels and per-call weight_norm fold as the reference's infer) timed on this box's
-    host cores — a reported baseline, kind "port" (the Python reference cannot travel to the GPU box).  Config 2's utterance on all
-    usable threads (2 warm-ups, median of up to ``iters`` runs), plus config 1's shape (T=64) and a single-thread figure, all
-    inside ``budget_s`` seconds."""
+    host cores — a reported baseline, kind "port" (the Python reference cannot travel to the GPU box; `reference_container` beside
+    it is the real reference timed on the build container with the port's time on that same machine, so the ratio is known).
+    Config 2's utterance on all usable threads (2 warm-ups, median of up to ``iters`` runs), plus config 1's shape (T=64) and a
+    single-thread figure, all inside ``budget_s`` seconds.  Also returns (batch, noise_w, noise_z, oracle output) of config 2's
+    utterance for the parity block."""
     from oracle import bv2_oracle as O
     nthreads = min(usable_cores(), 64)
     t_begin = time.perf_counter()
@@ -128,19 +149,59 @@ def cpu_baseline(hp, sd, iters, budget_s=40.0):
         ts.sort()
         med = ts[len(ts) // 2]
         audio = float(out["y_lengths"].sum()) * hp.total_upsample / hp.sampling_rate
-        return audio / med, med, len(ts), audio, int(out["y_lengths"].max())
+        return audio / med, med, len(ts), audio, int(out["y_lengths"].max()), (batch, nw, nz, out)
 
-    v2, med2, n2, audio2, ty2 = timed(128, nthreads, 2, iters)
+    v2, med2, n2, audio2, ty2, par = timed(128, nthreads, 2, iters)
     log(f"cpu baseline: config 2 on {nthreads} threads {v2:.2f} audio-s/s ({med2 * 1e3:.1f} ms)")
-    v1, med1, n1, _, _ = timed(64, nthreads, 1, 3)
-    vs, meds, ns, _, _ = timed(128, 1, 0, 1) if time.perf_counter() - t_begin < budget_s - 8 else (None, None, 0, None, None)
+    v1, med1, n1, _, _, _ = timed(64, nthreads, 1, 3)
+    vs, meds, ns = (None, None, 0)
+    if time.perf_counter() - t_begin < budget_s - 8:
+        vs, meds, ns, _, _, _ = timed(128, 1, 0, 1)
     torch.set_num_threads(nthreads)
+    rc = reference_container()
+    est = None if rc is None else round(v2 / rc["reference_over_port"], 3)
     return dict(value=round(v2, 3), unit="audio-seconds/sec", cores=nthreads, kind="port",
                 sample=f"median of {n2} timed runs of config 2's utterance (B=1, T=128, T_y={ty2}, {audio2:.3f} s audio) after 2 warm-ups, "
                        f"torch CPU fp32, oracle restatement",
                 ms_per_step=round(med2 * 1e3, 2),
                 config1_T64=dict(value=round(v1, 3), ms_per_step=round(med1 * 1e3, 2), runs=n1),
-                single_thread=None if vs is None else dict(value=round(vs, 3), ms_per_step=round(meds * 1e3, 2), cores=1, runs=ns))
+                single_thread=None if vs is None else dict(value=round(vs, 3), ms_per_step=round(meds * 1e3, 2), cores=1, runs=ns),
+                reference_container=rc,
+                reference_estimate_this_box=None if est is None else dict(
+                    value=est, unit="audio-seconds/sec",
+                    note="this box's port figure / reference_container.reference_over_port: what the reference's own infer() would "
+                         "reach on these host cores if the container's reference/port ratio carries over")), par
+
+
+def parity_block(model, hp, dev, par):
+    """Parity of the measured configuration, inside the measured line: config 2's utterance (the one the CPU leg just ran through
+    the oracle) through the HIP path with the SAME injected noise; waveform RMS error (north_star: <= 1e-3), mel-spectrogram L1
+    with the reference's definition (mel_processing.py:95-142, rebuilt in oracle/mel.py), exact-match rate of the ceil'd durations."""
+    from oracle import mel
+    batch, nw, nz, ref = par
+    model.enable_graphs(False)
+    model.set_generator_dtype(torch.float32)
+    if hp.use_transformer_flow:
+        model.set_flow_dtype(torch.float32)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    o, attn, y_mask, _ = model.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"],
+                                     noise_w=nw, noise_z=nz.to(dev), **KW)
+    torch.cuda.synchronize()
+    o = o.cpu()
+    wc = model.last_encode["w_ceil"].cpu().reshape(ref["w_ceil"].shape)
+    match = float((wc == ref["w_ceil"]).float().mean())
+    res = dict(config="BASELINE config 2's utterance (B=1, T=128, fp32, pinned durations), HIP path vs the CPU oracle, same injected noise",
+               w_ceil_match=match, frames=int(y_mask.sum().item()))
+    if o.shape == ref["o"].shape:
+        n = int(ref["y_lengths"][0]) * hp.total_upsample
+        d = (o[0, 0, :n] - ref["o"][0, 0, :n]).double()
+        res.update(wave_rms=float(d.pow(2).mean().sqrt()), wave_max_abs=float(d.abs().max()),
+                   signal_rms=float(ref["o"][0, 0, :n].double().pow(2).mean().sqrt()),
+                   mel_l1=float(mel.mel_l1(o[:, 0].numpy(), ref["o"][:, 0].numpy(), [n])),
+                   attn_equal=bool(torch.equal(attn.cpu(), ref["attn"])), bar="wave_rms <= 1e-3 (north_star)")
+    else:
+        res["error"] = f"shape mismatch {tuple(o.shape)} vs {tuple(ref['o'].shape)}"
+    return res
 
 
 def file_digest(name):
@@ -216,6 +277,32 @@ def roofline_block(prof, psteps, config=2):
                                alg_GBps=round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)) for r in prof])
 
 
+def upsampling_block(ups, psteps, config):
+    """HBM roofline of the Generator's five ConvTranspose1d launches (models.py:510-522, 545), each row = one launch site."""
+    tot_b = sum(r["bytes"] for r in ups)
+    tot_s = sum(r["total_ms"] for r in ups) * 1e-3
+    rows = []
+    for r in ups:
+        fam = r["name"].split("|")[1].split(" ")[0]
+        tr = pmc_traffic(fam, config)
+        rows.append(dict(site=r["name"], us_per_launch=round(r["total_ms"] * 1e3 / r["launches"], 2),
+                         alg_bytes_per_launch=round(r["bytes"] / r["launches"]), alg_GBps=round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1),
+                         frac_of_hbm_peak=round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         tflops=round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2),
+                         kernel_family_pmc_traffic_bytes_per_launch=tr.get("bytes_per_launch"),
+                         pmc_source=tr.get("source") or tr.get("note")))
+    narrow = [r for r in rows if "conv_cl_bf16<1x4>" in r["site"]]        # the one family that ONLY runs an upsampling launch
+    return dict(bound="hbm", achieved=round(tot_b / tot_s / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                frac=round(tot_b / tot_s / 1e9 / PEAK_HBM_GBPS, 4), launches_per_step=len(ups),
+                alg_bytes_per_step=round(tot_b / psteps), ms_per_step=round(tot_s * 1e3 / psteps, 4),
+                traffic=(narrow[0]["kernel_family_pmc_traffic_bytes_per_launch"] if narrow else None),
+                traffic_note="PMC bytes (FETCH x2 + WRITE) per launch of the last ConvTranspose1d's kernel family, the only family that runs "
+                             "nothing but an upsampling launch; the other rows share their kernel symbol with ResBlock launches, so their "
+                             "family averages are shown per row, not used here",
+                timing="HIP events around the ConvTranspose1d launches in a separate eager pass AFTER the timed region",
+                launches=rows)
+
+
 def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False):
     """Time `steps` steps of BASELINE config `num` on this rank; returns the result dict (rank-local times; the caller reduces)."""
     cfg = dict(CONFIGS[num])
@@ -258,29 +345,29 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     Ty = y_mask.shape[2]
     res = dict(config=num, B=B, T=T, Ty=Ty, gen_dtype=gen_dtype, flow_dtype=flow_dtype, graph=use_graph, dt=dt, steps=steps,
                audio_per_step=audio_per_step, lengths=lengths)
-    if rank != 0:
-        model.enable_graphs(False)
-        return res
+    if rank == 0:
+        # ---- PCIe-inclusive variant: inputs start in pinned HOST memory, the audio ends in pinned HOST memory.  The
+        # uploads land in the PERSISTENT device tensors the (static_io) graph reads in place, so a captured graph is replayed, not
+        # re-captured per step (a fresh upload per step has new addresses: ADVICE r2).
+        hbatch = {k: v.pin_memory() for k, v in batch.items()}
+        S = Ty * hp.total_upsample
+        host_o = torch.empty(B, 1, S, dtype=torch.float32, pin_memory=True)
+        n_io = max(3, min(steps, 10))
 
-    # ---- PCIe-inclusive variant: inputs start in pinned HOST memory, the audio ends in pinned HOST memory
-    hbatch = {k: v.pin_memory() for k, v in batch.items()}
-    S = Ty * hp.total_upsample
-    host_o = torch.empty(B, 1, S, dtype=torch.float32, pin_memory=True)
-    n_io = max(3, min(steps, 10))
+        def call_io():
+            for k, v in hbatch.items():
+                dbatch[k].copy_(v, non_blocking=True)
+            o = call()[0]
+            host_o.copy_(o, non_blocking=True)
 
-    def call_io():
-        b = {k: v.to(dev, non_blocking=True) for k, v in hbatch.items()}
-        o = call(b)[0]
-        host_o.copy_(o, non_blocking=True)
-
-    call_io()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(n_io):
         call_io()
-    torch.cuda.synchronize()
-    res["io_ms_per_step"] = (time.perf_counter() - t1) / n_io * 1e3
-    res["io_bytes_per_step"] = sum(v.numel() * v.element_size() for v in batch.values()) + host_o.numel() * 4
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_io):
+            call_io()
+        torch.cuda.synchronize()
+        res["io_ms_per_step"] = (time.perf_counter() - t1) / n_io * 1e3
+        res["io_bytes_per_step"] = sum(v.numel() * v.element_size() for v in batch.values()) + host_o.numel() * 4
 
     # ---- roofline leg: per-launch HIP events on the Generator's kernels, separate eager pass (events cannot be recorded inside a
     # captured graph, and inside the timed loop they cost ~10 us of bubble per event pair)
@@ -295,6 +382,19 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     prof = model.profile_report()
     model.profile(0)
     res["roofline"] = roofline_block(prof, psteps, num) if prof else None
+    # BASELINE config 5: "HBM-bandwidth roofline run on Generator upsampling" — the ConvTranspose1d launches alone (profile mode 4),
+    # algorithmic bytes (inputs read once, output written once, weights once) / HIP-event time against the 8 TB/s HBM peak
+    try:
+        model.profile(4)
+        for _ in range(psteps):
+            call()
+        torch.cuda.synchronize()
+        ups = model.profile_report()
+        model.profile(0)
+        res["upsampling_roofline"] = upsampling_block(ups, psteps, num) if ups else None
+    except Exception as e:
+        model.profile(0)
+        res["upsampling_roofline"] = dict(error=repr(e)[:200])
     if full_profile:
         model.profile(3)               # one row per launch site and shape
         for _ in range(3):
@@ -487,11 +587,18 @@ def bench_bert(dev, with_cpu, enc=None, sd=None):
     except Exception as e:
         res["deberta_error"] = repr(e)[:300]
     if with_cpu:
-        t1 = time.perf_counter()
-        ref = BO.hidden_state(sd, cfg, ids.cpu(), layers)
-        cpu_ms = (time.perf_counter() - t1) * 1e3
-        res["cpu_baseline"] = dict(value=round(1e3 / cpu_ms, 3), unit="sentences/sec", ms_per_sentence=round(cpu_ms, 1), cores=torch.get_num_threads(),
-                                   kind="port", sample="1 run of the same sentence, torch CPU fp32, oracle restatement of BertModel")
+        nthreads = min(usable_cores(), 64)           # torch's default team is the HOST's core count even inside a CPU quota
+        torch.set_num_threads(nthreads)
+        ref = BO.hidden_state(sd, cfg, ids.cpu(), layers)                       # warm-up
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ref = BO.hidden_state(sd, cfg, ids.cpu(), layers)
+            ts.append((time.perf_counter() - t1) * 1e3)
+        cpu_ms = sorted(ts)[1]
+        res["cpu_baseline"] = dict(value=round(1e3 / cpu_ms, 3), unit="sentences/sec", ms_per_sentence=round(cpu_ms, 1), cores=nthreads,
+                                   kind="port", sample="median of 3 runs of the same sentence after 1 warm-up, torch CPU fp32, oracle "
+                                                       "restatement of transformers' BertModel (the reference runs the HF model on torch)")
         res["max_abs_err_vs_oracle"] = float((out.cpu().transpose(1, 2) - ref).abs().max())
     return res
 
@@ -523,6 +630,13 @@ def summary(res, hp, world, dt=None, audio=None):
                                      note="inputs copied from pinned host memory and the audio copied back to pinned host memory every step")
     if res.get("roofline") is not None:
         out["roofline"] = res["roofline"]
+    if res.get("upsampling_roofline") is not None:
+        if res["config"] == 5 and "error" not in res["upsampling_roofline"]:
+            # BASELINE config 5 names its roofline: HBM bandwidth on the Generator upsampling.  The dominant-kernel (MFMA) block stays beside it.
+            out["roofline_dominant_kernel"] = out.get("roofline")
+            out["roofline"] = res["upsampling_roofline"]
+        else:
+            out["upsampling_roofline"] = res["upsampling_roofline"]
     return out
 
 
@@ -533,35 +647,92 @@ def dtype_label(res):
     return f"gen={gd},flow={fd}"                 # what each part computes in (fp32 accumulate everywhere)
 
 
-def main():
-    args = parse()
+class Seam:
+    """Everything in the N-rank driver that touches a GPU, so that a CPU test can drive the SAME launcher / reduction code with
+    gloo and world size 2 (tests/test_bench_multi_cpu.py passes --seam tests.bench_seam_cpu, whose `seam` object replaces this one)."""
+    backend = "nccl"                                   # RCCL
+
+    def device(self, local):
+        assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback for the product path"
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def init_pg(self, dev, rank, world):
+        import torch.distributed as dist
+        dist.init_process_group(self.backend, device_id=dev, rank=rank, world_size=world)
+
+    def load_model(self, hp, rank, dev):
+        """rank 0 folds/packs the seeded synthetic checkpoint, every other rank receives the blob over RCCL"""
+        model = models.from_hparams(hp)
+        sd = None
+        if rank == 0:
+            sd = synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5)
+            model.load_state_dict(sd, strict=False)
+        t_bcast = sharding.distribute_weights(model, dev, src=0)
+        return model, sd, t_bcast
+
+    def run_config(self, *a, **k):
+        return run_config(*a, **k)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def device_name(self, dev):
+        return torch.cuda.get_device_name(dev)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawned_rank(local, argv, port, world):
+    """One rank of a self-launched N>1 run (torch.multiprocessing.spawn entry point)."""
+    os.environ.update(RANK=str(local), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BV2_BENCH_SELF_LAUNCHED="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank_main(parse(argv))
+
+
+def main(argv=None):
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us (`python bench.py --gpus N`): spawn one process per GPU ourselves, rendezvous on 127.0.0.1
+        import torch.multiprocessing as mp
+        port = args.master_port or _free_port()
+        log(f"self-launching {args.gpus} ranks (127.0.0.1:{port})")
+        mp.spawn(_spawned_rank, args=(list(sys.argv[1:] if argv is None else argv), port, args.gpus), nprocs=args.gpus, join=True)
+        return
+    rank_main(args)
+
+
+def rank_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback for the product path"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or with no launcher at all")
+    seam = Seam()
+    if args.seam:
+        import importlib
+        seam = importlib.import_module(args.seam).seam
+    dev = seam.device(local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # RCCL
+        seam.init_pg(dev, rank, world)
 
     hp = H.default_v23(use_transformer_flow=not args.residual_flow)
     primary = args.config if args.config is not None else (2 if world == 1 else 4)
     overrides = dict(batch=args.batch, symbols=args.symbols, dtype=args.dtype, flow=args.flow_dtype, graph=args.graph)
-    if args.residual_flow:
-        overrides["flow"] = "f32"                     # the WN flow has no fp16 form (bv2_set_flow_dtype returns -2)
+    if args.residual_flow and overrides["flow"] is None:
+        overrides["flow"] = "f32"                     # --flow-dtype f16 selects the fp16 WN convolutions
 
-    # ---- weights: rank 0 folds/packs the seeded synthetic checkpoint, every other rank receives the blob over RCCL
-    model = models.from_hparams(hp)
-    sd = None
-    if rank == 0:
-        sd = synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5)
-        model.load_state_dict(sd, strict=False)
     log(f"rank {rank}/{world}: packing / distributing weights")
-    t_bcast = sharding.distribute_weights(model, dev, src=0)
+    model, sd, t_bcast = seam.load_model(hp, rank, dev)
     log("weights attached")
     if args.variants is not None:
         import ctypes
@@ -576,17 +747,26 @@ def main():
         model.set_option(key, int(val))
         log(f"option {key} = {val}")
 
-    res = run_config(primary, model, hp, dev, rank, world, args.steps, args.warmup, overrides, args.full_profile)
-    log(f"config {primary}: timed region {res['dt']:.3f}s for {args.steps} steps")
+    res = seam.run_config(primary, model, hp, dev, rank, world, args.steps, args.warmup, overrides, args.full_profile)
+    log(f"rank {rank}: config {primary}: timed region {res['dt']:.3f}s for {args.steps} steps")
     dt, audio = res["dt"], res["audio_per_step"] * args.steps
+    per_rank = None
     if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        # value = audio of ALL ranks / the slowest rank's time (max over ranks); each rank also reports its own line
+        mine = dict(rank=rank, local_rank=local, device=seam.device_name(dev), ms_per_step=round(res["dt"] / args.steps * 1e3, 4),
+                    audio_s_per_step=round(res["audio_per_step"], 4), utterances=res["B"], symbols_total=sum(res["lengths"]),
+                    weight_broadcast_ms=round(t_bcast * 1e3, 3),
+                    roofline=None if not res.get("roofline") else {k: res["roofline"][k] for k in
+                                                                    ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")
+                                                                    if k in res["roofline"]})
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        dt = max(r["ms_per_step"] for r in per_rank) * args.steps * 1e-3
+        audio = sum(r["audio_s_per_step"] for r in per_rank) * args.steps
+        # the same two numbers through a device collective (the contract's MAX over ranks), as a cross-check of the object gather
+        tmax = torch.tensor([res["dt"]], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        atot = torch.tensor([audio], dtype=torch.float64, device=dev)
-        dist.all_reduce(atot, op=dist.ReduceOp.SUM)
-        audio = float(atot.item())
 
     secondary = {}
     if world == 1 and rank == 0 and not args.no_secondary and args.config is None and not args.residual_flow:
@@ -597,6 +777,21 @@ def main():
                 log(f"secondary config {num}: {secondary[f'config{num}']['value']} audio-s/s ({secondary[f'config{num}']['ms_per_step']} ms/step)")
             except Exception as e:          # a secondary workload must never take the primary line down
                 secondary[f"config{num}"] = dict(error=repr(e)[:300])
+
+        # north_star names the ResidualCouplingBlock / WN flow explicitly (models.py:403-445, modules.py:185-210): the same utterances
+        # with use_transformer_flow=false — config 2 in fp32, config 3's batch with the bf16 Generator (+ the fp16 WN convs when built)
+        try:
+            hp_wn = H.default_v23(use_transformer_flow=False)
+            m_wn = models.from_hparams(hp_wn)
+            m_wn.load_state_dict(synth.synthetic_state_dict(hp_wn, seed=0, pin_durations=2.5), strict=False)
+            sharding.distribute_weights(m_wn, dev, src=0)
+            for num, key, ov in ((2, "config2_residual_flow", dict(flow="f32")), (3, "config3_residual_flow", dict(flow=WN_FLOW_B32))):
+                r = run_config(num, m_wn, hp_wn, dev, 0, 1, max(5, min(args.steps, 20 if num == 2 else 10)), 3, ov)
+                secondary[key] = summary(r, hp_wn, 1)
+                log(f"secondary {key}: {secondary[key]['value']} audio-s/s ({secondary[key]['ms_per_step']} ms/step)")
+            del m_wn
+        except Exception as e:
+            secondary["residual_flow_error"] = repr(e)[:300]
 
         for ns in sorted({args.streams, 4}):
             key = f"config2_{ns}_requests_in_flight"
@@ -625,10 +820,16 @@ def main():
             secondary["bert_zh_features"] = dict(error=repr(e)[:300])
 
     if rank == 0:
-        cpu = None
+        cpu, parity = None, None
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle port)")
-            cpu = cpu_baseline(hp, sd, args.cpu_iters)
+            cpu, par = cpu_baseline(hp, sd, args.cpu_iters)
+            if primary == 2 and not any(v is not None for v in overrides.values()):
+                try:
+                    parity = parity_block(model, hp, dev, par)
+                    log(f"parity (config 2's utterance vs the oracle): {parity}")
+                except Exception as e:
+                    parity = dict(error=repr(e)[:300])
         s = summary(res, hp, world, dt, audio)
         line = dict(
             metric="audio-seconds/sec (44.1 kHz), SynthesizerTrn.infer(), 128-phoneme utterance", value=s["value"],
@@ -640,14 +841,22 @@ def main():
                         pcie_inclusive=s.get("pcie_inclusive"),
                         note=("N=1 measures BASELINE config 2 (the metric's config); N>1 measures config 4 per GPU — the N=1 figure of "
                               "that same workload is secondary.config4 of the N=1 line" if args.config is None else None)),
-            roofline=s.get("roofline"), cpu_baseline=cpu)
+            roofline=s.get("roofline"), cpu_baseline=cpu, parity=parity)
+        if s.get("upsampling_roofline") is not None:
+            line["upsampling_roofline"] = s["upsampling_roofline"]
+        if per_rank is not None:
+            line["ranks_seen"] = len([r for r in per_rank if r is not None])
+            line["launcher"] = "self (torch.multiprocessing.spawn)" if os.environ.get("BV2_BENCH_SELF_LAUNCHED") else "torch.distributed.run"
+            line["per_rank"] = per_rank
+            line["weight_broadcast_ms"] = round(max(r["weight_broadcast_ms"] for r in per_rank), 3)
+            line["collectives_in_timed_region"] = "none on the data path (two barriers bracket it); the weight blob is broadcast once, before"
         if secondary:
             line["secondary"] = secondary
         if res.get("full"):
             line["kernel_families_untimed_pass"] = res["full"]
         print(json.dumps(line), flush=True)
     if world > 1:
-        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

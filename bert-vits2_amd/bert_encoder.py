@@ -184,10 +184,13 @@ class BertEncoder:
         B, S = ids.shape
         tt = None if token_type_ids is None else token_type_ids.to(dev, torch.int64).contiguous()
         if lengths is None and attention_mask is not None:
-            am = attention_mask.to(dev)
+            # the tokenizer's mask is a HOST tensor: lengths and the prefix check are computed there, before the upload — a device
+            # tensor is taken on trust (checking it would be a device-to-host sync per sentence in front of infer())
+            am = attention_mask
             lengths = am.long().sum(1)
-            if not bool((am.long() == (torch.arange(S, device=dev)[None, :] < lengths[:, None]).long()).all()):
-                raise ValueError("attention_mask must be a prefix mask (right padding)")
+            if am.device.type == "cpu":
+                if not bool((am.long() == (torch.arange(S)[None, :] < lengths[:, None]).long()).all()):
+                    raise ValueError("attention_mask must be a prefix mask (right padding)")
         ln = None if lengths is None else lengths.to(dev, torch.int64).contiguous()
         out = torch.empty(B, self.hidden_size, S, dtype=torch.float32, device=dev)
         need = int(self._lib.bv2_bert_workspace_bytes(self._h, B, S))

@@ -11,8 +11,10 @@ Python loop (:48-58), transposes, and ``infer.get_text`` uploads the ``[1024, T]
 * ``style_text`` mixing (chinese_bert.py:38-47, 52-56) is applied at word level on the device — mixing and repeating commute.
 
 The BERT encoder itself: ``bert_encoder.BertEncoder`` runs the Chinese extractor (a HuggingFace ``BertModel``) with libbv2's own
-kernels and hands back ``[1024, S]`` directly (``get_bert_feature`` below takes it as ``model``); any HF model object works as
-well (PyTorch-ROCm library kernels) — the Japanese / English extractors are DeBERTa-v2 models and go that way.
+kernels and hands back ``[1024, S]`` directly (``get_bert_feature`` below takes it as ``model``) — with ``model_type="deberta-v2"``
+the same class runs the reference's Japanese / English extractors (DeBERTa-v2 / v3 large); any HF model object works as well
+(PyTorch-ROCm library kernels).  ``len(word2ph) == S`` is checked on the host, so every index is < S by construction; the device
+gather additionally clamps to the feature's own column count.
 """
 from __future__ import annotations
 

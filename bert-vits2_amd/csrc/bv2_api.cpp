@@ -416,7 +416,7 @@ int bv2_profile_enable(bv2_handle* h, int on) {
     }
   }
   h->prof_on = on != 0;
-  h->prof_mode = (on == 2 || on == 3) ? on : 1;
+  h->prof_mode = (on >= 2 && on <= 4) ? on : 1;
   return 0;
   BV2_CATCH(h)
 }

@@ -191,7 +191,22 @@ int bv2_bert_pack_tensor(bv2_bert* h, void* host_blob, int64_t blob_bytes, const
     else if (k == "embeddings.token_type_embeddings.weight") { if (h->type < 0 || !is2(c.type_vocab_size, C)) return bad(); copy(h->type, (int64_t)c.type_vocab_size * C); }
     else if (k == "embeddings.LayerNorm.weight") { if (!is1(C)) return bad(); copy(h->emb_g, C); }
     else if (k == "embeddings.LayerNorm.bias") { if (!is1(C)) return bad(); copy(h->emb_b, C); }
-    else if (k == "encoder.relative_index") { if (!is1(2 * (int64_t)c.max_position - 1)) return bad(); copy(h->tab, 2 * (int64_t)c.max_position - 1); }
+    else if (k == "encoder.relative_index") {
+      const int64_t n = 2 * (int64_t)c.max_position - 1;
+      if (!is1(n)) return bad();
+      // kernels/deberta_attn.hip stages at most 63 consecutive table rows per 32x32 tile pair: t(r) must be monotone with slope <= 1
+      // (true for every log-bucket table with (max_relative_positions-1)/(position_buckets/2) >= e, i.e. the reference's models;
+      // the device-side clamp is only a backstop and would silently return wrong scores for a steeper table)
+      for (int64_t i = 1; i < n; ++i) {
+        const float d = data[i] - data[i - 1];
+        if (!(d >= 0.f && d <= 1.f)) {
+          h->err = "encoder.relative_index: the relative-position bucket table must be non-decreasing with steps <= 1 "
+                   "(position_buckets too large for max_relative_positions); unsupported by the disentangled-attention kernel";
+          return -2;
+        }
+      }
+      copy(h->tab, n);
+    }
     else if (k == "encoder.conv.conv.weight") {
       const int kk = c.conv_kernel_size;
       if (!(ndim == 3 && shape[0] == C && shape[1] == C && shape[2] == kk)) return bad();

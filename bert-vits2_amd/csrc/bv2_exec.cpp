@@ -44,6 +44,7 @@ struct Ctx {
     cur_tag = tag;
     if (!h->prof_on || h->prof_used >= h->prof_pool.size()) return -1;
     if (h->prof_mode == 2 && std::strncmp(tag, "dec.", 4) != 0) return -1;   // Generator kernels only
+    if (h->prof_mode == 4 && std::strcmp(tag, "dec.ups") != 0) return -1;     // the Generator's ConvTranspose1d launches only
     const int i = (int)h->prof_used++;
     (void)hipEventRecord(h->prof_pool[i].e0, s);
     return i;
@@ -52,7 +53,7 @@ struct Ctx {
     if (i < 0) return;
     (void)hipEventRecord(h->prof_pool[i].e1, s);
     std::string key = name;
-    if (h->prof_mode == 3) key = std::string(cur_tag) + "|" + name + cur_shape;   // one row per launch site and shape
+    if (h->prof_mode >= 3) key = std::string(cur_tag) + "|" + name + cur_shape;   // one row per launch site and shape
     int fam = -1;
     for (size_t k = 0; k < h->prof_names.size(); ++k)
       if (h->prof_names[k] == key) fam = (int)k;
@@ -91,7 +92,7 @@ struct Ctx {
     if (max_split > 1 && conv_use_splitk(L)) L.ksplit = conv_pick_ksplit(L, max_split);
     const char* vn = "conv1d_mfma";
     const int pi = prof_begin(tag);
-    if (pi >= 0 && h->prof_mode == 3) {
+    if (pi >= 0 && h->prof_mode >= 3) {
       const ConvProb& q = L.p[0];
       cur_shape = " n" + std::to_string(L.nprob) + " " + std::to_string(q.cin) + ">" + std::to_string(q.cout) + " k" +
                   std::to_string(q.k) + " L" + std::to_string(L.L) + " B" + std::to_string(L.B) + " s" + std::to_string(L.ksplit);
@@ -125,7 +126,7 @@ struct Ctx {
     hl.p = p; hl.B = B; hl.L = L;
     const char* vn = "conv_f16";
     const int pi = prof_begin(tag);
-    if (pi >= 0 && h->prof_mode == 3)
+    if (pi >= 0 && h->prof_mode >= 3)
       cur_shape = " n1 " + std::to_string(p.cin) + ">" + std::to_string(p.cout) + " k" + std::to_string(p.k) + " L" +
                   std::to_string(L) + " B" + std::to_string(B);
     const int r = launch_conv_f16(s, hl, &vn);
@@ -444,7 +445,10 @@ static void enc_p_core(Ctx& c, PlanA& P, const int64_t* x, const int64_t* tone, 
     e.n_vocab = cf.n_vocab; e.n_tones = cf.n_tones; e.n_langs = cf.n_languages;
     e.bsum = P.bsum; e.nslab = bert_slabs; e.slab_stride = P.slab;
     e.mask = mask; e.out = out_x; e.scale = (float)std::sqrt((double)H); e.B = B; e.C = H; e.T = T;
-    for (int i = 0; i < 3; ++i) e.idx[i] = bert_index ? bert_index[i] : nullptr;
+    for (int i = 0; i < 3; ++i) {
+      e.idx[i] = bert_index ? bert_index[i] : nullptr;
+      e.cols[i] = (bert_index && bert_index[i] && bert_cols) ? bert_cols[i] : 0;
+    }
     c.chk(launch_embed(c.s, e), "embed");
   }
   c.tap("enc.x0", out_x, (int64_t)B * H * T);
@@ -779,7 +783,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
         }
         if (!c.rc) {
           const int pi = c.prof_begin("dec.resblock.fused");
-          if (pi >= 0 && c.h->prof_mode == 3)
+          if (pi >= 0 && c.h->prof_mode >= 3)
             c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
                           std::to_string(Lo) + " B" + std::to_string(B);
           const int r = launch_resblock_fused(c.s, F);
@@ -856,7 +860,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     if (c.rc) return;
     const char* vn = "conv_cl_bf16";
     const int pi = c.prof_begin(tag);
-    if (pi >= 0 && c.h->prof_mode == 3) {
+    if (pi >= 0 && c.h->prof_mode >= 3) {
       const ClProb& q = cl.p[0];
       c.cur_shape = " n" + std::to_string(cl.nprob) + " " + std::to_string(q.cin) + ">" + std::to_string(q.cout) + " k" +
                     std::to_string(q.k) + " L" + std::to_string(cl.L) + " B" + std::to_string(cl.B);
@@ -926,7 +930,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
       }
       if (!c.rc) {
         const int pi = c.prof_begin("dec.resblock.whole");
-        if (pi >= 0 && c.h->prof_mode == 3)
+        if (pi >= 0 && c.h->prof_mode >= 3)
           c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
                         std::to_string(Lo) + " B" + std::to_string(B);
         const int r = launch_resblock_cl_bf16(c.s, F);

@@ -132,7 +132,7 @@ struct bv2_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling
   bool prof_on = false;
-  int prof_mode = 1;                 // 1: every MFMA kernel launch, 2: Generator (dec.*) launches only
+  int prof_mode = 1;                 // 1: every MFMA kernel launch, 2: Generator (dec.*) launches only, 3: per site, 4: dec.ups per site
   std::vector<bv2::ProfileRec> prof_pool;
   size_t prof_used = 0;
   std::vector<std::string> prof_names;

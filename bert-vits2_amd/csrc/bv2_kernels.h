@@ -334,6 +334,7 @@ struct EmbedArgs {
   // word-level features: slab s belongs to feature s / (nslab/3); with idx[f] set, symbol t reads column idx[f][b*T + t] of that
   // feature's slabs (the word2ph repeat of text/chinese_bert.py:48-58 as a gather); null = column t
   const int32_t* idx[3];
+  int cols[3];                                         // columns (words) of feature f when idx[f] is set; the gather clamps to them
 };
 int launch_embed(hipStream_t stream, const EmbedArgs& a);
 

@@ -252,8 +252,11 @@ __global__ void embed_kernel(const EmbedArgs A) {
   for (int f = 0; f < 3; ++f) {
     int tc = t;
     if (A.idx[f]) {
+      // word-level hand-over: clamp to the feature's own column count (columns >= cols of the projected slab hold the conv's
+      // bias-only output: an out-of-range word index must not silently read them)
+      const int nc = A.cols[f] > 0 && A.cols[f] < A.T ? A.cols[f] : A.T;
       tc = A.idx[f][bt];
-      tc = tc < 0 ? 0 : (tc >= A.T ? A.T - 1 : tc);
+      tc = tc < 0 ? 0 : (tc >= nc ? nc - 1 : tc);
     }
     const int64_t offf = ((int64_t)b * A.C + c) * A.T + tc;
     for (int sl = f * per; sl < (f + 1) * per; ++sl) bs += A.bsum[(int64_t)sl * A.slab_stride + offf];

@@ -96,6 +96,7 @@ class SynthesizerTrn(nn.Module):
         self._graphs_static = False
         self._graphs: Dict[tuple, dict] = {}
         self._cap_stream = None
+        self._options: Dict[str, int] = {}
 
     # ------------------------------------------------------------------ parameter tree
     def _register(self, key: str, value: torch.Tensor) -> None:
@@ -240,8 +241,8 @@ class SynthesizerTrn(nn.Module):
         outputs are returned as fresh tensors, so the call behaves exactly like the eager one.
 
         ``static_io=True`` (serving loops): no staging copies — a graph is recorded reading the caller's input tensors IN PLACE
-        (it is re-recorded when a tensor with another address shows up; up to 16 recordings are cached) and the returned tensors
-        are the graph's own output buffers, valid until the next call with the same shapes.  Only the two noise draws still move:
+        (when a tensor with another address shows up the shape's graph is re-recorded ONCE with input buffers of its own and the
+        inputs are copied in from then on; up to 16 shapes are cached) and the returned tensors are the graph's own output buffers, valid until the next call with the same shapes.  Only the two noise draws still move:
         the CPU draw of models.py:248-251 is uploaded into the graph's buffer, the device draw of :1071 is made in place."""
         self._graphs_on = bool(on)
         self._graphs_static = bool(on and static_io)
@@ -263,13 +264,24 @@ class SynthesizerTrn(nn.Module):
         self._check(fn(self._handle, C.c_void_p(self._cap_stream.cuda_stream), *args, C.byref(g)), fn.__name__)
         return g
 
-    def _graph_entry(self, key, build):
+    def _graph_entry(self, key, build, ptrs=()):
+        """Cached graph for ``key`` (shapes + scalars).  ``ptrs``: addresses of the tensors a static_io graph reads in place.  A
+        graph recorded on other addresses is NOT re-recorded per call: the first pointer miss rebuilds the entry ONCE with input
+        buffers the graph owns (``build(own_inputs=True)``) and from then on inputs are copied in — a caller that re-materialises
+        its inputs every call (CPU tensors, the ``w_ceil=`` override, fresh uploads) costs one copy per call, not one capture."""
         ent = self._graphs.get(key)
+        if ent is not None and not ent["own_inputs"] and ent["ptrs"] != ptrs:
+            self._lib.bv2_graph_destroy(self._graphs.pop(key)["graph"])
+            ent = None
+            own = True
+        else:
+            own = not self._graphs_static
         if ent is None:
             if len(self._graphs) >= 16:                   # bounded cache: drop the oldest shape
                 old = next(iter(self._graphs))
                 self._lib.bv2_graph_destroy(self._graphs.pop(old)["graph"])
-            ent = build()
+            ent = build(own)
+            ent["own_inputs"], ent["ptrs"] = own, ptrs
             self._graphs[key] = ent
         return ent
 
@@ -334,9 +346,9 @@ class SynthesizerTrn(nn.Module):
                     ins[f"bert_index{i}"] = bidx[i]
 
             static = self._graphs_static
-            staged = ("noise_w",) if static else tuple(ins)     # static_io: everything but the noise is read in place
 
-            def build():
+            def build(own_inputs):
+                staged = tuple(ins) if own_inputs else ("noise_w",)     # static_io: everything but the noise is read in place
                 sin = {k: (torch.empty_like(v) if k in staged else v) for k, v in ins.items()}
                 sout = mk_out()
                 ein = L.EncodeIn(B, T, *[_ptr(sin[k]) for k in ("x", "x_lengths", "sid", "tone", "language", "bert", "ja_bert",
@@ -347,11 +359,12 @@ class SynthesizerTrn(nn.Module):
                 with torch.cuda.device(dev):
                     g = self._capture(self._lib.bv2_graph_capture_encode, C.byref(ein), C.byref(eout),
                                       C.c_void_p(ws.data_ptr()), ws.numel())
-                return dict(graph=g, sin=sin, sout=sout)
+                return dict(graph=g, sin=sin, sout=sout, staged=staged)
 
-            ptrs = tuple(ins[k].data_ptr() for k in ins if k not in staged)
-            ent = self._graph_entry(("A", B, T, float(noise_scale_w), float(sdp_ratio), float(length_scale), ptrs, tuple(cols)), build)
-            for k in staged:
+            ptrs = tuple(ins[k].data_ptr() for k in ins if k != "noise_w") if static else ()
+            ent = self._graph_entry(("A", B, T, float(noise_scale_w), float(sdp_ratio), float(length_scale), tuple(cols),
+                                     tuple(sorted(ins))), build, ptrs)
+            for k in ent["staged"]:
                 ent["sin"][k].copy_(ins[k], non_blocking=True)
             with torch.cuda.device(dev):
                 if self._lib.bv2_graph_launch(ent["graph"], C.c_void_p(torch.cuda.current_stream().cuda_stream)):
@@ -396,8 +409,8 @@ class SynthesizerTrn(nn.Module):
 
             static = self._graphs_static
 
-            def build():
-                sin = {k: (enc[k] if static else torch.empty_like(enc[k])) for k in ikeys}
+            def build(own_inputs):
+                sin = {k: (torch.empty_like(enc[k]) if own_inputs else enc[k]) for k in ikeys}
                 # the reference's strides for the prior noise (draw_noise_z): an in-place normal_() on it IS randn_like(m_p)
                 sin["noise_z"] = torch.empty(B, Ty, Ci, dtype=torch.float32, device=dev).transpose(1, 2)
                 sout = mk_out()
@@ -411,9 +424,9 @@ class SynthesizerTrn(nn.Module):
                 return dict(graph=g, sin=sin, sout=sout)
 
             ptrs = tuple(enc[k].data_ptr() for k in ikeys) if static else ()
-            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale), bool(exact_lengths), ptrs),
-                                    build)
-            if not static:
+            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale), bool(exact_lengths)),
+                                    build, ptrs)
+            if ent["own_inputs"]:
                 for k in ikeys:
                     ent["sin"][k].copy_(enc[k])
             if draw_z:
@@ -580,6 +593,7 @@ class SynthesizerTrn(nn.Module):
         """Kernel-selection switches of ``bv2_set_option`` ("fused_resblock", "fused_dds"); tests only."""
         self._ensure_handle()
         self._check(self._lib.bv2_set_option(self._handle, key.encode(), int(value)), "bv2_set_option")
+        self._options[key] = int(value)
         self._drop_graphs()
 
     # ------------------------------------------------------------------ measurement

@@ -105,19 +105,26 @@ def replicas(model, n: int) -> list:
     if model._blob is None:
         model.repack()
     reps = getattr(model, "_serving_replicas", None)
-    if reps is None:
+    if reps is None or getattr(model, "_serving_replicas_device", None) != model.device:
+        # the cache belongs to ONE device: after model.to(another GPU) the old streams (and the replicas' handles) are on the wrong one
         reps = [(model, torch.cuda.Stream(model.device))]
     while len(reps) < n:
-        m = _models.from_hparams(model.hp)
+        with torch.device("meta"):                       # a replica only holds a handle: no CPU parameter set is materialised for it
+            m = _models.from_hparams(model.hp)
         m.attach_blob(model._blob)
         reps.append((m, torch.cuda.Stream(model.device)))
-    for m, _ in reps[1:]:                                # replicas follow the weights and precision switches of the model they serve
+    for m, _ in reps[1:]:                                # replicas follow the weights, precision switches and options of the model they serve
         if m._blob is not model._blob:
             m.attach_blob(model._blob)
         m.set_generator_dtype(model.generator_dtype)
         if model.hp.use_transformer_flow:
             m.set_flow_dtype(model.flow_dtype)
-    model._serving_replicas = reps
+        for key, val in getattr(model, "_options", {}).items():
+            if getattr(m, "_options", {}).get(key) != val:
+                m.set_option(key, val)
+        if (m._graphs_on, m._graphs_static) != (model._graphs_on, model._graphs_static):
+            m.enable_graphs(model._graphs_on, static_io=model._graphs_static)
+    model._serving_replicas, model._serving_replicas_device = reps, model.device
     return reps[:n]
 
 

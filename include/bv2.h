@@ -269,7 +269,8 @@ typedef struct bv2_profile_row {
   double bytes;           /* algorithmic bytes (inputs read once + outputs written once + weights) */
 } bv2_profile_row;
 int bv2_profile_enable(bv2_handle* h, int on);          /* 0 off, 1 every MFMA kernel launch, 2 Generator launches only,
-                                                            3 every MFMA launch with one row per launch site and shape */
+                                                            3 every MFMA launch with one row per launch site and shape,
+                                                            4 the Generator's ConvTranspose1d ("dec.ups") launches only, one row each */
 int bv2_profile_reset(bv2_handle* h);
 /* Synchronises the recorded events and aggregates them; returns the number of rows written (<= max_rows). */
 int bv2_profile_report(bv2_handle* h, bv2_profile_row* rows, int max_rows);

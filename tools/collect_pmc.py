@@ -10,6 +10,8 @@ sys/hip/hsa tracing next to --pmc):
 rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (GUI_ACTIVE / duration = 15-18 "GHz" for the long kernels), so
 kernel cycles = GUI_ACTIVE / 8 and the effective clock = that / duration (1.9 GHz under bf16 MFMA load, 2.3 GHz under fp32
 MFMA — the DVFS behaviour MI355X_MICROARCH.md describes).
+Short launches (< 30 us, or an implied clock above nominal) do not keep all XCDs busy, GUI_ACTIVE/8 under-counts their cycles, and
+their mfma_util is computed from the dispatch duration at the nominal 2.4 GHz instead (a lower bound; `mfma_util_basis` says which).
 Derived per family:  mfma_util = MFMA_BUSY / (GUI_ACTIVE/8 * 4 SIMDs * 256 CUs)  — cross-check against the HIP-event
 numbers: conv1d_mfma<64x64> 0.525 here vs 82 TF / 157.3 TF = 0.52 from bench.py;  hbm_GBps = (2*FETCH + WRITE) / duration,
 duration from the same trace (End - Start of the dispatch).
@@ -23,6 +25,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from collect_traffic import family  # noqa: E402
 
 N_SIMD = 4 * 256
+NOMINAL_GHZ = 2.4          # MI355X_MICROARCH.md: peak engine clock
+SHORT_US = 30.0            # below this a dispatch does not keep all 8 XCDs busy for its whole life
 
 
 def one_pass(counters, extra_args):
@@ -73,7 +77,22 @@ def main():
         if gui:
             row["mfma_busy_cycles_per_launch"] = t1[f]["SQ_VALU_MFMA_BUSY_CYCLES"] / max(n1[f], 1)
             row["gui_active_cycles_per_launch"] = gui / max(n1[f], 1)
-            row["mfma_util"] = round(t1[f]["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * N_SIMD), 4)
+            util_gui = t1[f]["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * N_SIMD)
+            # GRBM_GUI_ACTIVE / 8 is the kernel's cycle count only while all 8 XCDs are busy for the whole dispatch.  For short launches
+            # (a few workgroups, XCDs idle most of the time) it under-counts — "effective clocks" of 3-5 GHz came out of it.
+            # Those rows get the duration-based figure instead: busy cycles / (dispatch duration x 2.4 GHz nominal x SIMDs), a LOWER bound
+            # of the utilisation (the real clock is <= nominal).
+            secs1 = d1[f] / max(n1[f], 1) if d1.get(f) else None
+            util_dur = (t1[f]["SQ_VALU_MFMA_BUSY_CYCLES"] / max(n1[f], 1)) / (secs1 * NOMINAL_GHZ * 1e9 * N_SIMD) if secs1 else None
+            clock = gui / 8.0 / max(n1[f], 1) / secs1 / 1e9 if secs1 else None
+            row["avg_us_in_mfma_pass"] = round(secs1 * 1e6, 2) if secs1 else None
+            row["mfma_util_by_duration_at_nominal_clock"] = None if util_dur is None else round(util_dur, 4)
+            if secs1 is not None and (secs1 < SHORT_US * 1e-6 or (clock is not None and clock > NOMINAL_GHZ * 1.05)):
+                row["mfma_util"] = round(util_dur, 4)
+                row["mfma_util_basis"] = f"duration x {NOMINAL_GHZ} GHz (GUI_ACTIVE/8 is not kernel cycles for a launch this short: implied clock {clock:.2f} GHz)"
+            else:
+                row["mfma_util"] = round(util_gui, 4)
+                row["mfma_util_basis"] = "GRBM_GUI_ACTIVE / 8"
         if n2.get(f) and n3.get(f):
             fb = 2 * t2[f]["FETCH_SIZE"] * 1024 / n2[f]
             wb = t3[f]["WRITE_SIZE"] * 1024 / n3[f]
@@ -83,7 +102,7 @@ def main():
             if secs:
                 row["avg_us_in_pmc_pass"] = round(secs * 1e6, 2)
                 row["hbm_GBps"] = round((fb + wb) / secs / 1e9, 1)
-                if gui:
+                if gui and row.get("mfma_util_basis") == "GRBM_GUI_ACTIVE / 8":
                     row["effective_clock_GHz"] = round(gui / 8.0 / max(n1[f], 1) / secs / 1e9, 2)
         res["kernels"][f] = row
     json.dump(res, open(out, "w"), indent=1)
