@@ -91,12 +91,23 @@ def test_static_io_replay_reads_inputs_in_place_and_matches_eager():
     m.enable_graphs(False)
     torch.manual_seed(11)
     assert torch.equal(m.infer(*args, **kw)[0], o3) and not torch.equal(o3, e_o)
-    # ... and a tensor at ANOTHER address triggers a new recording instead of reading stale memory
+    # ... and a tensor at ANOTHER address never reads stale memory: the shape's graph is re-recorded ONCE with input buffers of its
+    # own (inputs copied in from then on), so a caller that re-materialises its inputs every call does not re-capture every call
     m.enable_graphs(True, static_io=True)
     torch.manual_seed(11)
     m.infer(*args, **kw)
     n1 = len(m._graphs)
+    assert all(not e["own_inputs"] for e in m._graphs.values())
     args2 = [a.clone() for a in args]
     torch.manual_seed(11)
-    o4 = m.infer(*args2, **kw)[0]
-    assert len(m._graphs) > n1 and torch.equal(o4, o3)
+    o4 = m.infer(*args2, **kw)[0].clone()
+    assert len(m._graphs) == n1 and torch.equal(o4, o3)
+    entry_a = next(e for k, e in m._graphs.items() if k[0] == "A")
+    assert entry_a["own_inputs"]
+    handle = entry_a["graph"].value
+    args3 = [a.clone() for a in args]
+    args3[5].mul_(2.0)                                    # the original content again, at a third address
+    torch.manual_seed(11)
+    o5 = m.infer(*args3, **kw)[0]
+    assert next(e for k, e in m._graphs.items() if k[0] == "A")["graph"].value == handle      # replayed, not re-recorded
+    assert torch.equal(o5, e_o)
