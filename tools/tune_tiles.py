@@ -27,7 +27,14 @@ def main():
     g = torch.randn(B, hp.gin_channels, device="cuda")
     names = {0: "default tile picker, cost-balanced placement", -7: "128x64 tile where C_out % 128 == 0", -8: "128x64 tile at C = 128 only",
              -9: "64x128 tile at C = 64", -10: "64x128 tile at C = 128", -11: "128x128 tile at C = 128"}
-    for occ, target in ((0, 0), (100, 0), (0, -7), (0, -8), (0, -9), (0, -10), (0, -11)):
+    # argv[2]: comma list of "force_ck:tile_target" pairs to run instead of the default sweep (force_ck 16 = 16-channel X chunks:
+    # half the LDS per workgroup, twice the barriers; +100 = plain z-major placement); the environment variable BV2_CONV_FLAGS=1
+    # turns the epilogue-operand prefetch of the 64x64 tile off (same-box A/B: run this script twice in one gpurun call)
+    sweep = ((0, 0), (100, 0), (0, -7), (0, -8), (0, -9), (0, -10), (0, -11))
+    if len(sys.argv) > 2:
+        sweep = tuple(tuple(int(v) for v in pair.split(":")) for pair in sys.argv[2].split(","))
+    print(f"BV2_CONV_FLAGS={os.environ.get('BV2_CONV_FLAGS', '0')}")
+    for occ, target in sweep:
         lib.bv2_test_set_tuning(0, occ, target)
         for _ in range(3):
             m.stage_generator(z, yl, g)
@@ -42,7 +49,10 @@ def main():
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 10)
         ts.sort()
-        print(f"{'plain z-major placement (no snake)' if occ == 100 else names[target]}: generator {ts[2]:.4f} ms/pass (min {ts[0]:.4f})", flush=True)
+        label = 'plain z-major placement (no snake)' if occ == 100 else names[target]
+        if occ % 100 == 16:
+            label += " + 16-channel X chunks"
+        print(f"{label}: generator {ts[2]:.4f} ms/pass (min {ts[0]:.4f})", flush=True)
     lib.bv2_test_set_tuning(0, 0, 0)
 
 
