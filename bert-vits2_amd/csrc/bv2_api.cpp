@@ -387,6 +387,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   if (k == "fused_resblock") h->no_fused_resblock = value == 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;
   else if (k == "fused_attn_o") h->no_fused_attn_o = value == 0;
+  else if (k == "attn_ksplit") h->attn_ksplit = value;
   else if (k == "overlap_dp") h->no_overlap_dp = value == 0;
   else { h->err = "bv2_set_option: unknown key '" + k + "'"; return -1; }
   return 0;

@@ -149,7 +149,7 @@ struct Ctx {
 //   f   = relu(conv_k(x*mask))            (MFMA, input mask + ReLU fused)
 //   s   = conv_k(f*mask)*mask + x         (MFMA, masks + residual fused)
 //   x   = LN2(s) [ + spk, *mask when the NEXT layer is the conditioning layer; *mask after the last layer ]
-struct EncBufs { float *x, *s, *att, *qkv, *f1; int64_t slab; };   // s holds kSlabs slabs of `slab` floats
+struct EncBufs { float *x, *s, *att, *qkv, *f1, *ml; int64_t slab; };   // s holds kSlabs slabs of `slab` floats; ml: key-split (max, sum) pairs
 
 constexpr int kSlabs = BV2_MAX_KSPLIT;
 inline int attn_ld(int T) { return (T + 31) / 32 * 32; }
@@ -177,9 +177,20 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow; a.f16 = f16 ? 1 : 0;
     // small-N regime (the one where `s` holds partial slabs): conv_o runs inside the attention kernel, head h -> slab h
     const bool fuse_o = !f16 && !c.h->no_fused_attn_o && n_slabs(B, T) >= e.heads && L.o.k == 1 && L.o.cin == H;
+    // key split (batch 1, long sequences): the key tiles of a (head, query tile) go to `ks` workgroups, each writing its own partial
+    // slab; LayerNorm-1 merges them with the flash-decoding weights and adds conv_o's bias and the residual itself
+    int ks = 1;
+    if (fuse_o && b.ml) {
+      ks = c.h->attn_ksplit < 0 ? attention_pick_ksplit(B, e.heads, T, n_slabs(B, T)) : c.h->attn_ksplit;
+      if (ks < 2 || e.heads * ks > n_slabs(B, T) || (e.heads * ks != 4 && e.heads * ks != 8) || (ks != 2 && ks != 4) ||
+          ks > (T + 31) / 32)
+        ks = 1;
+    }
     if (fuse_o) {
-      a.wo = c.W(L.o.w_off); a.bo = c.W(L.o.b_off); a.res = b.x; a.o_out = b.s; a.o_slab_stride = b.slab;
+      a.wo = c.W(L.o.w_off); a.o_out = b.s; a.o_slab_stride = b.slab;
       a.Co = L.o.cout; a.wo_groups = L.o.cin_pad / 8;
+      if (ks > 1) { a.ksplit = ks; a.ml_out = b.ml; }
+      else { a.bo = c.W(L.o.b_off); a.res = b.x; }
     }
     if (!c.rc) {
       const int pi = c.prof_begin("attention");
@@ -189,7 +200,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     }
     int ns = 1;
     if (fuse_o) {
-      ns = e.heads;
+      ns = e.heads * ks;
     } else if (f16) {
       HcProb q = c.hprob(L.o, b.att, true, b.s, true, T);
       q.res = b.x; q.res_mode = RES_ADD;
@@ -203,7 +214,9 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     std::memset(&l, 0, sizeof(l));
     l.a = b.s; l.nslab = ns; l.slab_stride = b.slab;
     l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T;
+    if (ks > 1) { l.ml = b.ml; l.ml_H = e.heads; l.ml_ks = ks; l.bias = c.W(L.o.b_off); l.add = b.x; }
     c.ln(l, "enc.ln1");
+    l.ml = nullptr; l.bias = nullptr; l.add = nullptr; l.ml_H = l.ml_ks = 0;
     if (f16) {
       // FFN (attentions.py:438-446): hidden activation relu(conv_1(x*mask))*mask kept as fp16 channels-last in b.f1
       HcProb q = c.hprob(L.ffn1, b.x, true, b.f1, false, T);
@@ -317,6 +330,7 @@ PlanA plan_a(Arena& A, const Model& m, int B, int T) {
   p.enc.att = A.get<float>(BT * H);
   p.enc.qkv = A.get<float>((int64_t)B * qkv_rows(m.enc) * attn_ld(T));
   p.enc.f1 = A.get<float>(BT * c.filter_channels);
+  p.enc.ml = ns > 1 ? A.get<float>((int64_t)B * kSlabs * 2 * T) : nullptr;
   p.dp0 = A.get<float>(BT * H);
   p.dp1 = A.get<float>(BT * kDpFilter);
   p.dp2 = A.get<float>(BT * kDpFilter);
@@ -367,6 +381,7 @@ PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
     p.enc.att = A.get<float>(BT * H);
     p.enc.qkv = A.get<float>((int64_t)B * qkv_rows(m.coupling[0].enc) * attn_ld(Ty));
     p.enc.f1 = A.get<float>(BT * c.filter_channels);
+    p.enc.ml = n_slabs(B, Ty) > 1 ? A.get<float>((int64_t)B * kSlabs * 2 * Ty) : nullptr;
   } else {
     p.acts = A.get<float>(BT * H);
     p.outacc = A.get<float>(BT * H);

@@ -124,6 +124,7 @@ struct bv2_handle {
   // bv2_set_option switches (tests compare the fused kernels with the layer-wise ones)
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
   bool no_fused_attn_o = false;      // "fused_attn_o" = 0: conv_o as its own launch after the attention kernel
+  int attn_ksplit = -1;              // "attn_ksplit": key ranges per (head, query tile) of the fused attention; -1 = picked per shape, 0 / 1 = off
   bool no_fused_dds = false;         // "fused_dds" = 0: DDSConv layers as 3 launches each
   bool no_overlap_dp = true;         // "overlap_dp" = 1: the (independent) DurationPredictor on an internal side stream, forked from and
   // joined back into the caller's stream with events (created on first use; capturable).  OFF by default: measured on MI355X at

@@ -229,7 +229,8 @@ int launch_conv_post(hipStream_t stream, const ConvPostArgs& a);
 
 // --------------------------------------------------------------------------------------------------------------
 // channel LayerNorm family (kernels/layernorm.hip)
-//   v[c][t]   = sum_{s<nslab} a[s*slab_stride + b][c][t] (+ add[b][c][t])   mode 0 (nslab partial slabs of a split-K conv)
+//   v[c][t]   = sum_{s<nslab} a[s*slab_stride + b][c][t] (+ add[b][c][t])   mode 0 (nslab partial slabs of a split-K conv;
+//               with `ml` set the slabs are weighted: the key-split attention's merge, see below)
 //             = dwb[c] + sum_j dww[c][j] * a[b][c][t+(j-1)*dil]*in_mask[b][.]   mode 1 (depthwise k=3, DDSConv)
 //   y         = (v - mean_c) * rsqrt(var_c + eps) * gamma[c] + beta[c];  y = gelu(y) if post_gelu
 //   out       = ((res ? res : 0) + y + (vec ? vec[b][c] : 0)) * (mask ? mask[b][t] : 1)
@@ -245,6 +246,10 @@ struct LnArgs {
   float* out;
   int B, C, T;
   float* out2; const float* vec2; int vec2_bstride;
+  // weighted slabs (mode 0, nslab = ml_H * ml_ks in {4, 8}): slab h*ml_ks + r is the key-split attention's partial (head h, key
+  // range r) behind conv_o; ml [B][ml_H][ml_ks][2][T] holds the range's softmax (max, sum) per query.  v = sum_{h,r} w_{h,r} slab
+  // + bias[c] (conv_o's bias) + add (the residual), w_{h,r} = l_r e^{m_r - M_h} / sum_r' l_r' e^{m_r' - M_h}  (AttnArgs::ksplit)
+  const float* ml; int ml_H, ml_ks; const float* bias;
 };
 int launch_layernorm(hipStream_t stream, const LnArgs& a);
 
@@ -298,8 +303,13 @@ struct AttnArgs {
   // o_out [B][Co][T] (slab h at o_out + h * o_slab_stride; head 0 adds bias `bo` and residual `res` [B][Co][T])
   const float* wo = nullptr; const float* bo = nullptr; const float* res = nullptr;
   float* o_out = nullptr; int64_t o_slab_stride = 0; int Co = 0, wo_groups = 0;
+  // key split (fused conv_o form only, bo == res == nullptr): the key tiles of a (head, query tile) are dealt to `ksplit` workgroups;
+  // workgroup r writes its LOCALLY normalised partial through conv_o into slab h*ksplit + r and (max, sum) of its key range to
+  // ml_out [B][H][ksplit][2][T]; the consumer (LnArgs::ml) merges the slabs with the flash-decoding weights
+  int ksplit = 1; float* ml_out = nullptr;
   unsigned long long* dbg = nullptr;   // tools/timeline.py only
 };
+int attention_pick_ksplit(int B, int H, int T, int max_slabs);   // key ranges per (head, query tile) that fill the chip at small batch
 int launch_attention(hipStream_t stream, const AttnArgs& a);
 double attention_flops(const AttnArgs& a);
 

@@ -17,6 +17,15 @@
 //   O^T tile  [D x 32 queries] += V·P^T with the K-steps taken in the D layout's own row order: step r pairs the keys
 //             rowmap(r,0) / rowmap(r,1), so the B operand is the probability register S[r] itself (no LDS round trip)
 //             and the A operand v[c][rowmap(r,lh)] comes as aligned float4s (4 consecutive keys) straight from global.
+//
+// Key split (A.ksplit > 1, fused conv_o form only; batch 1 leaves a launch at T_y/32 x H = 24 workgroups on a 256-CU part, each
+// walking 12 key tiles): the key tiles of a (head, query tile) are dealt to `ksplit` workgroups.  Workgroup r normalises over ITS keys
+// only (running max m_r, sum l_r), pushes that partial through conv_o — the projection is linear — into slab h*ksplit + r, and
+// writes (m_r, l_r) per query.  The LayerNorm that sums the slabs anyway weighs slab (h, r) by
+//     w_r = l_r e^{m_r - M} / sum_r' l_r' e^{m_r' - M},   M = max_r m_r
+// — exactly the flash-decoding merge, with no extra launch and no cross-workgroup hand-over inside the kernel (an agent-scope fence
+// costs more than a launch on this 8-XCD part: tools/probe/grid_barrier.hip).  Relative-value band terms belong to the workgroup that
+// owns the key; bias and residual move to the LayerNorm.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "../bv2_kernels.h"
@@ -57,7 +66,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
   const int l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AQ;
+  const int KS = A.ksplit > 1 ? A.ksplit : 1;
+  const int kr = KS > 1 ? (int)blockIdx.x % KS : 0;          // this workgroup's key range
+  const int b = blockIdx.z, h = blockIdx.y, i0 = (KS > 1 ? (int)blockIdx.x / KS : (int)blockIdx.x) * AQ;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;  // timeline stamps (tools/timeline.py; A.dbg is null in the product)
   if (A.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int T = A.T, W = A.W, NR = 2 * W + 1, ld = A.ld;
@@ -81,7 +92,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 
   const int iq = i0 + l31;                          // this lane's query
   const bool iok = iq < T;
-  const int ntiles = (T + AK - 1) / AK;
+  const int ntiles_all = (T + AK - 1) / AK;
+  const int kt0 = (ntiles_all * kr) / KS, kt1 = (ntiles_all * (kr + 1)) / KS;   // key tiles [kt0, kt1) are this workgroup's
+  const int ntiles = kt1 - kt0;
 
   // ---- everything this wave's first key tile needs goes in flight at once (one memory round trip):
   //      K tile -> D/2 registers + key mask now; the V tile (D/8 float4) is issued as soon as the K registers are consumed
@@ -104,7 +117,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   };
   const bool have_tile = wid < ntiles;
   if (have_tile) {
-    issue_k(wid * AK);
+    issue_k((kt0 + wid) * AK);
   }
   const float mi = iok ? mp[iq] : 0.f;
   // query tile and Ev -> LDS (all threads)
@@ -154,7 +167,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 
 #pragma unroll 1
   for (int kt = wid; kt < ntiles; kt += (ONE ? (1 << 20) : NW)) {    // ONE: the body runs at most once (ntiles <= NW)
-    const int j0 = kt * AK;
+    const int j0 = (kt0 + kt) * AK;
     if (!ONE && kt >= NW) issue_k(j0);
     // ---- S^T = K^T Q   (rows beyond T hold garbage: replaced below, never accumulated)
     f32x16 S;
@@ -308,7 +321,15 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       const float mw = Mw[w * AQ + i];
       lt += (mw == -INFINITY) ? 0.f : Lw[w * AQ + i] * __expf(mw - mt);
     }
-    Sb[e] = (j >= 0 && j < T && i0 + i < T) ? __expf(Sb[e] - mt) / lt : 0.f;
+    // key split: a band key outside [kt0, kt1) belongs to another workgroup (its Sb slot was never written here)
+    const bool mine = j >= kt0 * AK && j < kt1 * AK;
+    Sb[e] = (j >= 0 && j < T && i0 + i < T && mine) ? __expf(Sb[e] - mt) / lt : 0.f;
+  }
+  if (KS > 1 && tid < AQ && i0 + tid < T) {
+    // (m_r, l_r) of this key range for the merge in the LayerNorm: [b][h][kr][2][T]
+    float* ml = A.ml_out + ((((int64_t)b * A.H + h) * KS + kr) * 2) * T + i0 + tid;
+    ml[0] = m_tot;                                 // tid < 32: lane l31 == tid, so m_tot / l_tot are query tid's
+    ml[T] = l_tot;
   }
   if (A.dbg) ts3 = __builtin_amdgcn_s_memtime();
   constexpr int ROUNDS = (NW + ANS - 1) / ANS;
@@ -352,7 +373,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     const float* const wo = A.wo;
     const float* const bo = h == 0 ? A.bo : nullptr;
     const float* const resp = h == 0 && A.res ? A.res + (int64_t)b * Co * T : nullptr;
-    float* const ob = A.o_out + (int64_t)h * A.o_slab_stride + (int64_t)b * Co * T;
+    float* const ob = A.o_out + (int64_t)(h * KS + kr) * A.o_slab_stride + (int64_t)b * Co * T;
     __syncthreads();
     for (int mt = wid; mt * 32 < Co; mt += NW) {
       f32x4 wr[D / 8];
@@ -435,6 +456,7 @@ static int launch_attn_variant(hipStream_t stream, const AttnArgs& a, dim3 grid)
 
 template <int DT>
 static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int ntiles) {
+  // ntiles = key tiles per workgroup (of its key range when the keys are split)
   // Up to 8 key tiles: one per wave, no loop (T = 128: 19.4 -> 16.9 us).  More: 8 waves round-robin.  Measured at T_y = 384
   // (12 tiles) and NOT kept: 12 waves with one tile each (53 spilled registers: 27 -> 41 us) and 6 waves with two tiles each
   // (balanced, but 27 -> 31 us: the merge wait that tools/timeline.py shows is not the 1-vs-2-tile imbalance).
@@ -448,8 +470,11 @@ static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int n
 int launch_attention(hipStream_t stream, const AttnArgs& a) {
   if (a.W > AMAXW || a.W < 0 || a.T < 1 || a.B < 1 || a.H < 1 || a.ld % 32 || a.ld < a.T) return -1;
   if (a.wo && (a.f16 || !a.o_out || a.Co < 1 || a.wo_groups * 8 < a.H * a.D)) return -1;   // fused conv_o: fp32 form only
-  dim3 grid((a.T + AQ - 1) / AQ, a.H, a.B);
-  const int ntiles = (a.T + AK - 1) / AK;
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  const int ntiles_all = (a.T + AK - 1) / AK;
+  if (ks > 1 && (!a.wo || !a.ml_out || a.bo || a.res || ks > ntiles_all)) return -1;        // key split: partial slabs merged by the LayerNorm
+  dim3 grid(((a.T + AQ - 1) / AQ) * ks, a.H, a.B);
+  const int ntiles = (ntiles_all + ks - 1) / ks;                                            // the largest key range
   switch (a.D) {
     case 32: return launch_attn_d<1>(stream, a, grid, ntiles);
     case 64: return launch_attn_d<2>(stream, a, grid, ntiles);
@@ -457,6 +482,17 @@ int launch_attention(hipStream_t stream, const AttnArgs& a) {
     case 128: return launch_attn_d<4>(stream, a, grid, ntiles);
     default: return -2;   // head dim must be a multiple of 32 up to 128
   }
+}
+
+// Key ranges per (head, query tile).  Splitting pays only when a wave would otherwise walk several key tiles in turn (more tiles
+// than the 8 waves of a workgroup) and the launch is far from filling the chip; the target is one key tile per SIMD (4 per
+// workgroup).  H * ks partial slabs must be a count the slab-summing LayerNorm has (2, 4 or 8) and fit `max_slabs`.
+int attention_pick_ksplit(int B, int H, int T, int max_slabs) {
+  const int ntiles = (T + AK - 1) / AK, qtiles = (T + AQ - 1) / AQ;
+  if (ntiles <= 8 || H < 1 || (H & (H - 1))) return 1;
+  int ks = 1;
+  while (ks * 4 < ntiles && H * ks * 2 <= max_slabs && H * ks * 2 <= 8 && (long)B * H * qtiles * ks * 2 <= 512) ks *= 2;
+  return ks;
 }
 
 double attention_flops(const AttnArgs& a) {

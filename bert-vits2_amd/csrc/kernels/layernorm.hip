@@ -20,7 +20,7 @@ namespace bv2 {
 constexpr int LN_TT = 8;       // time steps per workgroup
 constexpr int LN_G = 32;       // channel groups (threads along C)
 
-template <int CPT, int NSLAB, int MODE, bool GUARD>   // CPT channels per thread; GUARD: C < CPT*LN_G allowed
+template <int CPT, int NSLAB, int MODE, bool GUARD, int KS = 0>   // CPT channels per thread; GUARD: C < CPT*LN_G allowed; KS > 0: weighted slabs, KS key ranges per head
 __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
   __shared__ float red[2][4][LN_TT];               // [pass][wave][time step]
   const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 3;
@@ -33,7 +33,53 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
   const float* ap = A.a + base;
 
   float v[CPT];
-  if (MODE == 0) {
+  if constexpr (MODE == 0 && KS > 0) {
+    // key-split attention (kernels/attention.hip): slab h*ks + r carries head h's output over key range r, normalised over that range
+    // only, already behind conv_o; the flash-decoding merge weights come from the ranges' (max, sum) pairs of this column
+    const float* mlp = A.ml + (int64_t)b * NSLAB * 2 * T + tcl;
+    float mm[NSLAB], ll[NSLAB], w[NSLAB];
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) { mm[sl] = mlp[(int64_t)sl * 2 * T]; ll[sl] = mlp[(int64_t)sl * 2 * T + T]; }
+    float xs[CPT][NSLAB];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      int c = ty + i * LN_G;
+      if (GUARD) c = c < C ? c : C - 1;
+      const int off = c * T + tcl;
+#pragma unroll
+      for (int sl = 0; sl < NSLAB; ++sl) xs[i][sl] = ap[(int64_t)sl * A.slab_stride + off];
+    }
+#pragma unroll
+    for (int h0 = 0; h0 < NSLAB; h0 += KS) {        // h0 = first slab of a head
+      float M = mm[h0];
+#pragma unroll
+      for (int r = 1; r < KS; ++r) M = fmaxf(M, mm[h0 + r]);
+      float den = 0.f;
+#pragma unroll
+      for (int r = 0; r < KS; ++r) { w[h0 + r] = ll[h0 + r] * __expf(mm[h0 + r] - M); den += w[h0 + r]; }
+      const float inv = 1.0f / den;
+#pragma unroll
+      for (int r = 0; r < KS; ++r) w[h0 + r] *= inv;
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      int c = ty + i * LN_G;
+      if (GUARD) c = c < C ? c : C - 1;
+      float x = A.bias ? A.bias[c] : 0.f;
+#pragma unroll
+      for (int sl = 0; sl < NSLAB; ++sl) x += w[sl] * xs[i][sl];
+      v[i] = x;
+    }
+    if (A.add) {
+      const float* dp = A.add + base;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        int c = ty + i * LN_G;
+        if (GUARD) c = c < C ? c : C - 1;
+        v[i] += dp[c * T + tcl];
+      }
+    }
+  } else if constexpr (MODE == 0) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       int c = ty + i * LN_G;
@@ -134,6 +180,13 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
 template <int CPT, bool GUARD>
 static void launch_ln_cfg(hipStream_t stream, const LnArgs& a, dim3 grid) {
   if (a.mode != 0) { hipLaunchKernelGGL((layernorm_kernel<CPT, 1, 1, GUARD>), grid, dim3(256), 0, stream, a); return; }
+  if (a.ml) {                                      // nslab = heads x key ranges
+    if (a.nslab == 8 && a.ml_ks == 4) hipLaunchKernelGGL((layernorm_kernel<CPT, 8, 0, GUARD, 4>), grid, dim3(256), 0, stream, a);
+    else if (a.nslab == 8) hipLaunchKernelGGL((layernorm_kernel<CPT, 8, 0, GUARD, 2>), grid, dim3(256), 0, stream, a);
+    else if (a.ml_ks == 4) hipLaunchKernelGGL((layernorm_kernel<CPT, 4, 0, GUARD, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((layernorm_kernel<CPT, 4, 0, GUARD, 2>), grid, dim3(256), 0, stream, a);
+    return;
+  }
   switch (a.nslab) {
     case 2: hipLaunchKernelGGL((layernorm_kernel<CPT, 2, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
     case 4: hipLaunchKernelGGL((layernorm_kernel<CPT, 4, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
@@ -147,6 +200,7 @@ int launch_layernorm(hipStream_t stream, const LnArgs& a) {
   if ((int64_t)a.C * a.T >= (1ll << 31)) return -1;             // 32-bit in-batch offsets
   const int ns = a.nslab < 1 ? 1 : a.nslab;
   if (a.mode == 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8) return -1;
+  if (a.ml && (a.mode != 0 || (ns != 4 && ns != 8) || (a.ml_ks != 2 && a.ml_ks != 4) || a.ml_H * a.ml_ks != ns)) return -1;
   dim3 grid((a.T + LN_TT - 1) / LN_TT, a.B);
   if (a.C == 6 * LN_G) launch_ln_cfg<6, false>(stream, a, grid);          // hidden_channels 192
   else if (a.C == 8 * LN_G) launch_ln_cfg<8, false>(stream, a, grid);     // DurationPredictor filter 256
