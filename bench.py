@@ -46,7 +46,7 @@ CONFIGS = {
     4: dict(batch=32, symbols=128, dtype="bf16", flow="f16", graph=1, ragged=True),
     5: dict(batch=8, symbols=512, dtype="bf16", flow="f16", graph=0, ragged=False),
 }
-WN_FLOW_B32 = "f32"               # flow arithmetic of secondary.config3_residual_flow ("f16" once the fp16 WN convs exist)
+WN_FLOW_B32 = "f16"               # flow arithmetic of secondary.config3_residual_flow: the WN convolutions on the fp16 matrix core
 KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
 KERNEL_SOURCES = {"conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
                   "conv_cl_bf16": "gen_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "conv_f16": "enc_f16.hip",
@@ -66,7 +66,7 @@ def parse(argv=None):
     ap.add_argument("--flow-dtype", choices=("f32", "f16"), default=None, help="transformer-flow conv arithmetic (overrides the config's)")
     ap.add_argument("--graph", type=int, default=None, choices=(0, 1), help="replay each phase as a captured hipGraph")
     ap.add_argument("--residual-flow", action="store_true",
-                    help="the ResidualCouplingBlock / WN flow (use_transformer_flow=false) instead of the transformer flow; fp32 flow only")
+                    help="the ResidualCouplingBlock / WN flow (use_transformer_flow=false) instead of the transformer flow (fp32 unless --flow-dtype f16)")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the secondary configs 3 / 4 / 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
@@ -313,8 +313,7 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     use_graph = bool(cfg["graph"]) if overrides.get("graph") is None else bool(overrides["graph"])
     model.enable_graphs(False)
     model.set_generator_dtype(torch.bfloat16 if gen_dtype == "bf16" else torch.float32)
-    if hp.use_transformer_flow:
-        model.set_flow_dtype(torch.float16 if flow_dtype == "f16" else torch.float32)
+    model.set_flow_dtype(torch.float16 if flow_dtype == "f16" else torch.float32)     # both flow variants have an fp16 form
     batch, lengths = make_batch(cfg, B, T, rank)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
     call = lambda b=dbatch: model.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"],
@@ -619,7 +618,7 @@ def describe(res, hp, world):
              f"random speakers" if ragged else f"B={res['B']} x T={res['T']} symbols")
     return (f"BASELINE config {res['config']}: {shape} per GPU, "
             f"{'bf16 Generator (fp32 accumulate)' if gd == 'bf16' else 'fp32 Generator'}, "
-            f"{'fp16 flow convs (fp32 accumulate / LayerNorm / softmax)' if fd == 'f16' else 'fp32 flow'}, "
+            f"{'fp16 flow convs (fp32 accumulate / LayerNorm / softmax / gate)' if fd == 'f16' else 'fp32 flow'}, "
             f"fp32 text encoder / durations / spline, T_y={res['Ty']} frames "
             f"({res['Ty'] * hp.total_upsample} samples, {res['Ty'] * hp.total_upsample / hp.sampling_rate:.3f} s) per padded utterance, "
             f"{'transformer' if hp.use_transformer_flow else 'residual (WN)'} flow, synthetic seeded weights, durations pinned to 3 frames/symbol, "

@@ -165,7 +165,20 @@ int bv2_set_generator_dtype(bv2_handle* h, int dtype) {
 int bv2_set_flow_dtype(bv2_handle* h, int dtype) {
   if (!h) return -1;
   if (dtype != BV2_F32 && dtype != BV2_F16) { h->err = "bv2_set_flow_dtype: BV2_F32 or BV2_F16"; return -1; }
-  if (dtype == BV2_F16) {
+  if (dtype == BV2_F16 && !h->model.cfg.use_transformer_flow) {
+    // residual (WN) flow: in_layers (gate epilogue) and res_skip_layers on the fp16 matrix core, reference modules.py:185-210
+    const Model& m = h->model;
+    bool ok = m.cfg.hidden_channels % 32 == 0;
+    for (int a = 0; a < m.n_coupling && ok; ++a)
+      for (int i = 0; i < m.coupling[a].wn_layers && ok; ++i) {
+        const CouplingW& K = m.coupling[a];
+        const bool last = i + 1 == K.wn_layers;
+        ok = K.wn_in[i].wh_off >= 0 && K.wn_skip[i].wh_off >= 0 && (last || K.wn_res[i].wh_off >= 0) &&
+             conv_f16_supported(K.wn_in[i].cin, K.wn_in[i].cout, K.wn_in[i].k, 1, true) &&
+             conv_f16_supported(K.wn_skip[i].cin, K.wn_skip[i].cout, 1, 1, false);
+      }
+    if (!ok) { h->err = "bv2_set_flow_dtype: the fp16 WN flow needs hidden_channels % 32 == 0"; return -2; }
+  } else if (dtype == BV2_F16) {
     const Model& m = h->model;
     bool ok = m.cfg.use_transformer_flow != 0;
     for (int a = 0; a < m.n_coupling && ok; ++a)
@@ -599,7 +612,8 @@ int bv2_test_conv_f16(void* stream, const void* x, int in_ct, const float* in_ma
     }
     HcLaunch hl;
     std::memset(&hl, 0, sizeof(hl));
-    HcProb& p = hl.p;
+    hl.nprob = 1;
+    HcProb& p = hl.p[0];
     p.x = x; p.in_ct = in_ct; p.x_bstride = (int64_t)cin * L; p.x_rstride = L; p.Lin = L;
     p.in_mask = in_mask; p.in_mask_bstride = L;
     p.w = static_cast<const uint16_t*>(wpack_dev);

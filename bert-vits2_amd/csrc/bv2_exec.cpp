@@ -120,10 +120,11 @@ struct Ctx {
     p.cin = w.cin; p.cout = w.cout; p.cout_pad = w.cout_pad; p.k = w.k; p.dil = 1; p.pad_left = (w.k - 1) / 2;
     return p;
   }
-  void conv_h(const HcProb& p, int B, int L, const char* tag) {
+  void conv_h(const HcProb& p, int B, int L, const char* tag, const HcProb* p2 = nullptr) {
     if (rc) return;
     HcLaunch hl;
-    hl.p = p; hl.B = B; hl.L = L;
+    hl.p[0] = p; hl.nprob = 1; hl.B = B; hl.L = L;
+    if (p2) { hl.p[1] = *p2; hl.nprob = 2; }
     const char* vn = "conv_f16";
     const int pi = prof_begin(tag);
     if (pi >= 0 && h->prof_mode >= 3)
@@ -685,6 +686,32 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
     const float* hres = P.h;
     if (cf.use_transformer_flow) {
       run_encoder(c, K.enc, P.enc, ymask, gv_flow + a * H, P.gv_stride, B, Ty, nullptr, c.h->flow_dtype == BV2_F16);
+    } else if (c.h->flow_dtype == BV2_F16) {
+      // WN.forward on the fp16 matrix core (bv2_set_flow_dtype(BV2_F16)): in_layer reads the fp32 x (rounded while staged), adds
+      // bias + g_l and gates in fp32, writes the gate output as fp16 channels-last — it is only ever res_skip's input; res_skip
+      // runs as two problems of one launch on that tensor with the fp32 epilogues of the fp32 path (x update in place with the
+      // mask, skip sum).  x, the skip sum, pre / post stay fp32.
+      const int nl = K.wn_layers;
+      const float* gl = gv_flow + (int64_t)a * 2 * H * nl;
+      uint16_t* actsh = reinterpret_cast<uint16_t*>(P.acts);
+      for (int i = 0; i < nl; ++i) {
+        const bool last = i == nl - 1;
+        HcProb q = c.hprob(K.wn_in[i], P.h, true, actsh, false, Ty);
+        q.bias2 = gl + (int64_t)i * 2 * H; q.bias2_bstride = P.gv_stride;
+        q.act = ACT_GATE; q.out_bstride = (int64_t)H * Ty;
+        c.conv_h(q, B, Ty, "wn.in+gate");
+        HcProb sk = c.hprob(K.wn_skip[i], actsh, false, P.outacc, true, Ty);
+        if (i > 0) { sk.res = P.outacc; sk.res_mode = RES_ADD; }
+        if (last) { sk.out_mask = ymask; sk.mask_post = 1; }
+        if (!last) {
+          HcProb r = c.hprob(K.wn_res[i], actsh, false, P.h, true, Ty);
+          r.res = P.h; r.res_mode = RES_ADD; r.out_mask = ymask; r.mask_post = 1;
+          c.conv_h(r, B, Ty, "wn.res_skip", &sk);
+        } else {
+          c.conv_h(sk, B, Ty, "wn.res_skip");
+        }
+      }
+      hres = P.outacc;
     } else {
       const int nl = K.wn_layers;
       const float* gl = gv_flow + (int64_t)a * 2 * H * nl;

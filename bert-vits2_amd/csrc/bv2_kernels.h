@@ -201,6 +201,7 @@ struct HcProb {
   const float* in_mask; int in_mask_bstride;      // in_ct only; null = no mask
   const uint16_t* w;
   const float* bias;        // [cout_pad] fp32 or null
+  const float* bias2; int bias2_bstride;           // [B][bias2_bstride] per-batch bias or null (WN conditioning slice g_l)
   void* out; int out_ct;
   int64_t out_bstride;      // elements between batches
   int out_rstride;          // out_ct: floats between channels
@@ -209,7 +210,12 @@ struct HcProb {
   int mask_pre, mask_post, act;
   int cin, cout, cout_pad, k, dil, pad_left;
 };
-struct HcLaunch { HcProb p; int B, L; unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
+// act == ACT_GATE (out_ct = 0 only; WN, reference commons.py:98-105): the weight rows come in gate order (bv2_model.cpp wn_gate_row:
+// rows [0,16) of every 32-row tile = tanh half, rows [16,32) = sigmoid half of the same 16 channels); the epilogue writes
+// out[b][t][16*mt + j] = fp16( tanh(v[j]) * sigmoid(v[j+16]) ), `out` has cout/2 channels (out_bstride = cout/2 * L).
+// A launch carries 1 or 2 problems (blockIdx.z) with the same cin / k / dil / cout_pad and input form: the two row halves of
+// res_skip_layers (x update in place, skip sum), reference modules.py:203-210.
+struct HcLaunch { HcProb p[2]; int nprob = 1; int B, L; unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
 int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name);
 void conv_f16_set_tuning(int generic);                       // tests / tuning only (bv2_test_set_variants)
 bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl);

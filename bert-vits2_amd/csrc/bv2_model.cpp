@@ -344,6 +344,7 @@ int pack_all(Model& m, Packer& P) {
       const std::function<int(int)> gate_row = [hid](int n) { const int mt = n / 32, j = n % 32; return j < 16 ? 16 * mt + j : hid + 16 * mt + (j - 16); };
       const std::function<int(int)> cond_row = [hid, &gate_row](int n) { return (n / (2 * hid)) * 2 * hid + gate_row(n % (2 * hid)); };
       C.wn_cond = P.gemv(p + ".enc.cond_layer", 2 * hid * nl, gin, true, /*wn=*/true, &cond_row);
+      P.emit_f16 = true;                           // "fp16 flow": in_layers / res_skip_layers also as fp16 streams (same row order)
       for (int i = 0; i < nl; ++i) {
         const std::string rsn = p + ".enc.res_skip_layers." + std::to_string(i);
         C.wn_in[i] = P.conv1d(p + ".enc.in_layers." + std::to_string(i), 2 * hid, hid, kFlowKernel, true, true, 0, -1, false, false, &gate_row);
@@ -356,6 +357,7 @@ int pack_all(Model& m, Packer& P) {
           C.wn_skip[i] = P.conv1d(rsn, hid, hid, 1, true, true);
         }
       }
+      P.emit_f16 = false;
     }
     C.post = P.conv1d(p + ".post", half, hid, 1, true, false, 0, -1, false, /*rev_out=*/C.flipped);
   }

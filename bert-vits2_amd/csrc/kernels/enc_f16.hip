@@ -203,7 +203,7 @@ template <int WN, int NI, bool IN_CT, bool OUT_CT, int G>   // G > 0: every chun
 __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, const int ngrp) {
   constexpr int NT = 64 * WN, BT = 32 * NI;
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
-  const HcProb& P = L.p;
+  const HcProb& P = L.p[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -301,6 +301,41 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
         outp[(unsigned)co * o_rs + (unsigned)t] = v;
       }
     }
+  } else if (P.act == ACT_GATE) {
+    // fused_add_tanh_sigmoid_multiply (commons.py:98-105) on gate-ordered rows: registers r and r + 8 of a lane are the (tanh,
+    // sigmoid) pair of output channel 16*mt + 8*(r>>2) + 4*lh + (r&3), r < 8; bias and the per-batch conditioning slice in fp32
+    uint16_t* outp = static_cast<uint16_t*>(P.out) + (int64_t)b * P.out_bstride;
+    const int couth = cout >> 1;
+    const float* const b2 = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
+    float bt[2][4], bsg[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int rt = mt * 32 + 8 * g + 4 * lh + i;
+        rt = rt + 16 < cout ? rt : 0;
+        bt[g][i] = (P.bias ? P.bias[rt] : 0.f) + (b2 ? b2[rt] : 0.f);
+        bsg[g][i] = (P.bias ? P.bias[rt + 16] : 0.f) + (b2 ? b2[rt + 16] : 0.f);
+      }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int t = t0 + ni * 32 + l31;
+      if (t >= L.L) continue;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int co = mt * 16 + 8 * g + 4 * lh;
+        if (co >= couth) continue;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = acc[ni][4 * g + i] + bt[g][i], sg = acc[ni][4 * g + 8 + i] + bsg[g][i];
+          v[i] = tanhf(a) * (1.f / (1.f + expf(-sg)));
+        }
+        u32x2 o;
+        o.x = h_pack(v[0], v[1]); o.y = h_pack(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(outp + (int64_t)t * couth + co) = o;
+      }
+    }
   } else {
     uint16_t* outp = static_cast<uint16_t*>(P.out) + (int64_t)b * P.out_bstride;
 #pragma unroll
@@ -345,16 +380,16 @@ bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl) {
 template <int WN, int NI, bool IN_CT, bool OUT_CT, int G>
 static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   constexpr int BT = 32 * NI;
-  const HcProb& p = L.p;
+  const HcProb& p = L.p[0];
   const int ck = p.cin < HC_CK ? p.cin : HC_CK;
   const size_t lds = (size_t)(BT + (p.k - 1) * p.dil) * (size_t)(ck + 8) * 2;
   if (lds > 160 * 1024) return -2;
   const int ngrp = (nt + WN - 1) / WN;
-  dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, 1);
+  dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
   auto kern = conv_f16_kernel<WN, NI, IN_CT, OUT_CT, G>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   HcLaunch Lt = L;
-  Lt.dbg = timeline_slice(grid.x, grid.y, 1, 99000 + WN * 100 + NI * 10 + (IN_CT ? 2 : 0) + (OUT_CT ? 1 : 0), p.k, p.cin, L.L);   // 99xxx: fp16 conv
+  Lt.dbg = L.nprob > 1 ? nullptr : timeline_slice(grid.x, grid.y, 1, 99000 + WN * 100 + NI * 10 + (IN_CT ? 2 : 0) + (OUT_CT ? 1 : 0), p.k, p.cin, L.L);   // 99xxx: fp16 conv
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN), lds, stream, Lt, ngrp);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -365,14 +400,14 @@ void conv_f16_set_tuning(int generic) { g_hc_generic = generic != 0; }
 template <int WN, int NI, bool IN_CT, bool OUT_CT>
 static int launch_hc(hipStream_t stream, const HcLaunch& L, int nt) {
   const bool generic = g_hc_generic;
-  if (!generic && L.p.cin == 192) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 12>(stream, L, nt);
-  if (!generic && L.p.cin % 256 == 0) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 16>(stream, L, nt);
+  if (!generic && L.p[0].cin == 192) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 12>(stream, L, nt);
+  if (!generic && L.p[0].cin % 256 == 0) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 16>(stream, L, nt);
   return launch_hc_g<WN, NI, IN_CT, OUT_CT, 0>(stream, L, nt);
 }
 
 template <int WN, int NI>
 static int launch_hc_io(hipStream_t stream, const HcLaunch& L, int nt) {
-  const bool ict = L.p.in_ct != 0, oct = L.p.out_ct != 0;
+  const bool ict = L.p[0].in_ct != 0, oct = L.p[0].out_ct != 0;
   if (ict && oct) return launch_hc<WN, NI, true, true>(stream, L, nt);
   if (ict) return launch_hc<WN, NI, true, false>(stream, L, nt);
   if (oct) return launch_hc<WN, NI, false, true>(stream, L, nt);
@@ -380,10 +415,19 @@ static int launch_hc_io(hipStream_t stream, const HcLaunch& L, int nt) {
 }
 
 int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name) {
-  const HcProb& p = L.p;
+  const HcProb& p = L.p[0];
   if (L.B < 1 || L.L < 1 || !conv_f16_supported(p.cin, p.cout, p.k, p.dil, !p.out_ct) || p.cout_pad % 32 || p.cout_pad < p.cout)
     return -1;
-  if (!p.out_ct && (p.res_mode != RES_NONE)) return -1;            // the residual add lives in the fp32 [C][T] epilogue
+  if (L.nprob < 1 || L.nprob > 2) return -1;
+  for (int i = 0; i < L.nprob; ++i) {
+    const HcProb& q = L.p[i];
+    if (q.cin != p.cin || q.k != p.k || q.dil != p.dil || q.cout_pad != p.cout_pad || q.in_ct != p.in_ct || q.out_ct != p.out_ct ||
+        q.pad_left != p.pad_left || q.cout > q.cout_pad)
+      return -1;
+    if (!q.out_ct && (q.res_mode != RES_NONE)) return -1;          // the residual add lives in the fp32 [C][T] epilogue
+    if (q.act == ACT_GATE && (q.out_ct || q.cout % 32)) return -1; // the gate writes fp16 channels-last, whole (tanh, sigmoid) tiles
+    if (q.bias2 && q.act != ACT_GATE) return -1;                   // the per-batch bias only exists in the gate epilogue
+  }
   const int nt = p.cout_pad / 32;
   // waves per workgroup (each owns one 32-channel output tile): the count in {8, 6, 4} that wastes the fewest wave slots
   int wn = 8, best = 1 << 30;
@@ -407,13 +451,21 @@ int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_
   return ni == 4 ? launch_hc_io<4, 4>(stream, L, nt) : launch_hc_io<4, 2>(stream, L, nt);
 }
 
-double conv_f16_flops(const HcLaunch& L) { return 2.0 * L.p.cout * L.p.cin * L.p.k * (double)L.L * L.B; }
+double conv_f16_flops(const HcLaunch& L) {
+  double f = 0;
+  for (int i = 0; i < L.nprob; ++i) f += 2.0 * L.p[i].cout * L.p[i].cin * L.p[i].k * (double)L.L * L.B;
+  return f;
+}
 
 double conv_f16_bytes(const HcLaunch& L) {   // input read once, output written once (+ residual read), weights once
-  const HcProb& p = L.p;
   const double n = (double)L.L * L.B;
-  return (p.in_ct ? 4.0 : 2.0) * p.cin * n + (p.out_ct ? 4.0 : 2.0) * p.cout * n + (p.res_mode ? 4.0 * p.cout * n : 0.0) +
-         2.0 * p.cout * p.cin * p.k;
+  double by = (L.p[0].in_ct ? 4.0 : 2.0) * L.p[0].cin * n;           // the problems of a launch share their input
+  for (int i = 0; i < L.nprob; ++i) {
+    const HcProb& p = L.p[i];
+    const double co = p.act == ACT_GATE ? 0.5 * p.cout : (double)p.cout;
+    by += (p.out_ct ? 4.0 : 2.0) * co * n + (p.res_mode ? 4.0 * p.cout * n : 0.0) + 2.0 * p.cout * p.cin * p.k;
+  }
+  return by;
 }
 
 }  // namespace bv2

@@ -294,18 +294,25 @@ def length_regulate(w_ceil, x_mask, m_p, logs_p):
 # --------------------------------------------------------------------------------------------
 # flows (models.py:82-145, 403-445; modules.py:133-218, 402-456, 519-580)
 
-def wn(sd, p, x, mask, g, n_layers, hidden, ksize=5, dilation_rate=1, fold_cache=None):
-    """reference modules.py:185-210; gate = tanh(first half)·sigmoid(second half) (commons.py:98-105)."""
+def wn(sd, p, x, mask, g, n_layers, hidden, ksize=5, dilation_rate=1, fold_cache=None, half=False):
+    """reference modules.py:185-210; gate = tanh(first half)·sigmoid(second half) (commons.py:98-105).
+
+    half=True pins the rounding points of the fp16 product path (bv2_set_flow_dtype(BV2_F16) with the residual flow): the
+    inputs and weights of in_layers / res_skip_layers are rounded to fp16 (the gate output is STORED as fp16: it is only ever
+    a conv input), accumulation, bias, the conditioning slice, tanh / sigmoid, the residual stream x and the skip sum stay
+    fp32; cond_layer (a [B,512] x [1536,512] product) stays fp32.  The reference's counterpart is `flow` under
+    torch.autocast(float16) (oracle/ref_import.py reference_autocast_runs), which also keeps fp16 partial sums."""
+    q = _h if half else (lambda t: t)
     out = torch.zeros_like(x)
     gc = F.conv1d(g, _fw(sd, p + ".cond_layer", fold_cache), sd[p + ".cond_layer.bias"])
     for i in range(n_layers):
         dil = dilation_rate ** i
         pad = (ksize * dil - dil) // 2
-        xin = F.conv1d(x, _fw(sd, f"{p}.in_layers.{i}", fold_cache), sd[f"{p}.in_layers.{i}.bias"],
+        xin = F.conv1d(q(x), q(_fw(sd, f"{p}.in_layers.{i}", fold_cache)), sd[f"{p}.in_layers.{i}.bias"],
                        padding=pad, dilation=dil)
         a = xin + gc[:, i * 2 * hidden:(i + 1) * 2 * hidden]
-        acts = torch.tanh(a[:, :hidden]) * torch.sigmoid(a[:, hidden:])
-        rs = F.conv1d(acts, _fw(sd, f"{p}.res_skip_layers.{i}", fold_cache), sd[f"{p}.res_skip_layers.{i}.bias"])
+        acts = q(torch.tanh(a[:, :hidden]) * torch.sigmoid(a[:, hidden:]))
+        rs = F.conv1d(acts, q(_fw(sd, f"{p}.res_skip_layers.{i}", fold_cache)), sd[f"{p}.res_skip_layers.{i}.bias"])
         if i < n_layers - 1:
             x = (x + rs[:, :hidden]) * mask
             out = out + rs[:, hidden:]
@@ -336,7 +343,7 @@ def flow_reverse(sd, hp, z_p, y_mask, g, fold_cache=None, flow_dtype="fp32"):
         if hp.use_transformer_flow:
             h = encoder(sd, p + ".enc", h, y_mask, g, hp.n_layers_trans_flow, hp.n_heads, 5, half=(flow_dtype == "fp16"))
         else:
-            h = wn(sd, p + ".enc", h, y_mask, g, hp.n_flow_layer, hp.hidden_channels, 5, 1, fold_cache)
+            h = wn(sd, p + ".enc", h, y_mask, g, hp.n_flow_layer, hp.hidden_channels, 5, 1, fold_cache, half=(flow_dtype == "fp16"))
         m = conv1x1(sd, p + ".post", h) * y_mask
         x1 = (x1 - m) * y_mask
         x = torch.cat([x0, x1], 1)

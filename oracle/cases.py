@@ -34,8 +34,9 @@ CASES = {
     # T >= 64 (several 32-column tiles per row in every kernel, T_y of a few hundred frames); also carries the reference's
     # own reduced-precision runs (dec under bf16 autocast, flow under fp16 autocast) — see AUTOCAST_KEYS
     "mid_b2_t72": dict(hp={}, lengths=[72, 64], languages=[0, 2], sids=[3, 421], seed=0, kw=INFER_KW, autocast=True),
+    # also carries the reference's autocast runs: `flow` here is the ResidualCouplingBlock / WN stack under fp16 autocast
     "wn_b2_t40": dict(hp=dict(use_transformer_flow=False), lengths=[40, 33], languages=[0, 1], sids=[11, 12], seed=0,
-                      kw=INFER_KW),
+                      kw=INFER_KW, autocast=True),
 }
 # cases whose fixture also stores the reference's autocast runs
 AUTOCAST_CASES = [n for n, c in CASES.items() if c.get("autocast")] + ["mix_b2_ragged"]

@@ -89,12 +89,11 @@ def test_random_shapes_vs_oracle(idx):
             S1 = r1["o"].shape[2]
             assert rms(oe[b, 0, :S1] - r1["o"][0, 0]) <= 5e-5, (b, rms(oe[b, 0, :S1] - r1["o"][0, 0]))
     # reduced-precision switches: finite, same path, waveform inside the mode's tolerance
-    if c["tf"]:
-        m.set_flow_dtype(torch.float16)
-        o16, attn16, _, (z16, *_rest) = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), w_ceil=ref["w_ceil"], **kw)
-        assert torch.equal(attn16.cpu(), ref["attn"]) and torch.isfinite(o16).all()
-        assert rms((z16.cpu() - ref["z"]) * ym) <= 5e-3 * max(rms(ref["z"] * ym), 1e-3)
-        assert rms((o16.cpu() - ref["o"])[vm]) <= 1e-3
+    m.set_flow_dtype(torch.float16)                  # both flow variants (transformer / WN) have an fp16 form
+    o16, attn16, _, (z16, *_rest) = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), w_ceil=ref["w_ceil"], **kw)
+    assert torch.equal(attn16.cpu(), ref["attn"]) and torch.isfinite(o16).all()
+    assert rms((z16.cpu() - ref["z"]) * ym) <= 5e-3 * max(rms(ref["z"] * ym), 1e-3)
+    assert rms((o16.cpu() - ref["o"])[vm]) <= 1e-3
     m.set_generator_dtype(torch.bfloat16)
     ob = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), w_ceil=ref["w_ceil"], **kw)[0]
     assert torch.isfinite(ob).all()
