@@ -119,7 +119,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   if (have_tile) {
     issue_k((kt0 + wid) * AK);
   }
-  const float mi = iok ? mp[iq] : 0.f;
+  // the query's mask value: loaded unconditionally (clamped) and selected after the staging barrier — as `iok ? mp[iq] : 0` the load sat
+  // in a branch that ended with s_waitcnt vmcnt(0), i.e. the whole K tile's round trip BEFORE the query loads were even issued
+  const float mi_raw = mp[iok ? iq : T - 1];
   // query tile and Ev -> LDS (all threads)
   constexpr int QP = D + 8;                         // fp16 row pitch of the transposed query tile (odd multiple of 16 B)
   _Float16* Qh = reinterpret_cast<_Float16*>(Qs);   // F16: [AQ][QP], row i holds Q[2(8t+e)+lh][i] at t*16 + lh*8 + e
@@ -134,6 +136,34 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       e = e < D * AQ ? e : D * AQ - 1;
       qv[q] = qp[(e >> 5) * ld + i0 + (e & 31)];    // columns beyond T: finite-or-not garbage, dead columns below
     }
+    // ... and so are the relative-value table and the relative-key logit rows of the tile (ISA of round 2: each `for (e = tid; ...)
+    // LDS[e] = global[e]` loop iteration was a load -> s_waitcnt vmcnt(0) -> ds_write of its own, four serial round trips behind the
+    // query tile's: most of the 7k-cycle staging phase of a workgroup that lives 36-60k cycles)
+    constexpr int EVPT = ((2 * AMAXW + 1) * D + NT - 1) / NT, QEPT = ((2 * AMAXW + 1) * AQ + NT - 1) / NT;
+    float evv[EVPT], qev[QEPT];
+#pragma unroll
+    for (int q = 0; q < EVPT; ++q) {
+      int e = tid + q * NT;
+      e = e < NR * D ? e : NR * D - 1;
+      evv[q] = A.erv[e];
+    }
+#pragma unroll
+    for (int q = 0; q < QEPT; ++q) {
+      int e = tid + q * NT;
+      e = e < NR * AQ ? e : NR * AQ - 1;
+      const int ic = i0 + (e & 31) < T ? i0 + (e & 31) : T - 1;
+      qev[q] = qe[(e >> 5) * ld + ic];
+    }
+#pragma unroll
+    for (int q = 0; q < EVPT; ++q) {
+      const int e = tid + q * NT;
+      if (e < NR * D) Ev[e] = evv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < QEPT; ++q) {
+      const int e = tid + q * NT;
+      if (e < NR * AQ) Qe[e] = (i0 + (e & 31) < T) ? qev[q] : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
       const int e = tid + q * NT;
@@ -147,16 +177,12 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       }
     }
   }
-  for (int e = tid; e < NR * D; e += NT) Ev[e] = A.erv[e];
-  // the 2W+1 relative-key logit rows of the tile's queries: staged once.  (Read from global inside the softmax loop they were a
+  // (the 2W+1 relative-key logit rows of the tile's queries are staged once: read from global inside the softmax loop they were a
   // dependent load per in-band element — up to 9 serial round trips in the wave that owns the diagonal tile, which every other
-  // wave of the workgroup then waited for at the merge barrier: tools/timeline.py, 12-16k cycles of a 62k-cycle workgroup.)
-  for (int e = tid; e < NR * AQ; e += NT) {
-    const int r = e >> 5, i = e & 31;
-    Qe[e] = (i0 + i < T) ? qe[r * ld + i0 + i] : 0.f;
-  }
+  // wave of the workgroup then waited for at the merge barrier: tools/timeline.py, 12-16k cycles of a 62k-cycle workgroup)
   __syncthreads();
   if (A.dbg) ts1 = __builtin_amdgcn_s_memtime();
+  const float mi = iok ? mi_raw : 0.f;
 
   f32x16 O[DT];
 #pragma unroll

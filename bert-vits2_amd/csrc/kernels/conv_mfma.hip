@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
     by = rest / per_xcd;
     bx = ((rest - by * per_xcd) << 3) | xcd;                    // decoded below exactly like the default form
   }
-  const ConvProb& P = L.p[pz];
+  const ConvProb P = L.p[pz];                    // BY VALUE: the descriptor's scalar loads are issued together, here (see the split-K kernel)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,18 +299,28 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
     const float* const biasp = P.bias;
     const float* const bias2p = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
     const float* const omaskp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : nullptr;
+    // bias vectors: a missing one reads a valid dummy address and is masked to +0.0 bit-wise, so that all 32 loads of a lane are
+    // unconditional and in flight together.  As `biasp ? biasp[row] : 0` + `if (bias2p) v += bias2p[row]` every row was a pair of
+    // loads followed by s_waitcnt vmcnt(0): 16 SERIAL memory round trips at the start of every workgroup's epilogue (ISA of round 2;
+    // tools/timeline.py: epilogue 9-18k cycles of an 80-175k-cycle workgroup)
+    const float* const b1p = biasp ? biasp : P.w;
+    const float* const b2p = bias2p ? bias2p : P.w;
+    const unsigned m_b1 = biasp ? 0xffffffffu : 0u, m_b2 = bias2p ? 0xffffffffu : 0u;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;       // this lane's rows: row0 + (r & 3) + 8 * (r >> 2)
-      float bs[16];
+      float bs[16], bs2[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int row = row0 + (r & 3) + 8 * (r >> 2);
         row = row < cout ? row : cout - 1;                            // clamped: the load is unconditional, the store is not
-        float v = biasp ? biasp[row] : 0.f;
-        if (bias2p) v += bias2p[row];
-        bs[r] = v;
+        bs[r] = ld_off(b1p, m_b1 ? 4u * (unsigned)row : 0u);
+        bs2[r] = ld_off(b2p, m_b2 ? 4u * (unsigned)row : 0u);
       }
+      // (combined at their use below: the residual loads of the tile are issued first, one round trip for both)
+      auto bsum = [&](int r) __attribute__((always_inline)) {
+        return __uint_as_float(__float_as_uint(bs[r]) & m_b1) + __uint_as_float(__float_as_uint(bs2[r]) & m_b2);
+      };
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
@@ -322,7 +332,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            const float a = acc[mi][ni][r] + bs[r], sg = acc[mi][ni][r + 8] + bs[r + 8];
+            const float a = acc[mi][ni][r] + bsum(r), sg = acc[mi][ni][r + 8] + bsum(r + 8);
             const float v = tanhf(a) * (1.f / (1.f + expf(-sg)));
             if (colok && row0 + dr + 16 < cout) outb[goff0 + (unsigned)dr * o_rs] = v;
           }
@@ -341,7 +351,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dr = (r & 3) + 8 * (r >> 2);
-          float v = acc[mi][ni][r] + bs[r];
+          float v = acc[mi][ni][r] + bsum(r);
           if (act == ACT_RELU) v = fmaxf(v, 0.f);
           else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
           if (mask_pre) v *= om;
@@ -391,7 +401,10 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const int z = rem % L.ksplit; rem /= L.ksplit;
   const int mt = rem % mtiles; rem /= mtiles;
   const int b = rem % L.B; rem /= L.B;
-  const ConvProb& P = L.p[rem];
+  // The problem descriptor BY VALUE: every field's scalar load is issued here, together (one kernarg round trip).  Through a
+  // reference the loads sat at their first uses — ~15 dependent s_load / s_waitcnt pairs spread over the prologue (ISA of round 2)
+  // in front of the first global load of a kernel whose whole life is ~14k cycles.
+  const ConvProb P = L.p[rem];
   const int m0 = mt * 32, t0 = nt * 32;
   if (m0 >= P.cout_pad) return;
 
@@ -417,8 +430,9 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const unsigned w_unit = w_tap * (unsigned)k;                      // bytes between consecutive channel groups
   const unsigned w_lane = 16u * (unsigned)(lh * 32 + l31) + (unsigned)mt * (unsigned)groups * w_unit;   // this m-tile's stream
   // channel groups of this (slice z, wave wid): contiguous range, balanced
-  const int nsl = L.ksplit * NWV, sl = z * NWV + wid;
-  const int g0 = (int)(((int64_t)groups * sl) / nsl), g1 = (int)(((int64_t)groups * (sl + 1)) / nsl);
+  // (32-bit: groups * slices < 2^31; the 64-bit form was three ~130-instruction software divisions in the prologue)
+  const unsigned nsl = (unsigned)(L.ksplit * NWV), sl = (unsigned)(z * NWV + wid);
+  const int g0 = (int)(((unsigned)groups * sl) / nsl), g1 = (int)(((unsigned)groups * (sl + 1u)) / nsl);
   const int U = (g1 - g0) * k;                   // units of (group, tap) = 4 MFMAs each
 
   f32x16 acc, acc2;                               // two accumulators on alternate K steps: see conv1d_mfma_kernel
@@ -483,28 +497,29 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const float om = (P.out_mask && colok) ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
   const unsigned coff = (unsigned)(colok ? col : 0) * o_ts + o_to;
   constexpr int RPP = 2 * NWV;                      // rows per pass (one element per thread per pass)
-  float rvv[32 / RPP], bsv[32 / RPP];
+  float rvv[32 / RPP], bsv[32 / RPP], b2v[32 / RPP];
 #pragma unroll
   for (int i = 0; i < 32 / RPP; ++i) {
     const int rl = (tid >> 5) + RPP * i;
     int row = m0 + rl;
     row = row < cout ? row : cout - 1;
-    float bsum = biasp ? biasp[row] : 0.f;
-    if (bias2p) bsum += bias2p[row];
-    bsv[i] = bsum;
+    bsv[i] = biasp ? biasp[row] : 0.f;
+    b2v[i] = bias2p ? bias2p[row] : 0.f;          // summed in the epilogue: an add here makes the load wait for itself
     rvv[i] = resb ? ld_off(resb, 4u * ((unsigned)row * o_rs + coff)) : 0.f;
   }
   // ---- LDSX: stage the workgroup's X tile.  Row rr = wid + NWV*i of the tile is channel 8*G0 + rr; lane = column.
-  const int G0 = (int)(((int64_t)groups * (z * NWV)) / nsl);
+  const int G0 = (int)(((unsigned)groups * (unsigned)(z * NWV)) / nsl);
   float* const Xs = red_raw;
   if (LDSX) {
-    const int G1 = (int)(((int64_t)groups * ((z + 1) * NWV)) / nsl);
+    const int G1 = (int)(((unsigned)groups * (unsigned)((z + 1) * NWV)) / nsl);
     const int nrows = 8 * (G1 - G0);
     const int XW = 32 + (k - 1) * dil;
     const int t = t0 - P.pad_left + lane;
     const bool tok = lane < XW && t >= 0 && t < Lin;
     const unsigned tcl = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
-    const float cs = tok ? (MASK ? in_scale * ld_off(mp, tcl) : in_scale) : 0.f;
+    // the mask value is loaded UNCONDITIONALLY (clamped address) and only used after the X loads are in flight: inside the
+    // `tok ? ... : 0` select it was a load + s_waitcnt vmcnt(0) of its own — one exposed memory round trip per masked launch
+    const float mval = MASK ? ld_off(mp, tcl) : 1.f;
     float xv[SK_RPW];
 #pragma unroll
     for (int i = 0; i < SK_RPW; ++i) {
@@ -512,6 +527,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
       row = row < cin ? row : cin - 1;
       xv[i] = ld_off(xp, (unsigned)row * x_rs4 + tcl);
     }
+    const float cs = tok ? in_scale * mval : 0.f;
 #pragma unroll
     for (int i = 0; i < SK_RPW; ++i) {
       const int rr = wid + NWV * i;
@@ -596,7 +612,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
 #pragma unroll
           for (int w = 0; w < NWV; w += 4)
             vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
-          vs[i] = vv + bsv[i];
+          vs[i] = vv + (bsv[i] + b2v[i]);
         }
 #pragma unroll
         for (int i = 0; i < 16 / RPP; ++i) {
@@ -614,7 +630,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
 #pragma unroll
       for (int w = 0; w < NWV; w += 4)
         vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
-      vv += bsv[i];
+      vv += bsv[i] + b2v[i];
       if (act == ACT_RELU) vv = fmaxf(vv, 0.f);             // host guarantees act == NONE when ksplit > 1
       else if (act == ACT_GELU) vv = 0.5f * vv * (1.0f + erff(vv * 0.70710678118654752440f));
       if (mask_pre) vv *= om;

@@ -92,32 +92,41 @@ __global__ void __launch_bounds__(64 * NU) dds_layer_kernel(const DdsArgs A) {
       const int tt = t + (j - 1) * A.dil;
       const bool ok = tok && tt >= 0 && tt < T;
       tt3[j] = ok ? tt : tcl;
-      mk3[j] = ok ? maskb[tt3[j]] : 0.f;
+      const float mv = maskb[tt3[j]];                 // unconditional (tt3 is a valid index), selected afterwards
+      mk3[j] = ok ? mv : 0.f;
     }
-    float z3[3] = {0.f, 0.f, 0.f};
-    if (A.pre_w) {
-      const float* zr = A.z + ((int64_t)b * 2 + A.z_src) * T;
+    float z3[3];
+    {
+      const float* zr = A.pre_w ? A.z + ((int64_t)b * 2 + A.z_src) * T : maskb;   // no ConvFlow.pre: valid dummy, values unused
 #pragma unroll
       for (int j = 0; j < 3; ++j) z3[j] = zr[tt3[j]];
     }
+    // all loads of the four channel groups first, arithmetic after: with the `pre_w ?` branch inside the unrolled channel loop
+    // every iteration was a basic block of its own ending in s_waitcnt vmcnt(0) — five serial memory round trips per layer
+    // launch (ISA of round 2)
+    float x3[4][3], dw[4][3], db[4], pw[4], pb[4];
+    const bool has_pre = A.pre_w != nullptr;
+    const float* const src = (has_pre ? A.g : A.x) + (int64_t)b * C * T;
+    const float* const pwp = has_pre ? A.pre_w : A.dwb;            // no ConvFlow.pre: any valid vector, values unused
+    const float* const pbp = has_pre ? A.pre_b : A.dwb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = cg + CG * i;
-      float x3[3];
-      if (A.pre_w) {
-        const float pw = A.pre_w[c], pb = A.pre_b[c];
-        const float* gp = A.g + ((int64_t)b * C + c) * T;
+      const float* xp = src + (int64_t)c * T;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) x3[j] = pw * z3[j] + pb + gp[tt3[j]];
-      } else {
-        const float* xp = A.x + ((int64_t)b * C + c) * T;
+      for (int j = 0; j < 3; ++j) { x3[i][j] = xp[tt3[j]]; dw[i][j] = A.dww[c * 3 + j]; }
+      db[i] = A.dwb[c]; pw[i] = pwp[c]; pb[i] = pbp[c];
+    }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) x3[j] = xp[tt3[j]];
+    for (int i = 0; i < 4; ++i) {
+      if (has_pre) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) x3[i][j] = pw[i] * z3[j] + pb[i] + x3[i][j];
       }
-      xc[i] = x3[1];
-      float acc = A.dwb[c];
+      xc[i] = x3[i][1];
+      float acc = db[i];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc += A.dww[c * 3 + j] * (x3[j] * mk3[j]);
+      for (int j = 0; j < 3; ++j) acc += dw[i][j] * (x3[i][j] * mk3[j]);
       v[i] = acc;
     }
   }

@@ -80,24 +80,27 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
       }
     }
   } else if constexpr (MODE == 0) {
+    // every slab element AND the residual of this thread are loaded before the first add: written as `x += slab[sl]` the compiler
+    // issued the loads in batches of 16 with a full s_waitcnt between them (ISA of round 2: 3 serial round trips for 8 slabs, a 4th
+    // for the residual) — most of this kernel's life, which is one memory latency otherwise
+    float xs[CPT][NSLAB], ad[CPT];
+    const float* dp = (A.add ? A.add : A.a) + base;         // no residual: any valid address, result unused
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       int c = ty + i * LN_G;
       if (GUARD) c = c < C ? c : C - 1;
       const int off = c * T + tcl;
-      float x = ap[off];
 #pragma unroll
-      for (int sl = 1; sl < NSLAB; ++sl) x += ap[(int64_t)sl * A.slab_stride + off];
-      v[i] = x;
+      for (int sl = 0; sl < NSLAB; ++sl) xs[i][sl] = ap[(int64_t)sl * A.slab_stride + off];
+      ad[i] = dp[off];
     }
-    if (A.add) {
-      const float* dp = A.add + base;
+    const bool has_add = A.add != nullptr;
 #pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        int c = ty + i * LN_G;
-        if (GUARD) c = c < C ? c : C - 1;
-        v[i] += dp[c * T + tcl];
-      }
+    for (int i = 0; i < CPT; ++i) {
+      float x = xs[i][0];
+#pragma unroll
+      for (int sl = 1; sl < NSLAB; ++sl) x += xs[i][sl];
+      v[i] = has_add ? x + ad[i] : x;
     }
   } else {
     // depthwise k=3 conv with dilation: taps at t-dil, t, t+dil; zero padding; input pre-multiplied by in_mask

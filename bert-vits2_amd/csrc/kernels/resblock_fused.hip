@@ -220,15 +220,35 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     rf_gemm(acc, P.w1, w_lane, groups, k, Xs, RF_XP, 32 * wid + l31, dil, lh);
+    // conv1's 16 bias rows into registers in ONE batch before the first LDS store: read as P.b1[row] inside the store loop, every
+    // row re-loaded the pointer from the kernarg segment (the store in between may alias it, as far as the compiler knows) and
+    // waited for its own load — 16 serial s_load + global_load round trips between the two GEMMs of every workgroup (ISA of
+    // round 2).  (Loaded before the GEMM they would cost 16 registers across it: 140 in all, one workgroup per CU instead of two.)
+    // Two batches of 8, not one of 16: 16 values in flight put the kernel at 129 registers — one over the 128 that let two workgroups
+    // share a CU — and squeezing it back with __launch_bounds__(512, 4) spilled two registers to scratch, which costs far more than
+    // it saves: a kernel with a scratch segment drains the queue at dispatch (config 2: 4.59 -> 4.84 ms per step with this one
+    // kernel spilling, while the sum of kernel times FELL by 0.12 ms).
+    const float* const b1p = P.b1;
     const int t = t0 - RF_LEAD + 32 * wid + l31;
     const bool tin = t >= 0 && t < Lv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < C) {
-        float v = acc[r] + P.b1[row];
-        v = v < 0.f ? v * slope : v;
-        Tm[row * RF_TP + 32 * wid + l31] = tin ? v : 0.f;
+    for (int hb = 0; hb < 2; ++hb) {
+      float b1v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int row = (r & 3) + 8 * ((r + 8 * hb) >> 2) + 4 * lh;
+        row = row < C ? row : C - 1;
+        b1v[r] = rf_ld(b1p, 4u * (unsigned)row);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int rr = r + 8 * hb;
+        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+        if (row < C) {
+          float v = acc[rr] + b1v[r];
+          v = v < 0.f ? v * slope : v;
+          Tm[row * RF_TP + 32 * wid + l31] = tin ? v : 0.f;
+        }
       }
     }
   }
@@ -267,7 +287,8 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
     const int t = t0 + 32 * wid + l31;
     if (t < L) {
       // pointers and the 16 bias / residual values into registers BEFORE the first store: P lives in the kernarg segment and is
-      // re-loaded after every global store otherwise (see conv_mfma.hip's epilogue)
+      // re-loaded after every global store otherwise (see conv_mfma.hip's epilogue).  (Loading them before the GEMM instead — under
+      // its MFMAs — costs 32 registers across it: 156 in all, one workgroup per CU instead of two.)
       float* const op = P.out + (int64_t)b * C * L;
       const float* const b2p = P.b2;
       float bv[16], xv[16];
