@@ -534,7 +534,9 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
       float x = xv[i];
       const float xn = x * slope;
       x = (lrelu && x < 0.f) ? xn : x;
-      if (rr < nrows) Xs[rr * SK_XP + lane] = (8 * G0 + rr < cin) ? x * cs : 0.f;
+      // unconditional: the tile is allocated for SK_RPW rows per wave, rows >= nrows are never read.  Behind `if (rr < nrows)` every
+      // store was a basic block of its own and the compiler SANK the row's global load into it (load -> s_waitcnt vmcnt(0) -> store)
+      Xs[rr * SK_XP + lane] = (rr < nrows && 8 * G0 + rr < cin) ? x * cs : 0.f;
     }
   }
 #pragma unroll
@@ -787,7 +789,8 @@ template <bool MASK, bool LDSX>
 static void launch_splitk_nw(hipStream_t stream, const ConvLaunch& L, int nw, dim3 grid, int mtiles, int ntiles, int per_xcd,
                              int total, int stage_rows) {
   size_t lds = sizeof(float) * (size_t)nw * 32 * 33;
-  if (LDSX && sizeof(float) * (size_t)stage_rows * SK_XP > lds) lds = sizeof(float) * (size_t)stage_rows * SK_XP;
+  if (LDSX) lds = sizeof(float) * (size_t)nw * SK_RPW * SK_XP;     // every wave stores its SK_RPW rows unconditionally (>= the reduce buffer)
+  (void)stage_rows;
   if (nw == 16) {
     auto kern = conv1d_splitk_kernel<MASK, 16, LDSX>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -337,23 +337,40 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
       }
     }
   } else {
+    // every problem field, the four bias float4 and the NI mask values into registers BEFORE the first store (after a global store
+    // the compiler re-loads P.* from the kernarg segment and, in the loop form, waited for each bias load: (ni, g) serial round trips)
     uint16_t* outp = static_cast<uint16_t*>(P.out) + (int64_t)b * P.out_bstride;
+    const float* const biasp = P.bias;
+    const float* const omp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : nullptr;
+    const bool relu = P.act == ACT_RELU, masked = P.mask_pre || P.mask_post;
+    const int Lout = L.L;
+    f32x4 bvv[4];
+    float omv[NI];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int co = mt * 32 + 8 * g + 4 * lh;
+      co = co + 4 <= cout ? co : 0;
+      bvv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (biasp) bvv[g] = *reinterpret_cast<const f32x4*>(biasp + co);
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int t = t0 + ni * 32 + l31;
-      if (t >= L.L) continue;
-      const float om = P.out_mask ? P.out_mask[(int64_t)b * P.out_mask_bstride + t] : 1.f;
+      omv[ni] = omp ? omp[t < Lout ? t : Lout - 1] : 1.f;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int t = t0 + ni * 32 + l31;
+      if (t >= Lout) continue;
+      const float om = omv[ni];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int co = mt * 32 + 8 * g + 4 * lh;
         if (co >= cout) continue;
         float v0 = acc[ni][4 * g], v1 = acc[ni][4 * g + 1], v2 = acc[ni][4 * g + 2], v3 = acc[ni][4 * g + 3];
-        if (P.bias) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + co);
-          v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
-        }
-        if (P.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        if (P.mask_pre || P.mask_post) { v0 *= om; v1 *= om; v2 *= om; v3 *= om; }
+        v0 += bvv[g].x; v1 += bvv[g].y; v2 += bvv[g].z; v3 += bvv[g].w;
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        if (masked) { v0 *= om; v1 *= om; v2 *= om; v3 *= om; }
         u32x2 o;
         o.x = h_pack(v0, v1); o.y = h_pack(v2, v3);
         *reinterpret_cast<u32x2*>(outp + (int64_t)t * cout + co) = o;

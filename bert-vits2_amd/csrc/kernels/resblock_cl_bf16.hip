@@ -186,9 +186,18 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-    rb_gemm<NI, C / 16, PITCH>(acc, ring, U, Upad, XA + (RB_G + row0 - half * dil) * PITCH + lh * 8, dil);
+    // this conv's bias (NG float4 per lane) goes in flight BEFORE the GEMM and lands under its MFMAs.  Loaded inside the (ni, g)
+    // loop below, between LDS stores, every iteration waited for its own load: NI*NG serial round trips per conv, 6 convs per
+    // workgroup, with every wave of the workgroup in its epilogue at the same time (ISA of round 2) — a large part of what looked
+    // like an LDS-bandwidth bound on this kernel
+    f32x4 bvv[NG];
     {
       const float* bias = P.bias + (2 * d) * 32;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bvv[g] = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * lh);
+    }
+    rb_gemm<NI, C / 16, PITCH>(acc, ring, U, Upad, XA + (RB_G + row0 - half * dil) * PITCH + lh * 8, dil);
+    {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int row = row0 + 32 * ni;
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
         const bool inside = t >= 0 && t < Lseq;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * lh);
+          const f32x4 bv = bvv[g];
           float v0 = acc[ni][4 * g] + bv.x, v1 = acc[ni][4 * g + 1] + bv.y, v2 = acc[ni][4 * g + 2] + bv.z,
                 v3 = acc[ni][4 * g + 3] + bv.w;
           // t = bf16(conv1 + b1); conv2's operand = bf16(lrelu(t))
@@ -215,9 +224,13 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-    rb_gemm<NI, C / 16, PITCH>(acc, ring, U, Upad, TA + (RB_G + row0 - half) * PITCH + lh * 8, 1);
     {
       const float* bias = P.bias + (2 * d + 1) * 32;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bvv[g] = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * lh);
+    }
+    rb_gemm<NI, C / 16, PITCH>(acc, ring, U, Upad, TA + (RB_G + row0 - half) * PITCH + lh * 8, 1);
+    {
       const bool last = d + 1 == nd;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -227,7 +240,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_cl_bf16_kernel(const RbClLau
         const bool store = t >= t0 && t < t0 + TT && t < Lseq;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * lh);
+          const f32x4 bv = bvv[g];
           const float v0 = acc[ni][4 * g] + bv.x + xr[ni][g][0], v1 = acc[ni][4 * g + 1] + bv.y + xr[ni][g][1],
                       v2 = acc[ni][4 * g + 2] + bv.z + xr[ni][g][2], v3 = acc[ni][4 * g + 3] + bv.w + xr[ni][g][3];
           u32x2 q;
