@@ -288,32 +288,6 @@ conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
   // land in LDS after it; a piece loop that loads and stores one 16-byte piece per iteration serialises EPI_PIECES global round
   // trips (measured: +12k cycles per workgroup on every convs2 launch).
   constexpr int EPI_PIECES = (BT * (WGC / 8) + NT - 1) / NT;      // 16-byte pieces per thread of a full [BT][WGC] tile
-  // The bias (+ per-batch bias) of this lane's channels: 4*MI float4 loads, issued HERE in one batch.  Inside the accumulator loop
-  // below — `if (P.bias) bv = *(P.bias + co)` between LDS stores — every (time tile, channel group) iteration re-loaded the
-  // pointer from the kernarg segment (the LDS store may alias it, for all the compiler knows) and waited for its own load: 16
-  // serial scalar + vector round trips per wave in EVERY workgroup's epilogue (ISA of round 2; tools/timeline.py had the epilogue
-  // at 17-25k cycles next to a 20k-cycle GEMM).
-  f32x4 bvv[MI][4];
-  {
-    const float* const b1 = P.bias;
-    const float* const b2 = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
-    f32x4 wv[MI][4];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int co = cg * WGC + (wn * MI + mi) * 32 + 8 * g + 4 * lh;
-        co = co + 4 <= cout ? co : 0;             // beyond the problem's channels: any valid address, value unused
-        bvv[mi][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wv[mi][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (b1) bvv[mi][g] = *reinterpret_cast<const f32x4*>(b1 + co);
-        if (b2) wv[mi][g] = *reinterpret_cast<const f32x4*>(b2 + co);
-      }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bvv[mi][g] = bvv[mi][g] + wv[mi][g];
-  }
   const uint16_t* const resp = P.res;
   u32x4 rv[EPI_PIECES];
   if (resp) {
@@ -327,6 +301,31 @@ conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
       rv[i] = *reinterpret_cast<const u32x4*>(rg + (int64_t)r * cout + c * 8);
     }
   }
+  // The bias of this lane's channels: 4*MI float4 loads, issued HERE in one batch behind the residual's (both fly while the slower
+  // waves finish their GEMM; nothing reads them before the barriers below).  Inside the accumulator loop — `if (P.bias) bv = *(P.bias
+  // + co)` between LDS stores — every (time tile, channel group) iteration re-loaded the pointer from the kernarg segment (the LDS
+  // store may alias it, for all the compiler knows) and waited for its own load: 16 serial scalar + vector round trips per wave in
+  // EVERY workgroup's epilogue (ISA of round 2; tools/timeline.py had the epilogue at 17-25k cycles next to a 20k-cycle GEMM).
+  // The per-batch bias (conv_pre's launch only) stays a load in the loop.
+  // (Only for one accumulator row block per wave: with MI = 2 — the C = 64 stage's <1x8,2x2> tile — the 32 extra live registers
+  // changed the allocation of the whole kernel, 167 -> 136, and that variant ran 20 % SLOWER in a same-box A/B of the two builds,
+  // tools/ab_build.py; it keeps the loads in the loop.)
+  constexpr bool HB = MI == 1;
+  f32x4 bvv[MI][4];
+  if constexpr (HB) {
+    const float* const b1 = P.bias ? P.bias : reinterpret_cast<const float*>(P.w);     // no bias: valid dummy, masked below
+    const bool has_b1 = P.bias != nullptr;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int co = cg * WGC + (wn * MI + mi) * 32 + 8 * g + 4 * lh;
+        co = (co + 4 <= cout && has_b1) ? co : 0;
+        bvv[mi][g] = *reinterpret_cast<const f32x4*>(b1 + co);
+      }
+  }
+  const float bsel = P.bias != nullptr ? 1.f : 0.f;   // applied at the use: a select here would have to wait for the loads
+  const float* const bias2p = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
   __syncthreads();                                // every wave is done reading the input tile
   if (resp) {
     const int npc = rows * ppr;
@@ -354,7 +353,16 @@ conv_cl_bf16_kernel(const ClLaunch L, const int ngrp) {
           const int co = ch0 + cl;
           if (co >= cout) continue;
           float v0 = acc[mi][ni][4 * g], v1 = acc[mi][ni][4 * g + 1], v2 = acc[mi][ni][4 * g + 2], v3 = acc[mi][ni][4 * g + 3];
-          v0 += bvv[mi][g].x; v1 += bvv[mi][g].y; v2 += bvv[mi][g].z; v3 += bvv[mi][g].w;
+          if constexpr (HB) {
+            if (bsel != 0.f) { v0 += bvv[mi][g].x; v1 += bvv[mi][g].y; v2 += bvv[mi][g].z; v3 += bvv[mi][g].w; }
+          } else if (P.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + co);
+            v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+          }
+          if (HB ? bias2p != nullptr : P.bias2 != nullptr) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>((HB ? bias2p : P.bias2 + (int64_t)b * P.bias2_bstride) + co);
+            v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+          }
           unsigned short* slot = xs + tr * OP + cl;
           if (resp) {
             const u32x2 rr = *reinterpret_cast<const u32x2*>(slot);

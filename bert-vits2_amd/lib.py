@@ -163,7 +163,15 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if not os.path.exists(_build.LIB):
         raise RuntimeError(f"{_build.LIB} is missing: the HIP extension must be built (python -m bert_vits2_amd.build); "
                            "there is no CPU fallback")
-    lib = C.CDLL(_build.LIB)
+    path = _build.LIB
+    alt = os.environ.get("BV2_AB_LIBRARY")
+    if alt:
+        # same-box A/B of two BUILDS (tools/ab_build.py): a reference libbv2 built from an older commit, same ABI.  Measurement
+        # tooling only — the product loads the stamped in-tree library.
+        path = alt if os.path.isabs(alt) else os.path.join(os.path.dirname(_build.LIB), alt)
+        if not os.path.exists(path):
+            raise RuntimeError(f"BV2_AB_LIBRARY={alt}: no such library")
+    lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)         # AttributeError if the .so does not export a declared symbol
         fn.restype = res
