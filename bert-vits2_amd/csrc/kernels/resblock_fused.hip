@@ -39,7 +39,21 @@ constexpr int RF_PD = 8;          // weight prefetch ring depth
 
 // acc += sum over all (group, tap) units of W_unit x B(unit), B read from the LDS tile `bs` (pitch bp) at column
 // col0 + tap * tstep; weights of unit u live at wp + lane offset + u * 1 KB.
-__device__ __forceinline__ void rf_gemm(f32x16& acc, const float* wp, unsigned w_lane, int groups, int k, const float* bs,
+// The weight ring lives OUTSIDE the GEMM: rf_prime puts a conv's first RF_PD units in flight before the phase that precedes it
+// (conv1's before the x tile is staged, conv2's before conv1's epilogue and the barrier), so that the first MFMA of a GEMM never
+// waits for a weight round trip of its own (ISA of round 2: the ring was primed behind the staging barrier).
+struct RfRing { f32x4 ar[RF_PD]; int lu; };
+__device__ __forceinline__ void rf_prime(RfRing& R, const float* wp, unsigned w_lane, int U) {
+  R.lu = 0;
+#pragma unroll
+  for (int i = 0; i < RF_PD; ++i) {
+    const int uc = R.lu < U ? R.lu : U - 1;
+    R.ar[i] = rf_ld4(wp, w_lane + (unsigned)uc * 1024u);
+    ++R.lu;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__device__ __forceinline__ void rf_gemm(f32x16& acc, RfRing& R, const float* wp, unsigned w_lane, int groups, int k, const float* bs,
                                         int bp, int col0, int tstep, int lh) {
   const int U = groups * k;
   // two accumulators on alternate K steps: back-to-back MFMAs on ONE accumulator with anything issued in between stall the
@@ -47,15 +61,13 @@ __device__ __forceinline__ void rf_gemm(f32x16& acc, const float* wp, unsigned w
   f32x16 acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-  f32x4 ar[RF_PD];
-  int lu = 0;
+  f32x4 (&ar)[RF_PD] = R.ar;
+  int& lu = R.lu;
   auto load_unit = [&](int slot) __attribute__((always_inline)) {
     const int uc = lu < U ? lu : U - 1;                           // past the end: re-read the last unit, result unused
     ar[slot] = rf_ld4(wp, w_lane + (unsigned)uc * 1024u);
     ++lu;
   };
-#pragma unroll
-  for (int i = 0; i < RF_PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
   // operands of unit u+1 are read from LDS before unit u's MFMAs are issued (software pipeline, order pinned below)
   int g = 0, j = 0;
   float bq[2][4];
@@ -95,20 +107,22 @@ __device__ __forceinline__ void rf_gemm(f32x16& acc, const float* wp, unsigned w
 // the ordinary fragment-ordered stream, i.e. channels 8(kk >> 1) + 2q + (kk & 1) for q = 0..3; MFMA q therefore pairs it with row
 // 8(kk >> 1) + (kk & 1) + 2q of the LDS tile (any K-index <-> channel assignment works as long as A and B agree).  Half the MFMA
 // cycles per tap of the 32x32x2 form, same number of LDS reads.   D layout: lane (n = l & 15, rg = l >> 4), register r -> row 4 rg + r.
-__device__ __forceinline__ void rf_gemm16(f32x4 (&acc)[2], const float* wp, int k, const float* bs, int bp, int col0, int tstep,
+__device__ __forceinline__ unsigned rf16_wlane(int k, int lane) {
+  const int n = lane & 15, kk = lane >> 4;
+  return 16u * (unsigned)(((kk >> 1) * k * 2 + (kk & 1)) * 32 + n);                       // + tap j * 1 KB
+}
+__device__ __forceinline__ void rf_gemm16(f32x4 (&acc)[2], RfRing& R, const float* wp, int k, const float* bs, int bp, int col0, int tstep,
                                           int lane) {
   const int n = lane & 15, kk = lane >> 4;
-  const unsigned w_lane = 16u * (unsigned)(((kk >> 1) * k * 2 + (kk & 1)) * 32 + n);     // + tap j * 1 KB
+  const unsigned w_lane = rf16_wlane(k, lane);
   const float* b0 = bs + (8 * (kk >> 1) + (kk & 1)) * bp + col0 + n;
-  f32x4 ar[RF_PD];
-  int lu = 0;
+  f32x4 (&ar)[RF_PD] = R.ar;                      // primed by rf_prime(R, wp, rf16_wlane(k, lane), k): one unit per tap
+  int& lu = R.lu;
   auto load_tap = [&](int slot) __attribute__((always_inline)) {
     const int uc = lu < k ? lu : k - 1;                             // past the end: re-read the last tap, result unused
     ar[slot] = rf_ld4(wp, w_lane + (unsigned)uc * 1024u);
     ++lu;
   };
-#pragma unroll
-  for (int i = 0; i < RF_PD; ++i) { load_tap(i); __builtin_amdgcn_sched_barrier(0); }
   float bq[2][4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { bq[0][q][0] = b0[2 * q * bp]; bq[0][q][1] = b0[2 * q * bp + 16]; }
@@ -162,6 +176,9 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
   const float slope = F.slope;
   const float* xp = P.x + (int64_t)b * C * L;
   const unsigned w_lane = 16u * (unsigned)(lh * 32 + l31);
+  RfRing ring;
+  // conv1's first weight units fly while the x tile is staged
+  if constexpr (C16) rf_prime(ring, P.w1, rf16_wlane(k, lane), k); else rf_prime(ring, P.w1, w_lane, groups * k);
 
   // ---- stage lrelu(x) for columns [t0 - LEAD - h1, t0 - LEAD - h1 + TW + 2*h1): wave w owns rows 4w..4w+3
   {
@@ -198,7 +215,8 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
   // ---- phase 1: intermediate columns [32*wid, 32*wid + 32)
   if constexpr (C16) {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    rf_gemm16(acc, P.w1, k, Xs, RF_XP, 32 * wid, dil, lane);
+    rf_gemm16(acc, ring, P.w1, k, Xs, RF_XP, 32 * wid, dil, lane);
+    if (wid < RF_BN / 32) rf_prime(ring, P.w2, rf16_wlane(k, lane), k);
     const int n = lane & 15, rg = lane >> 4;
     float bv[4];
 #pragma unroll
@@ -219,7 +237,8 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    rf_gemm(acc, P.w1, w_lane, groups, k, Xs, RF_XP, 32 * wid + l31, dil, lh);
+    rf_gemm(acc, ring, P.w1, w_lane, groups, k, Xs, RF_XP, 32 * wid + l31, dil, lh);
+    if (wid < RF_BN / 32) rf_prime(ring, P.w2, w_lane, groups * k);   // conv2's first units fly under conv1's epilogue and the barrier
     // conv1's 16 bias rows into registers in ONE batch before the first LDS store: read as P.b1[row] inside the store loop, every
     // row re-loaded the pointer from the kernarg segment (the store in between may alias it, as far as the compiler knows) and
     // waited for its own load — 16 serial s_load + global_load round trips between the two GEMMs of every workgroup (ISA of
@@ -258,7 +277,7 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
   // ---- phase 2: output columns [32*wid, 32*wid + 32) of the tile, waves 0..6
   if (C16 && wid < RF_BN / 32) {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    rf_gemm16(acc, P.w2, k, Tm, RF_TP, RF_LEAD + 32 * wid - h2, 1, lane);
+    rf_gemm16(acc, ring, P.w2, k, Tm, RF_TP, RF_LEAD + 32 * wid - h2, 1, lane);
     const int n = lane & 15, rg = lane >> 4;
     float* const op = P.out + (int64_t)b * C * L;
     const float* const b2p = P.b2;
@@ -283,7 +302,7 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    rf_gemm(acc, P.w2, w_lane, groups, k, Tm, RF_TP, RF_LEAD + 32 * wid + l31 - h2, 1, lh);
+    rf_gemm(acc, ring, P.w2, w_lane, groups, k, Tm, RF_TP, RF_LEAD + 32 * wid + l31 - h2, 1, lh);
     const int t = t0 + 32 * wid + l31;
     if (t < L) {
       // pointers and the 16 bias / residual values into registers BEFORE the first store: P lives in the kernarg segment and is
