@@ -16,7 +16,8 @@ Derived per family:  mfma_util = MFMA_BUSY / (GUI_ACTIVE/8 * 4 SIMDs * 256 CUs) 
 numbers: conv1d_mfma<64x64> 0.525 here vs 82 TF / 157.3 TF = 0.52 from bench.py;  hbm_GBps = (2*FETCH + WRITE) / duration,
 duration from the same trace (End - Start of the dispatch).
 
-    python tools/collect_pmc.py out.json [bench.py args...]
+    python tools/collect_pmc.py out.json [--lds] [--traffic traffic.json] [bench.py args...]
+`--lds` adds a 4th pass (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT): how busy the LDS array is and what conflicts cost.
 """
 import collections, csv, glob, json, os, subprocess, sys, tempfile
 
@@ -67,9 +68,12 @@ def main():
         i = extra.index("--traffic")
         traffic_out = extra[i + 1]
         extra = extra[:i] + extra[i + 2:]
+    lds = "--lds" in extra                        # 4th pass: LDS-array cycles and bank-conflict cycles
+    extra = [a for a in extra if a != "--lds"]
     t1, n1, d1 = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], extra)
     t2, n2, d2 = one_pass(["FETCH_SIZE"], extra)
     t3, n3, d3 = one_pass(["WRITE_SIZE"], extra)
+    t4, n4, d4 = one_pass(["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"], extra) if lds else ({}, {}, {})
     res = {"_method": __doc__.split("Derived")[0].strip(), "_bench_args": extra, "kernels": {}}
     for f in sorted(set(t1) | set(t2) | set(t3)):
         row = dict(launches=n1.get(f, 0))
@@ -104,6 +108,13 @@ def main():
                 row["hbm_GBps"] = round((fb + wb) / secs / 1e9, 1)
                 if gui and row.get("mfma_util_basis") == "GRBM_GUI_ACTIVE / 8":
                     row["effective_clock_GHz"] = round(gui / 8.0 / max(n1[f], 1) / secs / 1e9, 2)
+        if lds and f in t4 and t4[f].get("GRBM_GUI_ACTIVE"):
+            # SQ_LDS_IDX_ACTIVE = cycles the LDS array worked, SQ_LDS_BANK_CONFLICT = the extra cycles conflicts cost
+            # (MI355X_MICROARCH.md, LDS section), both summed over the CUs; kernel cycles = GUI_ACTIVE / 8 as above
+            cyc = t4[f]["GRBM_GUI_ACTIVE"] / 8.0
+            row["lds_active_frac"] = round(t4[f].get("SQ_LDS_IDX_ACTIVE", 0.0) / (cyc * 256), 4)
+            row["lds_bank_conflict_frac_of_lds_cycles"] = round(t4[f].get("SQ_LDS_BANK_CONFLICT", 0.0) / max(t4[f].get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4)
+            row["lds_note"] = "lds_active_frac = SQ_LDS_IDX_ACTIVE / (kernel cycles x 256 CUs): the share of time the LDS array of a CU is busy"
         res["kernels"][f] = row
     json.dump(res, open(out, "w"), indent=1)
     if traffic_out:
