@@ -240,3 +240,16 @@ def test_fp16_flow_streams_and_tap_major_resblock_streams():
                     assert pl2 == pl4 and torch.equal(w2, w4) and torch.equal(b2, b4)
     dims = (C.c_int32 * 4)()
     assert lib.bv2_test_dump_cl_conv(h, C.c_void_p(blob.data_ptr()), 4, 0, 0, 0, 0, dims, None, None) == -2   # wide stage: none
+
+
+def test_no_kernel_on_the_default_path_has_a_scratch_segment():
+    """A kernel that spills registers gets a scratch segment, and a dispatch with a scratch segment drains the queue on this stack: one
+    such kernel (2 spilled registers, 6 launches per step) cost +0.3 ms per 4.6 ms step in round 3 while the sum of kernel times fell.
+    tools/kernel_resources.py --check compiles every kernel source for gfx950 (no GPU needed) and fails on ScratchSize > 0 outside
+    the few variants the default model never launches."""
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--check"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

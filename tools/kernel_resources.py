@@ -41,8 +41,10 @@ def main():
     check = "--check" in sys.argv
     files = args or sorted(glob.glob(os.path.join(KDIR, "*.hip")))
     bad = []
-    for f in files:
-        rows, rc = table(f)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, len(files))) as ex:      # hipcc runs are independent processes
+        results = list(ex.map(table, files))
+    for f, (rows, rc) in zip(files, results):
         if rc:
             print(f"{f}: hipcc failed")
             bad.append(f)
