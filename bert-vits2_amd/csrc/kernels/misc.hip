@@ -79,17 +79,20 @@ __global__ void __launch_bounds__(256) conv_post_c_kernel(const ConvPostArgs A) 
   // main column j = tid, halo column j = 256 + tid (tid < k - 1)
   const int ta = t0 - pad + tid, tb = ta + 256;
   const bool oka = ta >= 0 && ta < Lv, okb = tid < k - 1 && tb >= 0 && tb < Lv;
-  const unsigned ca = (unsigned)(ta < 0 ? 0 : (ta >= Lv ? Lv - 1 : ta)), cb = (unsigned)(tb < 0 ? 0 : (tb >= Lv ? Lv - 1 : tb));
+  // halo loads are UNCONDITIONAL: a thread without a halo column re-reads halo column k - 2 (one broadcast line per wave
+  // instruction, no extra traffic).  Behind `if (tid < k - 1)` the compiler merged the load block with the store block below into
+  // load-pair -> s_waitcnt vmcnt(0) -> store per channel: 16 serial round trips in the one wave every other wave of the workgroup
+  // then waits for at the barrier (ISA of round 2)
+  const int tbc = tid < k - 1 ? tb : t0 - pad + 256 + (k - 2);
+  const unsigned ca = (unsigned)(ta < 0 ? 0 : (ta >= Lv ? Lv - 1 : ta)), cb = (unsigned)(tbc < 0 ? 0 : (tbc >= Lv ? Lv - 1 : tbc));
   float va[C][3], vb[C][3];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     va[c][0] = x0[c * rs + ca]; va[c][1] = x1[c * rs + ca]; va[c][2] = x2[c * rs + ca];
   }
-  if (tid < k - 1) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      vb[c][0] = x0[c * rs + cb]; vb[c][1] = x1[c * rs + cb]; vb[c][2] = x2[c * rs + cb];
-    }
+  for (int c = 0; c < C; ++c) {
+    vb[c][0] = x0[c * rs + cb]; vb[c][1] = x1[c * rs + cb]; vb[c][2] = x2[c * rs + cb];
   }
   for (int i = tid; i < C * k; i += 256) ws[i] = A.w[i];
 #pragma unroll

@@ -477,7 +477,8 @@ class SynthesizerTrn(nn.Module):
             wc = w_ceil.to(dev, torch.float32).reshape(B, T).contiguous()
             enc["w_ceil"] = wc
             enc["y_lengths"] = torch.clamp_min(wc.sum(1), 1).long()
-        Ty = int(enc["y_lengths"].max().item())        # the reference's one host sync (commons.py:120-122)
+        # the reference's one host sync (commons.py:120-122).  One utterance: no reduction kernel in front of the copy.
+        Ty = int(enc["y_lengths"].item()) if B == 1 else int(enc["y_lengths"].max().item())
         if noise_z is not None:                        # None: decode() draws it (in place in the graph's buffer when replaying)
             noise_z = noise_z.to(dev, torch.float32)
         dec = self.decode(enc, noise_z, Ty, noise_scale=noise_scale, max_len=max_len, want_attn=want_attn,
