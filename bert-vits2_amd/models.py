@@ -17,6 +17,7 @@ the built library ``infer()`` raises.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Dict, Optional
 
 import torch
@@ -399,10 +400,20 @@ class SynthesizerTrn(nn.Module):
             assert noise_z.is_cuda and noise_z.dtype == torch.float32 and noise_z.shape[2] >= Ty and noise_z.shape[1] == Ci
         L_dec = Ty if (max_len is None or max_len <= 0 or max_len >= Ty) else int(max_len)
         S = L_dec * hp.total_upsample
-        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         okeys = ("o", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")
-        mk_out = lambda: dict(o=e(B, 1, S), attn=e(B, 1, Ty, T) if want_attn else None, y_mask=e(B, 1, Ty), z=e(B, Ci, Ty),
-                              z_p=e(B, Ci, Ty), m_p=e(B, Ci, Ty), logs_p=e(B, Ci, Ty))
+
+        def mk_out():
+            # ONE allocation carved into the seven outputs: this runs between the reference's host sync and the first launch of
+            # phase B, i.e. with the GPU idle — seven caching-allocator calls there cost ~25 us of a 4.5 ms step at batch 1
+            shapes = dict(o=(B, 1, S), attn=(B, 1, Ty, T) if want_attn else None, y_mask=(B, 1, Ty), z=(B, Ci, Ty), z_p=(B, Ci, Ty),
+                          m_p=(B, Ci, Ty), logs_p=(B, Ci, Ty))
+            sizes = {k: (0 if sh is None else (math.prod(sh) + 63) // 64 * 64) for k, sh in shapes.items()}     # 256-byte aligned views
+            flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=dev)
+            out, off = {}, 0
+            for k, sh in shapes.items():
+                out[k] = None if sh is None else flat[off:off + math.prod(sh)].view(*sh)
+                off += sizes[k]
+            return out
         if self._graphs_on and not self._taps:
             ws = self._workspace(B, T, Ty)
             ikeys = ("m_p", "logs_p", "x_mask", "w_ceil", "y_lengths", "g")
