@@ -182,32 +182,25 @@ __device__ __forceinline__ void cl_gemm_tm(f32x16 (&acc)[MI][NI], const uint16_t
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // B operands are read from LDS PF units ahead of the MFMAs that consume them.  PF = 1 (double buffer) leaves one unit = NI MFMAs =
-  // 32*NI cycles between a ds_read_b128 and its use — about the LDS latency under load with 3 waves per SIMD (the GEMM phase ran at
-  // 1.8-2.0x its MFMA-only time, profiles/r02_timeline.md).  PF = 2 (four rotating buffers, three live) where the registers allow it.
-  constexpr int PF = (MI == 1 && G % 4 == 0) ? 2 : 1;
-  constexpr int NB = PF == 2 ? 4 : 2;
-  bf16x8 bb[NB][NI];
+  // (Round 3: reading the B operands TWO units ahead — four rotating buffers — was measured in a same-box A/B of builds: <4x1> 4.03 ->
+  // 4.05 ms, <8x1> 2.15 -> 2.17 ms per step.  The LDS latency is not what keeps the GEMM phase at 1.8x its MFMA-only time.)
+  bf16x8 bb[2][NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) bb[0][ni] = *reinterpret_cast<const bf16x8*>(xb + ni * 32 * PITCH);
-  if constexpr (PF == 2) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bb[1][ni] = *reinterpret_cast<const bf16x8*>(xb + 16 + ni * 32 * PITCH);
-  }
   const unsigned short* xrow = xb;
   for (int j = 0; j < k; ++j) {
     const unsigned short* xnext = (j + 1 < k) ? xrow + tstep * PITCH : xrow;   // after the last tap: re-read (unused)
     const int step = (j + 2 < k) ? 512 : 0;       // slot s is refilled with (s, j+1); the last tap's unit is not followed
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const unsigned short* xn = (s + PF < G) ? xrow + (s + PF) * 16 : xnext + (s + PF - G) * 16;
+      const unsigned short* xn = (s + 1 < G) ? xrow + (s + 1) * 16 : xnext;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bb[(s + PF) % NB][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * PITCH);
+      for (int ni = 0; ni < NI; ++ni) bb[(s & 1) ^ 1][ni] = *reinterpret_cast<const bf16x8*>(xn + ni * 32 * PITCH);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[s][mi], bb[s % NB][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[s][mi], bb[s & 1][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         ar[s][mi] = *(const GlobalFrag*)(reinterpret_cast<const char*>(wq[s][mi]) + wlane_bytes);
