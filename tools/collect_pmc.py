@@ -73,7 +73,11 @@ def main():
     t1, n1, d1 = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], extra)
     t2, n2, d2 = one_pass(["FETCH_SIZE"], extra)
     t3, n3, d3 = one_pass(["WRITE_SIZE"], extra)
-    t4, n4, d4 = one_pass(["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"], extra) if lds else ({}, {}, {})
+    t4, n4, d4 = one_pass(["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL", "GRBM_GUI_ACTIVE"],
+                          extra) if lds else ({}, {}, {})
+    # 5th pass (with --lds): what the waves wait for — wave-cycles, cycles waiting for anything / for an instruction to issue / for LDS
+    t5, n5, d5 = one_pass(["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"],
+                          extra) if lds else ({}, {}, {})
     res = {"_method": __doc__.split("Derived")[0].strip(), "_bench_args": extra, "kernels": {}}
     for f in sorted(set(t1) | set(t2) | set(t3)):
         row = dict(launches=n1.get(f, 0))
@@ -115,6 +119,17 @@ def main():
             row["lds_active_frac"] = round(t4[f].get("SQ_LDS_IDX_ACTIVE", 0.0) / (cyc * 256), 4)
             row["lds_bank_conflict_frac_of_lds_cycles"] = round(t4[f].get("SQ_LDS_BANK_CONFLICT", 0.0) / max(t4[f].get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4)
             row["lds_note"] = "lds_active_frac = SQ_LDS_IDX_ACTIVE / (kernel cycles x 256 CUs): the share of time the LDS array of a CU is busy"
+            for cname in ("SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL"):
+                if cname in t4[f]:
+                    row[cname.lower() + "_frac_of_kernel_cu_cycles"] = round(t4[f][cname] / (cyc * 256), 4)
+        if lds and f in t5 and t5[f].get("SQ_WAVE_CYCLES"):
+            wc = t5[f]["SQ_WAVE_CYCLES"]
+            row["wave_wait_any_frac"] = round(t5[f].get("SQ_WAIT_ANY", 0.0) / wc, 4)
+            row["wave_wait_inst_any_frac"] = round(t5[f].get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
+            row["wave_wait_inst_lds_frac"] = round(t5[f].get("SQ_WAIT_INST_LDS", 0.0) / wc, 4)
+            row["wave_active_inst_lds_frac"] = round(t5[f].get("SQ_ACTIVE_INST_LDS", 0.0) / wc, 4)
+            row["wave_active_inst_vmem_frac"] = round(t5[f].get("SQ_ACTIVE_INST_VMEM", 0.0) / wc, 4)
+            row["wave_note"] = "fractions of SQ_WAVE_CYCLES (cycles a wave is resident): waiting on any s_waitcnt / on instruction issue / on LDS issue"
         res["kernels"][f] = row
     json.dump(res, open(out, "w"), indent=1)
     if traffic_out:
