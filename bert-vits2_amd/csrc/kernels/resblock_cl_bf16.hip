@@ -42,6 +42,11 @@ __device__ __forceinline__ unsigned rb_pack(float a, float b) {     // round-to-
 __device__ __forceinline__ float rb_lrelu(float v, float slope) { return v < 0.f ? v * slope : v; }
 
 constexpr int RB_G = 32;          // guard rows on each side of the LDS tiles (dilated taps reach <= 25 rows outside)
+// (Round 3, measured and not kept: 4 waves and half the rows per workgroup — R = 384 / 512, 72 / 55 KB of LDS — so that TWO
+// independent workgroups share a CU and one's epilogue overlaps the other's GEMM.  PMC (profiles/r03_e_pmc_c3.json) has this kernel's
+// MFMA pipe busy 0.27-0.28 of the time and its LDS array 0.25 (a fifth of it bank conflicts): neither is the bound, the lock-step
+// GEMM / epilogue / barrier phases of the one resident workgroup are.  But at R = 384 only 264 of the rows are output for k = 11
+// (648 of 768 now), and the extra halo GEMM work ate the overlap: 2.93-2.97 -> 3.02-3.03 ms per step in a same-box A/B of builds.)
 
 struct Ring {
   bf16x8 ar[RBCL_PD];
