@@ -33,8 +33,14 @@ constexpr int RF_BN = 224;        // output columns per tile
 constexpr int RF_TW = 256;        // intermediate columns per tile
 constexpr int RF_LEAD = 16;       // intermediate starts this many columns before the outputs
 constexpr int RF_XS = 5;          // 64-column strips of the staged x tile
-constexpr int RF_XP = RF_XS * 64; // x tile pitch
-constexpr int RF_TP = RF_TW + 4;  // intermediate pitch
+// LDS pitches: both ≡ 16 (mod 32 banks).  The C = 16 path's B operand (rf_gemm16) is read by 16-lane groups that sit on ADJACENT
+// rows (lanes 0-15 row r, lanes 16-31 row r + 1, serviced in one LDS cycle group): with a pitch ≡ 0 (the x tile's 320) or ≡ 4 (the
+// intermediate's 260) the two rows share banks — PMC SQ_LDS_BANK_CONFLICT was 30 % of this kernel's LDS cycles
+// (profiles/r03_e_pmc_c2.json).  The C = 32 path reads one row per lane group: any pitch.  (Same-box A/B of builds: 0.521-0.528 vs
+// 0.517-0.521 ms per step — the conflicts were not what this kernel waits for; the layout stays because it is the right one.)
+constexpr int RF_XW = RF_XS * 64; // staged columns of the x tile
+constexpr int RF_XP = RF_XW + 16; // x tile pitch
+constexpr int RF_TP = RF_TW + 16; // intermediate pitch
 constexpr int RF_PD = 8;          // weight prefetch ring depth
 
 // acc += sum over all (group, tap) units of W_unit x B(unit), B read from the LDS tile `bs` (pitch bp) at column
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(512) resblock_fused_kernel(const FusedLaunch F
 }
 
 bool resblock_fused_supported(int C, int k, int dil) {
-  return C >= 8 && C <= 32 && C % 8 == 0 && k % 2 == 1 && (k - 1) / 2 <= RF_LEAD && RF_TW + (k - 1) * dil <= RF_XP &&
+  return C >= 8 && C <= 32 && C % 8 == 0 && k % 2 == 1 && (k - 1) / 2 <= RF_LEAD && RF_TW + (k - 1) * dil <= RF_XW &&
          RF_LEAD + RF_BN + (k - 1) / 2 <= RF_TW;
 }
 
