@@ -398,6 +398,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   BV2_TRY
   const std::string k = key ? key : "";
   if (k == "fused_resblock") h->no_fused_resblock = value == 0;
+  else if (k == "conv_x6") h->no_conv_x6 = value == 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;
   else if (k == "fused_attn_o") h->no_fused_attn_o = value == 0;
   else if (k == "attn_ksplit") h->attn_ksplit = value;
@@ -477,7 +478,13 @@ static inline int t_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 int64_t bv2_test_conv_pack_floats(int cin, int cout, int k) {
   // + 2048 floats: the register-ring conv kernel prefetches up to 4 units (4 KB) past the last weight unit
-  return (int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048;
+  // + the three split-bf16 planes of conv_x6.hip (tile >= TILE_X6), 6 bytes per weight of the 32-row padded matrix
+  const int64_t base = (int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048;
+  return base + (cin % 32 == 0 ? (x6_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 : 0);
+}
+void bv2_test_x6_split(float v, uint16_t* h3) { x6_split(v, h3); }
+static int64_t t_x6_off(int cin, int cout, int k) {
+  return ((int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048 + 63) / 64 * 64;
 }
 
 int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const float* bias_host, float* out, float* wpack_dev,
@@ -496,6 +503,17 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
           pk[(size_t)conv_w_index(j, ci, co, cin_pad, k)] = w_host[((size_t)co * cin + ci) * k + j];
     const size_t boff = (size_t)k * cin_pad * ld;
     if (w_host && bias_host) for (int co = 0; co < cout; ++co) pk[boff + co] = bias_host[co];
+    const bool x6 = tile >= TILE_X6 && cin % 32 == 0;
+    if (w_host && x6) {
+      uint16_t* wx = reinterpret_cast<uint16_t*>(pk.data() + t_x6_off(cin, cout, k));
+      for (int j = 0; j < k; ++j)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) {
+            uint16_t hh[3];
+            x6_split(w_host[((size_t)co * cin + ci) * k + j], hh);
+            for (int pl = 0; pl < 3; ++pl) wx[x6_w_index(j, ci, co, cin, k, pl)] = hh[pl];
+          }
+    }
     if (w_host && hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
     ConvLaunch cl;
     std::memset(&cl, 0, sizeof(cl));
@@ -504,6 +522,7 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
     p.x_bstride = (int64_t)cin * L; p.x_rstride = L; p.Lin = L;
     p.in_mask = in_mask; p.in_mask_bstride = L; p.out_mask = out_mask; p.out_mask_bstride = L;
     p.w = wpack_dev; p.bias = bias_host ? wpack_dev + boff : nullptr;
+    if (x6) p.w6 = reinterpret_cast<const uint16_t*>(wpack_dev + t_x6_off(cin, cout, k));
     p.bias2 = bias2; p.bias2_bstride = cout;
     p.out = out; p.out_bstride = (int64_t)cout * L; p.out_rstride = L; p.out_tstride = 1; p.out_toff = 0;
     p.res = res; p.res_bstride = p.out_bstride; p.res_mode = res_mode;

@@ -844,12 +844,15 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
           float* cur = S[1 + j];
           float* tmp = S[1 + nb + j];
           const float* xin = d == 0 ? x : cur;
+          const bool x6 = !c.h->no_conv_x6;                       // the split-bf16 planes ride along: launch_conv1d picks conv_x6.hip
           ConvProb p = c.prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
           p.pre_act = PRE_LRELU; p.slope = 0.1f;
+          if (x6 && m.rb[i][j][d][0].wx_off >= 0) p.w6 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off));
           c1.p[jj] = p;
           p = c.prob(m.rb[i][j][d][1], tmp, cur, Lo, 1);
           p.pre_act = PRE_LRELU; p.slope = 0.1f;
           p.res = xin; p.res_mode = RES_ADD;
+          if (x6 && m.rb[i][j][d][1].wx_off >= 0) p.w6 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][1].wx_off));
           c2.p[jj] = p;
         }
         c.conv(c1, "dec.resblock.convs1");

@@ -32,6 +32,7 @@ struct ConvW {
   int64_t w_off = -1, b_off = -1;    // b_off < 0: no bias
   int64_t wb_off = -1;               // Generator convs only: bf16 fragment stream (cl_w_index), offset in floats
   int64_t wh_off = -1;               // flow Encoder convs only: fp16 fragment stream (cl_w_index), offset in floats
+  int64_t wx_off = -1;               // wide Generator ResBlock convs only: three bf16 planes (x6_w_index), offset in floats
 };
 struct VecW { int64_t off = -1; int64_t n = 0; };
 struct GemvW { int cout = 0, cin = 0; int64_t w_off = -1, b_off = -1; };
@@ -122,6 +123,7 @@ struct bv2_handle {
   int gen_dtype = BV2_F32;           // Generator arithmetic: BV2_F32 (conv_mfma.hip) or BV2_BF16 (gen_bf16.hip)
   int flow_dtype = BV2_F32;          // transformer-flow Encoder convs: BV2_F32 (conv_mfma.hip) or BV2_F16 (enc_f16.hip)
   // bv2_set_option switches (tests compare the fused kernels with the layer-wise ones)
+  bool no_conv_x6 = false;           // "conv_x6" = 0: wide Generator convs on the fp32 matrix core (conv_mfma.hip) instead of the bf16x6 form
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
   bool no_fused_attn_o = false;      // "fused_attn_o" = 0: conv_o as its own launch after the attention kernel
   int attn_ksplit = -1;              // "attn_ksplit": key ranges per (head, query tile) of the fused attention; -1 = picked per shape, 0 / 1 = off

@@ -39,6 +39,7 @@ struct ConvProb {
   const float* in_mask;     // [b*in_mask_bstride + t] or null
   int in_mask_bstride;
   const float* w;           // packed weights
+  const uint16_t* w6;       // the same weights as three bf16 planes (x6_w_index; kernels/conv_x6.hip) or null
   const float* bias;        // [cout_pad] or null
   const float* bias2;       // [B][bias2_bstride] per-batch bias or null
   int bias2_bstride;
@@ -80,8 +81,39 @@ int conv_timeline_report(long long* meta, int max_launches);
 unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int tile, int ks, int cin, int L);   // per launch: {offset_u64, gx, gy, gz, tile id, nprob k0 | k1<<8 | k2<<16, cin, L}
 
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
-enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6, TILE_128x64 = 7 };
+enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6, TILE_128x64 = 7,
+       TILE_X6 = 8,            // the split-bf16 form of the LDS-tiled kernel (kernels/conv_x6.hip); TILE_AUTO picks it when every problem has w6
+       TILE_X6_128x64 = 9, TILE_X6_128x128 = 10, TILE_X6_64x128 = 11 };   // tests / tuning: one x6 tile forced
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
+// fp32 conv on the bf16 matrix core (kernels/conv_x6.hip): every fp32 operand is the exact sum of three bf16 values
+// (v = h1 + h2 + h3, 8 + 8 + 8 significand bits), and the product is accumulated from the six largest of the nine cross terms
+// (w1x1, w1x2, w2x1, w1x3, w2x2, w3x1 — the three dropped ones are below 2^-23 of the product, the rounding of an fp32 multiply).
+// Weight planes are split at pack time: element (tap j, ci, co) of plane p lives at x6_w_index(...) of a uint16 stream
+//   [m-tile = co/32][group s = ci/16][tap j][plane p][lane = co%32 + 32*((ci%16)/8)][ci%8]
+// i.e. the A operand of one v_mfma_f32_32x32x16_bf16 per (unit, plane) is one 16-byte load per lane, a unit is 3 KB contiguous.
+inline int64_t x6_w_index(int j, int ci, int co, int cin, int k, int plane) {
+  const int64_t U = (int64_t)(cin / 16) * k, u = (int64_t)(ci / 16) * k + j;
+  const int lane = (co & 31) + 32 * ((ci % 16) / 8);
+  return ((((int64_t)(co >> 5) * U + u) * 3 + plane) * 64 + lane) * 8 + (ci % 8);
+}
+inline int64_t x6_w_elems(int cin, int cout_pad, int k) { return (int64_t)(cout_pad / 32) * (cin / 16) * k * 3 * 512; }
+// v = h[0] + h[1] + h[2] exactly (round-to-nearest-even at every step), as bf16 bit patterns
+inline void x6_split(float v, uint16_t h[3]) {
+  for (int p = 0; p < 3; ++p) {
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    uint16_t b;
+    if ((u & 0x7fffffffu) > 0x7f800000u) b = (uint16_t)((u >> 16) | 0x40u);
+    else { u += 0x7fffu + ((u >> 16) & 1u); b = (uint16_t)(u >> 16); }
+    h[p] = b;
+    const uint32_t w = (uint32_t)b << 16;
+    float f;
+    __builtin_memcpy(&f, &w, 4);
+    v -= f;
+  }
+}
+bool conv_x6_supported(const ConvLaunch& L);        // every problem carries w6 and fits the staged tile
+int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 // true when TILE_AUTO will pick the split-K kernel for this launch (small-N regime); only then may ksplit exceed 1
 bool conv_use_splitk(const ConvLaunch& L);
 // K-split factor (power of two <= max_split) that fills the chip for a split-K launch whose consumer sums the slabs

@@ -50,6 +50,7 @@ struct Packer {
   std::vector<std::string> missing;
   bool emit_bf16 = false;                                  // also write the channels-last bf16 fragment stream (dec.*)
   bool emit_f16 = false;                                   // also write the fp16 fragment stream (flow Encoder convs)
+  bool emit_x6 = false;                                    // also write the three-plane bf16 split of the fp32 weights (conv_x6.hip)
 
   bool fill() const { return blob != nullptr; }
 
@@ -121,6 +122,7 @@ struct Packer {
     c.b_off = bias ? alloc(c.cout_pad) : -1;
     if (emit_bf16 && cin % 16 == 0) c.wb_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (emit_f16 && cin % 16 == 0) c.wh_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
+    if (emit_x6 && cin % 32 == 0) c.wx_off = alloc((x6_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (fill() && ok) {
       for (int j = 0; j < k; ++j)
         for (int ci = 0; ci < cin; ++ci)
@@ -133,6 +135,17 @@ struct Packer {
         for (int j = 0; j < k; ++j)
           for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co) wb[cl_w_index(j, ci, co, cin, k)] = f2bf(src(co, ci, j));
+      }
+      if (c.wx_off >= 0) {
+        // w = h1 + h2 + h3 exactly, one bf16 plane each (x6_split / x6_w_index, bv2_kernels.h)
+        uint16_t* wx = reinterpret_cast<uint16_t*>(blob + c.wx_off);
+        for (int j = 0; j < k; ++j)
+          for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) {
+              uint16_t h[3];
+              x6_split(src(co, ci, j), h);
+              for (int pl = 0; pl < 3; ++pl) wx[x6_w_index(j, ci, co, cin, k, pl)] = h[pl];
+            }
       }
       if (c.wh_off >= 0) {
         uint16_t* wh = reinterpret_cast<uint16_t*>(blob + c.wh_off);
@@ -418,10 +431,13 @@ int pack_all(Model& m, Packer& P) {
     for (int j = 0; j < m.n_rbk; ++j) {
       const int k = c.resblock_kernel_sizes[j];
       const std::string rp = "dec.resblocks." + std::to_string(i * m.n_rbk + j);
+      // wide stages (the ones the LDS-tiled fp32 conv runs): the weights also as the three bf16 planes of conv_x6.hip
+      P.emit_x6 = ch >= 64 && ch % 32 == 0;
       for (int d = 0; d < m.n_rbd; ++d) {
         m.rb[i][j][d][0] = P.conv1d(rp + ".convs1." + std::to_string(d), ch, ch, k, true, true);
         m.rb[i][j][d][1] = P.conv1d(rp + ".convs2." + std::to_string(d), ch, ch, k, true, true);
       }
+      P.emit_x6 = false;
       // narrow stages: the 2*n_rbd convs of the block once more as ONE contiguous bf16 stream (+ one bias block) for the
       // whole-ResBlock kernel; copied out of the per-conv streams just written (m-tile 0 = the whole channel dim)
       m.rbcl_w_off[i][j] = m.rbcl_b_off[i][j] = -1;

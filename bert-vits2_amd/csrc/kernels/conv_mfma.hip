@@ -885,6 +885,9 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     return launch_splitk(stream, L, max_cout_pad, variant_name);
   }
   if (L.ksplit != 1) return -1;                   // the LDS-tiled kernel never splits K across workgroups
+  // every problem carries its split-bf16 weight planes: the same conv on the bf16 matrix core (conv_x6.hip)
+  if (tile >= TILE_X6) return launch_conv1d_x6(stream, L, tile, variant_name);
+  if (tile == TILE_AUTO && g_tune_tile_target == 0 && conv_x6_supported(L)) return launch_conv1d_x6(stream, L, TILE_X6, variant_name);
   if (tile == TILE_AUTO) {
     // largest tile that still yields >= ~6 workgroups per CU (256 CUs; measured optimum, profiles/r01_c_*): the problems
     // of one launch differ in cost (k = 3 / 7 / 11 branches) and only 2-3 workgroups are resident per CU, so the

@@ -1,0 +1,389 @@
+// conv_x6.hip — the LDS-tiled fp32 conv1d of conv_mfma.hip on the gfx950 BF16 matrix core: fp32 operands, fp32 results, the
+// products formed from three-way bf16 splits ("bf16x6" emulation of an fp32 GEMM).
+//
+// Why: the wide Generator stages are bound by the fp32 MFMA rate (v_mfma_f32_32x32x2_f32: 157 TF, 32 MAC per cycle per SIMD);
+// v_mfma_f32_32x32x16_bf16 multiplies 16x as many bf16 pairs per cycle (2.5 PF dense) and accumulates in fp32.  Every fp32 value is
+// EXACTLY the sum of three bf16 values, v = h1 + h2 + h3 (8 + 8 + 8 significand bits, same exponent range; round-to-nearest at every
+// step), every bf16 x bf16 product is exact in fp32, and of the nine cross terms of w*x the six largest
+//      w1x1 + (w1x2 + w2x1) + (w1x3 + w2x2 + w3x1)
+// leave out |w2x3 + w3x2 + w3x3| < 2^-23 |wx| — less than the rounding of ONE fp32 multiply-add — so the conv is computed to fp32
+// accuracy with 6 bf16 MFMAs (6/16 of the fp32 MFMA time) per 16 channels instead of 8 fp32 MFMAs.  tests/test_x6_gpu.py compares
+// it against the fp32-MFMA kernel and the oracle; the end-to-end parity numbers (bench.py `parity`) are the same to the last digit
+// shown.  (The same technique as the BF16x9 / x6 fp32-emulation modes of vendor BLAS libraries; no reference counterpart — the
+// reference runs these convs through MIOpen / cuDNN fp32.)
+//
+//   GEMM view:  M = C_out (rows),  N = time (columns, contiguous in HBM, fp32 [B][C][T] like every other tensor of the fp32 path),
+//   K = (C_in group of 16, tap j).
+//
+// Workgroup = 4 waves = WM x WN, wave tile = MI x NI blocks of 32x32.
+//   * weights: pre-split at pack time into three bf16 planes in MFMA-A fragment order (x6_w_index, bv2_kernels.h), streamed
+//     global -> registers through a ring with one slot per 16-channel group of the chunk (the ring is never drained; same
+//     bookkeeping as conv1d_mfma_kernel: slot g holds unit (g, tap j), then (g, j+1), after the last tap (g, 0) of the next chunk);
+//   * X: a chunk of CK input channels x (BN + halo) columns is loaded fp32 from HBM (lane = column: coalesced), pre-activated,
+//     split into its three planes ONCE per element and written CHANNELS-LAST to LDS (plane p: [column][CK + 8] bf16, row pitch an
+//     odd multiple of 16 B), so that the MFMA B operand — 8 consecutive channels of one column — is one ds_read_b128 and the k taps
+//     are row shifts of the same tile.  The next chunk's global loads fly under this chunk's MFMAs; two barriers per chunk.
+//   * per unit (16 channels x 1 tap): NI*3 ds_read_b128 + MI*3 global_load_dwordx4 feed MI*NI*6 MFMAs (24 for the 2x2 wave tile).
+#include <hip/hip_runtime.h>
+#include "../bv2_kernels.h"
+
+namespace bv2 {
+
+namespace {
+
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef float xf32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+// explicit global address space for the ring (see gen_bf16.hip: a FLAT load would also count on lgkmcnt)
+typedef __attribute__((address_space(1))) xbf16x8 XGlobalFrag;
+
+__device__ __forceinline__ float x6_ld(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ unsigned x6_pack(float a, float b) {     // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  xbf16x2 r;
+  r[0] = (__bf16)a; r[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float x6_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float x6_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+constexpr int X6_UNIT = 3 * 512;          // elements of one (group, tap) unit of one m-tile: 3 planes x 64 lanes x 8
+
+}  // namespace
+
+template <int WM, int WN, int MI, int NI, int CK, int XR>
+__global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
+  constexpr int BM = WM * MI * 32;
+  constexpr int BN = WN * NI * 32;
+  constexpr int PITCH = CK + 8;                    // bf16 elements per LDS row: (CK/8 + 1) * 16 B, an odd multiple of 16 B
+  constexpr int PLANE = XR * PITCH;                // elements per plane
+  constexpr int GR = CK / 16;                      // 16-channel groups per chunk = ring slots
+  constexpr int NRG = XR / 64;                     // 64-column groups of the staged tile
+  constexpr int OPW = CK / 32;                     // channel octets per wave per column group (CK/8 octets over 4 waves)
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(XR % 64 == 0 && XR >= BN && (CK == 32 || CK == 64), "staged tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]
+
+  // placement: identical to conv1d_mfma_kernel (grid (time tiles, m-tiles x batch, problems), or the cost-balanced snake)
+  int pz = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
+  if (snake_n > 0) {
+    const int xcd = blockIdx.x & 7, pp = blockIdx.x >> 3;
+    if (pp >= snake_n) return;
+    const int r = pp >> 5, cc = pp & 31;
+    const int rem = snake_n - (r << 5) < 32 ? snake_n - (r << 5) : 32;
+    const int sidx = (r << 5) + ((r & 1) ? rem - 1 - cc : cc);
+    const int per_prob = per_xcd * mtiles * L.B;
+    pz = sidx / per_prob;
+    const int rest = sidx - pz * per_prob;
+    by = rest / per_xcd;
+    bx = ((rest - by * per_xcd) << 3) | xcd;
+  }
+  const ConvProb P = L.p[pz];                     // BY VALUE: one kernarg round trip (see conv_mfma.hip)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int b = by / mtiles;
+  const int m0 = (by - b * mtiles) * BM;
+  const int vt = per_xcd ? (bx & 7) * per_xcd + (bx >> 3) : bx;
+  const int t0 = vt * BN;
+  if (t0 >= L.L) return;
+  if (m0 >= P.cout_pad) return;
+
+  const int k = P.k, dil = P.dil;
+  int Lin = P.Lin;
+  if (L.lens) {
+    const int64_t lv = L.lens[b] * L.len_mul;
+    Lin = lv < Lin ? (int)lv : Lin;
+    if (t0 >= Lin) return;
+  }
+  const float in_scale = P.in_scale, slope = P.slope;
+  const bool lrelu = P.pre_act == PRE_LRELU;
+  const float* const x0p = P.x[0] + (int64_t)b * P.x_bstride;
+  const float* const maskp = P.in_mask ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
+  const unsigned x_rs4 = 4u * (unsigned)P.x_rstride;
+  const int XW = BN + (k - 1) * dil;
+  const int nchunks = P.cin / CK;
+  const int groups = P.cin / 16;
+
+  xf32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // ---- weight ring: unit (group s, tap j) of m-tile mt starts at element ((mt*groups + s)*k + j) * X6_UNIT; plane p 512 elements in
+  xbf16x8 ar[GR][MI][3];
+  const uint16_t* wq[GR][MI];
+  const unsigned wlane = 16u * (unsigned)lane;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int mt = (m0 >> 5) + wm * MI + mi;
+    mt = mt * 32 < P.cout_pad ? mt : (m0 >> 5);   // rows beyond the problem: any valid tile (results are dropped)
+#pragma unroll
+    for (int g = 0; g < GR; ++g) wq[g][mi] = P.w6 + ((int64_t)mt * groups + g) * k * X6_UNIT;
+  }
+  auto load_unit = [&](int slot, int step) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        ar[slot][mi][p] = *(const XGlobalFrag*)(reinterpret_cast<const char*>(wq[slot][mi]) + wlane + 1024u * (unsigned)p);
+      wq[slot][mi] += step;
+    }
+  };
+
+  // ---- X prefetch: wave `wid` loads the channel octets {wid, wid + 4, ...} of every 64-column group (lane = column)
+  float xr[NRG][OPW][8];
+  float xm[NRG];
+  const int tbase = t0 - P.pad_left;
+  unsigned tc[NRG];
+  float colsc[NRG];
+#pragma unroll
+  for (int rg = 0; rg < NRG; ++rg) {
+    const int r = rg * 64 + lane;
+    const int t = tbase + r;
+    const bool tok = r < XW && t >= 0 && t < Lin;
+    colsc[rg] = tok ? in_scale : 0.f;
+    tc[rg] = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
+  }
+  auto issue_x = [&](int c) __attribute__((always_inline)) {
+    if (maskp) {
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg) xm[rg] = x6_ld(maskp, tc[rg]);
+    } else {
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg) xm[rg] = 1.f;
+    }
+#pragma unroll
+    for (int o = 0; o < OPW; ++o) {
+      const unsigned row0 = (unsigned)(c * CK + (wid + 4 * o) * 8) * x_rs4;
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[rg][o][e] = x6_ld(x0p, row0 + (unsigned)e * x_rs4 + tc[rg]);
+    }
+  };
+  auto store_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg) {
+      const float sc = colsc[rg] * xm[rg];
+#pragma unroll
+      for (int o = 0; o < OPW; ++o) {
+        xu32x4 p1, p2, p3;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float a = xr[rg][o][2 * w], bq = xr[rg][o][2 * w + 1];
+          const float an = a * slope, bn = bq * slope;
+          a = (lrelu && a < 0.f) ? an : a;
+          bq = (lrelu && bq < 0.f) ? bn : bq;
+          a *= sc; bq *= sc;
+          const unsigned u1 = x6_pack(a, bq);
+          a -= x6_lo(u1); bq -= x6_hi(u1);
+          const unsigned u2 = x6_pack(a, bq);
+          a -= x6_lo(u2); bq -= x6_hi(u2);
+          p1[w] = u1; p2[w] = u2; p3[w] = x6_pack(a, bq);
+        }
+        unsigned short* dst = xs + (rg * 64 + lane) * PITCH + (wid + 4 * o) * 8;
+        *reinterpret_cast<xu32x4*>(dst) = p1;
+        *reinterpret_cast<xu32x4*>(dst + PLANE) = p2;
+        *reinterpret_cast<xu32x4*>(dst + 2 * PLANE) = p3;
+      }
+    }
+  };
+
+  // prologue: X chunk 0 first (the long latency), then prime the ring
+  issue_x(0);
+#pragma unroll
+  for (int g = 0; g < GR; ++g) { load_unit(g, k == 1 ? (nchunks > 1 ? GR * X6_UNIT : 0) : X6_UNIT); __builtin_amdgcn_sched_barrier(0); }
+  store_x();
+  __syncthreads();
+
+  const unsigned short* const xlane = xs + (wn * (NI * 32) + l31) * PITCH + lh * 8;
+  const int tap_step = dil * PITCH;
+  const int last_step = ((GR - 1) * k + 1) * X6_UNIT;             // elements from (g, k-1) to (g, 0) of the next chunk
+  for (int c = 0; c < nchunks; ++c) {
+    const bool next_chunk = (c + 1) < nchunks;
+    if (next_chunk) issue_x(c + 1);               // in flight under this chunk's MFMAs
+    const int jump = next_chunk ? last_step : -(((nchunks - 1) * GR * k + (k - 1)) * X6_UNIT);
+    xbf16x8 bb[2][NI][3];
+    const unsigned short* xrow = xlane;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const xbf16x8*>(xrow + ni * 32 * PITCH + p * PLANE);
+    for (int j = 0; j < k; ++j) {
+      const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;   // the chunk's last unit re-reads itself (unused)
+      const int step_after = (j + 2 == k || k == 1) ? jump : X6_UNIT;
+#pragma unroll
+      for (int g = 0; g < GR; ++g) {
+        {
+          const unsigned short* xn = (g + 1 < GR) ? xrow + (g + 1) * 16 : xnext;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              bb[(g & 1) ^ 1][ni][p] = *reinterpret_cast<const xbf16x8*>(xn + ni * 32 * PITCH + p * PLANE);
+        }
+        // the six products, smallest first; consecutive MFMAs go to different accumulators
+#define X6_PROD(WP, XP)                                                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                            \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                            \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][mi][WP], bb[g & 1][ni][XP], acc[mi][ni], 0, 0, 0);
+        X6_PROD(2, 0) X6_PROD(1, 1) X6_PROD(0, 2) X6_PROD(1, 0) X6_PROD(0, 1) X6_PROD(0, 0)
+#undef X6_PROD
+        load_unit(g, step_after);
+        // pin the emitted order: next unit's LDS reads first (they land under this unit's MFMAs), MFMAs, ring loads
+        __builtin_amdgcn_sched_group_barrier(0x100, NI * 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI * 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, MI * 3, 0);
+        __builtin_amdgcn_sched_barrier(0);        // keep program order: the ring's vmcnt distances stay GR - 1 units
+      }
+      xrow = xnext;
+    }
+    if (next_chunk) {
+      __syncthreads();                            // every wave is done reading this chunk's tile
+      store_x();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (conv1d_mfma_kernel's, without the gate): every ConvProb field into a register first, 32-bit element offsets from
+  // wave-uniform bases, the bias / residual loads of a tile issued together, then the arithmetic, then the stores
+  {
+    const int cout = P.cout, Lout = L.L;
+    const int act = P.act, mask_pre = P.mask_pre, mask_post = P.mask_post, res_mode = P.res_mode;
+    const unsigned o_rs = (unsigned)P.out_rstride, o_ts = (unsigned)P.out_tstride, o_to = (unsigned)P.out_toff;
+    float* const outb = P.out + (int64_t)b * P.out_bstride;
+    const float* const resb = res_mode != RES_NONE ? P.res + (int64_t)b * P.res_bstride : nullptr;
+    const float* const biasp = P.bias;
+    const float* const bias2p = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
+    const float* const omaskp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : nullptr;
+    const float* const b1p = biasp ? biasp : reinterpret_cast<const float*>(P.w6);   // missing: a valid dummy address, masked to +0.0
+    const float* const b2p = bias2p ? bias2p : reinterpret_cast<const float*>(P.w6);
+    const unsigned m_b1 = biasp ? 0xffffffffu : 0u, m_b2 = bias2p ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;       // this lane's rows: row0 + (r & 3) + 8 * (r >> 2)
+      float bs[16], bs2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = row0 + (r & 3) + 8 * (r >> 2);
+        row = row < cout ? row : cout - 1;
+        bs[r] = x6_ld(b1p, m_b1 ? 4u * (unsigned)row : 0u);
+        bs2[r] = x6_ld(b2p, m_b2 ? 4u * (unsigned)row : 0u);
+      }
+      auto bsum = [&](int r) __attribute__((always_inline)) {
+        return __uint_as_float(__float_as_uint(bs[r]) & m_b1) + __uint_as_float(__float_as_uint(bs2[r]) & m_b2);
+      };
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
+        const bool colok = col < Lout;
+        const int colc = colok ? col : Lout - 1;
+        const float om = omaskp ? omaskp[colc] : 1.f;
+        const unsigned off0 = (unsigned)row0 * o_rs + (unsigned)colc * o_ts + o_to;
+        float rv[16];
+        if (resb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const unsigned off = row0 + dr < cout ? off0 + (unsigned)dr * o_rs : off0;
+            rv[r] = x6_ld(resb, 4u * off);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          float v = acc[mi][ni][r] + bsum(r);
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+          if (mask_pre) v *= om;
+          if (res_mode == RES_ADD) v += rv[r];
+          else if (res_mode == RES_RSUB) v = rv[r] - v;
+          if (mask_post) v *= om;
+          if (colok && row0 + dr < cout) outb[off0 + (unsigned)dr * o_rs] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+bool conv_x6_supported(const ConvLaunch& L) {
+  if (L.nprob < 1 || L.ksplit > 1) return false;
+  for (int i = 0; i < L.nprob; ++i) {
+    const ConvProb& p = L.p[i];
+    if (!p.w6 || p.nsrc != 1 || p.cin % 32 || p.cin != p.cin_pad || p.cout_pad % 32 || p.k < 1 || p.dil < 1) return false;
+    if ((p.k - 1) * p.dil > 64 || p.act == ACT_GATE) return false;
+  }
+  return true;
+}
+
+static int g_x6_tune_ck = 0;
+void conv_x6_set_tuning(int ck) { g_x6_tune_ck = ck; }
+
+template <int WM, int WN, int MI, int NI, int CK, int XR>
+static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_cout_pad) {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  const int mtiles = (max_cout_pad + BM - 1) / BM;
+  const int ntx = (L0.L + BN - 1) / BN;
+  const int per_xcd = (ntx % 8 == 0 || ntx >= 64) ? (ntx + 7) / 8 : 0;      // contiguous per-XCD ranges only if they balance
+  dim3 grid(per_xcd ? per_xcd * 8 : ntx, mtiles * L0.B, L0.nprob);
+  ConvLaunch Ls = L0;
+  int snake_n = 0;
+  if (per_xcd && L0.nprob > 1) {                  // cost-balanced placement, see conv_mfma.hip launch_variant
+    const long total = (long)per_xcd * 8 * mtiles * L0.B * L0.nprob;
+    bool differ = false;
+    for (int i = 1; i < L0.nprob; ++i)
+      if (L0.p[i].k * L0.p[i].cin_pad != L0.p[0].k * L0.p[0].cin_pad) differ = true;
+    if (differ && total > 256 && total <= 512) {
+      for (int i = 0; i < Ls.nprob; ++i)
+        for (int j = i; j > 0 && Ls.p[j].k * Ls.p[j].cin_pad > Ls.p[j - 1].k * Ls.p[j - 1].cin_pad; --j) {
+          const ConvProb t = Ls.p[j]; Ls.p[j] = Ls.p[j - 1]; Ls.p[j - 1] = t;
+        }
+      snake_n = per_xcd * mtiles * L0.B * L0.nprob;
+      grid = dim3(snake_n * 8, 1, 1);
+    }
+  }
+  const size_t lds = (size_t)3 * XR * (CK + 8) * 2;
+  auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, Ls, mtiles, per_xcd, snake_n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name) {
+  if (!conv_x6_supported(L)) return -2;
+  int max_cout_pad = 0;
+  bool ck64 = true;
+  for (int i = 0; i < L.nprob; ++i) {
+    if (L.p[i].cout_pad > max_cout_pad) max_cout_pad = L.p[i].cout_pad;
+    if (L.p[i].cin % 64) ck64 = false;
+  }
+  if (g_x6_tune_ck == 32) ck64 = false;
+  if (tile == TILE_X6) {
+    // wave tile 32x64 (MI = 1, NI = 2) with all four waves on the same 64 columns for >= 128 output channels; 64 channels: 2 x 2 waves
+    if (max_cout_pad % 128 == 0) tile = TILE_X6_128x64;
+    else tile = TILE_X6_64x128;
+  }
+  switch (tile) {
+    case TILE_X6_128x64:
+      if (variant_name) *variant_name = ck64 ? "conv1d_x6<128x64,ck64>" : "conv1d_x6<128x64,ck32>";
+      return ck64 ? launch_x6_variant<4, 1, 1, 2, 64, 128>(stream, L, max_cout_pad) : launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
+    case TILE_X6_128x128:
+      if (variant_name) *variant_name = "conv1d_x6<128x128,ck32>";
+      return launch_x6_variant<2, 2, 2, 2, 32, 192>(stream, L, max_cout_pad);
+    case TILE_X6_64x128:
+      if (variant_name) *variant_name = ck64 ? "conv1d_x6<64x128,ck64>" : "conv1d_x6<64x128,ck32>";
+      return ck64 ? launch_x6_variant<2, 2, 1, 2, 64, 192>(stream, L, max_cout_pad) : launch_x6_variant<2, 2, 1, 2, 32, 192>(stream, L, max_cout_pad);
+  }
+  return -1;
+}
+
+}  // namespace bv2

@@ -24,6 +24,12 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
                     int mask_post, const float* bias2, int nsrc, const float* x1, const float* x2, float in_scale, int ksplit,
                     int64_t slab_stride);
 
+/* tile 8 = the split-bf16 form of the LDS-tiled kernel with its own tile choice (kernels/conv_x6.hip; cin % 32 == 0, nsrc == 1),
+ * 9 / 10 / 11 = its 128x64 / 128x128 / 64x128 workgroup tiles forced. */
+
+/* v = h[0] + h[1] + h[2] exactly as bf16 bit patterns: the host-side split the packer applies to the x6 weight planes (host only) */
+void bv2_test_x6_split(float v, uint16_t* h3);
+
 /* fused ResBlock1 pair (kernels/resblock_fused.hip): out = x + conv2(lrelu(conv1(lrelu(x), k, dil) + b1), k, 1) + b2 on
  * [B][C][L]; w*_host [C][C][k], b*_host [C] are HOST pointers; wpack_dev needs 2 * bv2_test_conv_pack_floats(C, C, k) floats */
 int bv2_test_resblock_fused(void* stream, const float* x, float* out, const float* w1_host, const float* b1_host,

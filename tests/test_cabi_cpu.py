@@ -253,3 +253,36 @@ def test_no_kernel_on_the_default_path_has_a_scratch_segment():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--check"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_x6_split_is_exact_and_round_to_nearest():
+    """The packer's three-way bf16 split (bv2_kernels.h x6_split, behind the x6 weight planes): h1 + h2 + h3 == v EXACTLY for every
+    finite fp32 whose low planes stay normal, and each plane is the round-to-nearest-even bf16 of what is left."""
+    import ctypes as C
+    import numpy as np
+    from bert_vits2_amd import lib as L
+    lib = L.load()
+    lib.bv2_test_x6_split.restype = None
+    lib.bv2_test_x6_split.argtypes = [C.c_float, C.POINTER(C.c_uint16)]
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * np.exp(rng.uniform(-30, 30, 2000)).astype(np.float32),
+                           np.array([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, np.float32(1) + np.float32(2 ** -23),
+                                     np.float32(1) - np.float32(2 ** -24), 0.1, 1 / 3], dtype=np.float32)])
+    h = (C.c_uint16 * 3)()
+
+    def bf(u):
+        return np.array([int(u) << 16], dtype=np.uint32).view(np.float32)[0]
+
+    def rne(v):
+        u = int(np.array([v], dtype=np.float32).view(np.uint32)[0])
+        u += 0x7fff + ((u >> 16) & 1)
+        return (u >> 16) & 0xffff
+
+    for v in vals:
+        lib.bv2_test_x6_split(float(v), h)
+        planes = [bf(h[i]) for i in range(3)]
+        assert float(np.float64(planes[0]) + np.float64(planes[1]) + np.float64(planes[2])) == float(v), (v, planes)
+        rest = np.float32(v)
+        for i in range(3):
+            assert h[i] == rne(rest), (v, i)
+            rest = np.float32(rest - planes[i])

@@ -1,0 +1,95 @@
+"""GPU: kernels/conv_x6.hip — the LDS-tiled fp32 conv with its products formed on the bf16 matrix core from exact three-way bf16
+splits of both operands (six of the nine cross terms; the dropped ones are < 2^-23 of a product).  The claim under test is "fp32
+accuracy": against an fp64 reference the x6 kernel must be as close as the fp32-MFMA kernel (conv_mfma.hip) on the same inputs —
+not merely within a looser tolerance of its own — across tile shapes, taps / dilations, ragged lengths and the fused epilogues."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_kernels_gpu import _lib, P, rel_err
+
+pytestmark = pytest.mark.gpu
+
+X6_CASES = [
+    # B, cin, cout, k, dil, L
+    (1, 128, 128, 11, 5, 517), (2, 64, 64, 7, 3, 300), (1, 256, 256, 3, 1, 129), (1, 128, 128, 1, 1, 200), (1, 64, 64, 3, 1, 64),
+    (2, 128, 128, 7, 5, 1000), (1, 256, 256, 11, 1, 3072), (1, 96, 160, 5, 2, 333), (1, 64, 32, 3, 3, 77), (3, 32, 64, 7, 1, 130),
+]
+
+
+def _run(lib, x, w, bias, tile, k, dil, lrelu=0.0, relu=0, res=None, res_mode=0, in_mask=None, out_mask=None, mask_pre=0, mask_post=0,
+         bias2=None):
+    B, cin, L = x.shape
+    cout = w.shape[0]
+    out = torch.full((B, cout, L), float("nan"), device="cuda")
+    wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
+    rc = lib.bv2_test_conv1d(None, P(x), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, tile, lrelu, relu, P(res), res_mode,
+                             P(in_mask), P(out_mask), mask_pre, mask_post, P(bias2), 1, None, None, 1.0, 1, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("tile", [8, 9, 10, 11])
+@pytest.mark.parametrize("B,cin,cout,k,dil,L", X6_CASES)
+def test_conv1d_x6_is_as_accurate_as_the_fp32_mfma_kernel(B, cin, cout, k, dil, L, tile):
+    lib = _lib()
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k + L)
+    # a wide dynamic range in both operands: the split must not lose the small ones
+    x = torch.randn(B, cin, L, generator=g) * torch.exp(2.0 * torch.randn(B, cin, 1, generator=g))
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k) * torch.exp(torch.randn(cout, 1, 1, generator=g))
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv1d(x.double(), w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil)
+    xd = x.cuda()
+    y6 = _run(lib, xd, w, bias, tile, k, dil)
+    y32 = _run(lib, xd, w, bias, 3 if cout % 64 == 0 else 4, k, dil)
+    e6, e32 = rel_err(y6, ref), rel_err(y32, ref)
+    assert e6 < 2e-5
+    assert e6 <= 2.0 * e32 + 2e-7, (e6, e32)
+    # element-wise, relative to each output ROW's scale (rows differ by e^2 in scale): nothing hides behind the largest row
+    scale = ref.abs().amax(dim=2, keepdim=True).clamp_min(1e-30)
+    r6 = ((y6.double().cpu() - ref).abs() / scale).max().item()
+    r32 = ((y32.double().cpu() - ref).abs() / scale).max().item()
+    assert r6 <= 2.0 * r32 + 3e-7, (r6, r32)
+
+
+@pytest.mark.parametrize("tile", [9, 10, 11])
+def test_conv1d_x6_fused_epilogues(tile):
+    """lrelu pre-activation, input mask, per-batch bias, ReLU, pre-mask, residual add / rsub, post-mask — conv_mfma.hip's epilogue."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(tile)
+    B, cin, cout, k, dil, L = 2, 64, 128, 5, 2, 333
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias, bias2 = torch.randn(cout, generator=g), torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, L, generator=g)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, L - 57])[:, None]).float()
+    xin = F.leaky_relu(x.double(), 0.1) * mask[:, None].double()
+    y = F.conv1d(xin, w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil) + bias2[:, :, None].double()
+    y = torch.relu(y) * mask[:, None].double()
+    xd, rd, md, b2 = x.cuda(), res.cuda(), mask.cuda(), bias2.cuda()
+    for res_mode, ref in ((1, (y + res.double()) * mask[:, None].double()), (2, (res.double() - y) * mask[:, None].double())):
+        out = _run(lib, xd, w, bias, tile, k, dil, lrelu=0.1, relu=1, res=rd, res_mode=res_mode, in_mask=md, out_mask=md, mask_pre=1,
+                   mask_post=1, bias2=b2)
+        assert rel_err(out, ref) < 2e-5
+
+
+def test_conv1d_x6_resblock_shape_with_residual_in_place_like_the_generator():
+    """convs2 of a wide stage: out = x + conv(lrelu(t)) with k = 11 — the launch the Generator issues, at a length that is not a
+    multiple of any tile, compared with the fp32-MFMA kernel element by element."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    B, C, k, L = 1, 128, 11, 24576 + 37
+    t = torch.randn(B, C, L, generator=g)
+    xres = torch.randn(B, C, L, generator=g)
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    bias = torch.randn(C, generator=g)
+    td, rd = t.cuda(), xres.cuda()
+    y6 = _run(lib, td, w, bias, 8, k, 1, lrelu=0.1, res=rd, res_mode=1)
+    y32 = _run(lib, td, w, bias, 3, k, 1, lrelu=0.1, res=rd, res_mode=1)
+    ref = xres.double() + F.conv1d(F.leaky_relu(t.double(), 0.1), w.double(), bias.double(), padding=5)
+    e6, e32 = rel_err(y6, ref), rel_err(y32, ref)
+    assert e6 <= 2.0 * e32 + 2e-7, (e6, e32)
+    assert (y6 - y32).abs().max().item() < 4e-6 * ref.abs().max().item()
