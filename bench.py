@@ -48,7 +48,7 @@ CONFIGS = {
 }
 WN_FLOW_B32 = "f16"               # flow arithmetic of secondary.config3_residual_flow: the WN convolutions on the fp16 matrix core
 KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
-KERNEL_SOURCES = {"conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
+KERNEL_SOURCES = {"conv1d_x6": "conv_x6.hip", "conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
                   "conv_cl_bf16": "gen_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "conv_f16": "enc_f16.hip",
                   "attention": "attention.hip"}
 
@@ -265,7 +265,21 @@ def roofline_block(prof, psteps, config=2):
     else:
         ach, peak, unit, bound = dom["bytes"] / secs / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
     tr = pmc_traffic(dom["name"], config)
-    return dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 4),
+    x6 = {}
+    if dom["name"].startswith("conv1d_x6") and bound == "mfma":
+        # kernels/conv_x6.hip computes the fp32 conv with SIX bf16 MFMA products per multiply-add (exact three-way bf16 splits of both
+        # operands): the roof that binds it is the bf16 matrix core, and what it must issue per launch is 6x the conv's FLOPs.
+        # `achieved` / `frac` are in those issued bf16 FLOPs against the 2.5 PF bf16 peak; the fp32-equivalent rate (the conv's own
+        # FLOPs per second) and its ratio to the fp32 matrix peak the previous kernel was bounded by are reported beside it.
+        x6 = dict(math="fp32 operands / fp32 results; every product formed on the bf16 matrix core from exact 3-way bf16 splits, 6 of the "
+                       "9 cross terms (dropped terms < 2^-23 of a product): 6 issued bf16 MFMA FLOPs per algorithmic FLOP",
+                  issued_flops_per_alg_flop=6, fp32_equivalent_tflops=round(ach, 3),
+                  frac_of_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                  measured_mfma_ceiling="tools/probe/mfma_bf16_probe.hip on this chip: 0.75-0.80 of 2.5 PF with operands in registers "
+                                        "(clock drops to ~1.8 GHz under dense bf16 MFMA), 0.60-0.65 with this kernel's operand traffic "
+                                        "(profiles/r03_mfma_bf16_probe.txt)")
+        ach, peak = 6.0 * ach, PEAK_BF16_MFMA_TFLOPS
+    return dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 4), **x6,
                 arithmetic_intensity_flop_per_byte=round(ai, 1), traffic=tr.get("bytes_per_launch"), traffic_detail=tr,
                 alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]), launches_per_step=dom["launches"] / psteps,
                 avg_launch_us=round(dom["total_ms"] * 1e3 / dom["launches"], 2), flops_per_launch=dom["flops"] / dom["launches"],
@@ -617,7 +631,7 @@ def describe(res, hp, world):
     shape = (f"B={res['B']} utterances of uniform [96,{res['T']}] symbols (mean {sum(res['lengths']) / res['B']:.1f}), ZH/JA/EN round-robin, "
              f"random speakers" if ragged else f"B={res['B']} x T={res['T']} symbols")
     return (f"BASELINE config {res['config']}: {shape} per GPU, "
-            f"{'bf16 Generator (fp32 accumulate)' if gd == 'bf16' else 'fp32 Generator'}, "
+            f"{'bf16 Generator (fp32 accumulate)' if gd == 'bf16' else 'fp32 Generator (wide-stage products on the bf16 matrix core from exact 3-way bf16 operand splits, fp32 accuracy; secondary.config2_fp32_mfma = the fp32-MFMA form)'}, "
             f"{'fp16 flow convs (fp32 accumulate / LayerNorm / softmax / gate)' if fd == 'f16' else 'fp32 flow'}, "
             f"fp32 text encoder / durations / spline, T_y={res['Ty']} frames "
             f"({res['Ty'] * hp.total_upsample} samples, {res['Ty'] * hp.total_upsample / hp.sampling_rate:.3f} s) per padded utterance, "
@@ -785,6 +799,18 @@ def rank_main(args):
                 log(f"secondary config {num}: {secondary[f'config{num}']['value']} audio-s/s ({secondary[f'config{num}']['ms_per_step']} ms/step)")
             except Exception as e:          # a secondary workload must never take the primary line down
                 secondary[f"config{num}"] = dict(error=repr(e)[:300])
+
+        # config 2 once more with the wide Generator convs on the fp32 matrix core (v_mfma_f32_32x32x2_f32, conv_mfma.hip) instead
+        # of the split-bf16 form (conv_x6.hip): the same fp32 numerics at the fp32 MFMA rate — the kernel of rounds 1-2
+        try:
+            model.set_option("conv_x6", 0)
+            r = run_config(2, model, hp, dev, 0, 1, max(5, min(args.steps, 20)), 3, {})
+            secondary["config2_fp32_mfma"] = summary(r, hp, 1)
+            log(f"secondary config 2 on the fp32 matrix core: {secondary['config2_fp32_mfma']['value']} audio-s/s")
+        except Exception as e:
+            secondary["config2_fp32_mfma"] = dict(error=repr(e)[:300])
+        finally:
+            model.set_option("conv_x6", 1)
 
         # north_star names the ResidualCouplingBlock / WN flow explicitly (models.py:403-445, modules.py:185-210): the same utterances
         # with use_transformer_flow=false — config 2 in fp32, config 3's batch with the bf16 Generator (+ the fp16 WN convs when built)

@@ -483,6 +483,21 @@ int64_t bv2_test_conv_pack_floats(int cin, int cout, int k) {
   return base + (cin % 32 == 0 ? (x6_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 : 0);
 }
 void bv2_test_x6_split(float v, uint16_t* h3) { x6_split(v, h3); }
+int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_floats, int max_regions) {
+  if (!h || !off_floats || !n_floats) return -1;
+  const Model& m = h->model;
+  int n = 0;
+  for (int i = 0; i < m.n_ups; ++i)
+    for (int j = 0; j < m.n_rbk; ++j)
+      for (int d = 0; d < m.n_rbd; ++d)
+        for (int e = 0; e < 2; ++e) {
+          const ConvW& w = m.rb[i][j][d][e];
+          if (w.wx_off < 0) continue;
+          if (n < max_regions) { off_floats[n] = w.wx_off; n_floats[n] = (x6_w_elems(w.cin, w.cout_pad, w.k) + 1) / 2; }
+          ++n;
+        }
+  return n;
+}
 static int64_t t_x6_off(int cin, int cout, int k) {
   return ((int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048 + 63) / 64 * 64;
 }
@@ -741,6 +756,7 @@ void bv2_test_conv_timeline(void* dev_buf, long long capacity_u64) {
 int bv2_test_conv_timeline_report(long long* meta, int max_launches) { return conv_timeline_report(meta, max_launches); }
 
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target) { conv_set_tuning(splitk_waves, force_ck, tile_target); }
+void bv2_test_set_x6_tuning(int t256, int t128, int t64, int ck) { conv_x6_set_tuning(t256, t128, t64, ck); }
 void bv2_test_set_variants(const char* cl_spec, int cl_generic, int hc_generic) {
   conv_cl_set_tuning(cl_spec, cl_generic);
   conv_f16_set_tuning(hc_generic);

@@ -17,8 +17,8 @@
 //
 // Workgroup = 4 waves = WM x WN, wave tile = MI x NI blocks of 32x32.
 //   * weights: pre-split at pack time into three bf16 planes in MFMA-A fragment order (x6_w_index, bv2_kernels.h), streamed
-//     global -> registers through a ring with one slot per 16-channel group of the chunk (the ring is never drained; same
-//     bookkeeping as conv1d_mfma_kernel: slot g holds unit (g, tap j), then (g, j+1), after the last tap (g, 0) of the next chunk);
+//     global -> registers through a ring with TWO slots per 16-channel group of the chunk (taps j and j + 1; the ring is never
+//     drained: every group's stream runs (g, 0) .. (g, k-1), then (g, 0) of the next chunk — a unit is requested 2*GR - 1 units ahead);
 //   * X: a chunk of CK input channels x (BN + halo) columns is loaded fp32 from HBM (lane = column: coalesced), pre-activated,
 //     split into its three planes ONCE per element and written CHANNELS-LAST to LDS (plane p: [column][CK + 8] bf16, row pitch an
 //     odd multiple of 16 B), so that the MFMA B operand — 8 consecutive channels of one column — is one ds_read_b128 and the k taps
@@ -54,7 +54,7 @@ constexpr int X6_UNIT = 3 * 512;          // elements of one (group, tap) unit o
 }  // namespace
 
 template <int WM, int WN, int MI, int NI, int CK, int XR>
-__global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
+__global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ? 3 : 2) conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
   constexpr int PITCH = CK + 8;                    // bf16 elements per LDS row: (CK/8 + 1) * 16 B, an odd multiple of 16 B
@@ -86,6 +86,8 @@ __global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, c
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsw = 0;           // timeline stamps (tools/timeline.py; L.dbg is null in the product)
+  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int b = by / mtiles;
   const int m0 = (by - b * mtiles) * BM;
   const int vt = per_xcd ? (bx & 7) * per_xcd + (bx >> 3) : bx;
@@ -117,8 +119,12 @@ __global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  // ---- weight ring: unit (group s, tap j) of m-tile mt starts at element ((mt*groups + s)*k + j) * X6_UNIT; plane p 512 elements in
-  xbf16x8 ar[GR][MI][3];
+  // ---- weight ring: unit (group s, tap j) of m-tile mt starts at element ((mt*groups + s)*k + j) * X6_UNIT; plane p 512 elements in.
+  // One pointer per (group of the chunk, m-tile) walks that group's stream: (g, 0), (g, 1) ... (g, k-1), then (g, 0) of the next chunk.
+  // The ring holds TWO taps per group — slot [g][(j + par) & 1] for tap j, par = parity of the taps consumed before this chunk — so a
+  // unit is requested 2*GR - 1 units (>= 1150 MFMA cycles) before its first MFMA: with one slot per group (the fp32 kernel's ring, one
+  // unit = 384 cycles ahead here) a workgroup alone on its CU (C = 256 at batch 1: 288 workgroups) spent 980 cycles per 384-cycle unit.
+  xbf16x8 ar[GR][2][MI][3];
   const uint16_t* wq[GR][MI];
   const unsigned wlane = 16u * (unsigned)lane;
 #pragma unroll
@@ -128,13 +134,20 @@ __global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, c
 #pragma unroll
     for (int g = 0; g < GR; ++g) wq[g][mi] = P.w6 + ((int64_t)mt * groups + g) * k * X6_UNIT;
   }
-  auto load_unit = [&](int slot, int step) __attribute__((always_inline)) {
+  const int last_step = ((GR - 1) * k + 1) * X6_UNIT;             // elements from (g, k-1) to (g, 0) of the next chunk
+  const int wrap_step = -(((nchunks - 1) * GR * k + (k - 1)) * X6_UNIT);   // from (g, k-1) of the last chunk back to (g, 0) of the first
+  // pointer step after loading tap jl of chunk cl (cl < nchunks): the stream of a group never ends — past the last chunk it wraps to
+  // the first one (valid memory, values unused) instead of branching around the loads
+  auto step_after = [&](int jl, int cl) __attribute__((always_inline)) {
+    return jl + 1 < k ? X6_UNIT : (cl + 1 < nchunks ? last_step : wrap_step);
+  };
+  auto load_unit = [&](int g, int SL, int step) __attribute__((always_inline)) {   // g, SL: literals at every (inlined) call site
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        ar[slot][mi][p] = *(const XGlobalFrag*)(reinterpret_cast<const char*>(wq[slot][mi]) + wlane + 1024u * (unsigned)p);
-      wq[slot][mi] += step;
+        ar[g][SL][mi][p] = *(const XGlobalFrag*)(reinterpret_cast<const char*>(wq[g][mi]) + wlane + 1024u * (unsigned)p);
+      wq[g][mi] += step;
     }
   };
 
@@ -197,29 +210,43 @@ __global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, c
     }
   };
 
-  // prologue: X chunk 0 first (the long latency), then prime the ring
+  // prologue: X chunk 0 first (the long latency), then prime the ring with the first two units of every group's stream
   issue_x(0);
+  {
+    const int s0 = step_after(0, 0);
+    const int j1 = k > 1 ? 1 : 0, c1 = k > 1 ? 0 : (nchunks > 1 ? 1 : 0);
+    const int s1 = step_after(j1, c1);
 #pragma unroll
-  for (int g = 0; g < GR; ++g) { load_unit(g, k == 1 ? (nchunks > 1 ? GR * X6_UNIT : 0) : X6_UNIT); __builtin_amdgcn_sched_barrier(0); }
+    for (int g = 0; g < GR; ++g) { load_unit(g, 0, s0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int g = 0; g < GR; ++g) { load_unit(g, 1, s1); __builtin_amdgcn_sched_barrier(0); }
+  }
   store_x();
   __syncthreads();
+  if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
   const unsigned short* const xlane = xs + (wn * (NI * 32) + l31) * PITCH + lh * 8;
   const int tap_step = dil * PITCH;
-  const int last_step = ((GR - 1) * k + 1) * X6_UNIT;             // elements from (g, k-1) to (g, 0) of the next chunk
-  for (int c = 0; c < nchunks; ++c) {
+  // k is odd (conv_x6_supported): chunk c starts at ring parity c & 1.  The control flow is loops and straight-line code only — a
+  // conditional tap inside the loop made every ring register a phi (copies + spills at the merge).
+  auto chunk = [&](int c, int PAR) __attribute__((always_inline)) {           // PAR: a literal at every (inlined) call site
     const bool next_chunk = (c + 1) < nchunks;
     if (next_chunk) issue_x(c + 1);               // in flight under this chunk's MFMAs
-    const int jump = next_chunk ? last_step : -(((nchunks - 1) * GR * k + (k - 1)) * X6_UNIT);
     xbf16x8 bb[2][NI][3];
     const unsigned short* xrow = xlane;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const xbf16x8*>(xrow + ni * 32 * PITCH + p * PLANE);
-    for (int j = 0; j < k; ++j) {
+    // one tap: the GR units (g, j) from ring slots [g][SL]; each slot is refilled with the unit two taps further down its stream
+    auto tap = [&](int j, int SL) __attribute__((always_inline)) {               // SL: a literal at every (inlined) call site
       const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;   // the chunk's last unit re-reads itself (unused)
-      const int step_after = (j + 2 == k || k == 1) ? jump : X6_UNIT;
+      int jl = j + 2, cl = c;                     // the unit loaded during this tap: tap jl of chunk cl (branch-free wrap; k = 1: twice)
+      if (jl >= k) { jl -= k; ++cl; }
+      if (jl >= k) { jl -= k; ++cl; }
+      if (cl >= nchunks) cl -= nchunks;
+      if (cl >= nchunks) cl -= nchunks;
+      const int step = step_after(jl, cl);
 #pragma unroll
       for (int g = 0; g < GR; ++g) {
         {
@@ -234,24 +261,33 @@ __global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, c
 #define X6_PROD(WP, XP)                                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                            \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                            \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][mi][WP], bb[g & 1][ni][XP], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][SL][mi][WP], bb[g & 1][ni][XP], acc[mi][ni], 0, 0, 0);
         X6_PROD(2, 0) X6_PROD(1, 1) X6_PROD(0, 2) X6_PROD(1, 0) X6_PROD(0, 1) X6_PROD(0, 0)
 #undef X6_PROD
-        load_unit(g, step_after);
+        load_unit(g, SL, step);
         // pin the emitted order: next unit's LDS reads first (they land under this unit's MFMAs), MFMAs, ring loads
         __builtin_amdgcn_sched_group_barrier(0x100, NI * 3, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, MI * NI * 6, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, MI * 3, 0);
-        __builtin_amdgcn_sched_barrier(0);        // keep program order: the ring's vmcnt distances stay GR - 1 units
+        __builtin_amdgcn_sched_barrier(0);        // keep program order: the ring's vmcnt distances stay 2*GR - 1 units
       }
       xrow = xnext;
-    }
+    };
+    for (int j = 0; j + 1 < k; j += 2) { tap(j, PAR); tap(j + 1, PAR ^ 1); }
+    tap(k - 1, PAR);
     if (next_chunk) {
+      unsigned long long ta = 0;
+      if (L.dbg) ta = __builtin_amdgcn_s_memtime();
       __syncthreads();                            // every wave is done reading this chunk's tile
       store_x();
       __syncthreads();
+      if (L.dbg) tsw += __builtin_amdgcn_s_memtime() - ta;
     }
-  }
+  };
+  int c = 0;
+  for (; c + 1 < nchunks; c += 2) { chunk(c, 0); chunk(c + 1, 1); }
+  if (c < nchunks) chunk(c, 0);
+  if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue (conv1d_mfma_kernel's, without the gate): every ConvProb field into a register first, 32-bit element offsets from
   // wave-uniform bases, the bias / residual loads of a tile issued together, then the arithmetic, then the stores
@@ -312,6 +348,16 @@ __global__ void __launch_bounds__(256, 2) conv1d_x6_kernel(const ConvLaunch L, c
       }
     }
   }
+  if (L.dbg && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* d = L.dbg + 8ull * (snake_n > 0 ? (unsigned long long)blockIdx.x
+                                                        : ((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
+    d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);               // HW_ID
+    d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);              // XCC_ID
+    d[6] = (unsigned long long)k | (tsw << 16);                     // taps | ticks spent in the chunk switches (barrier, split, barrier)
+    d[7] = 1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -320,13 +366,14 @@ bool conv_x6_supported(const ConvLaunch& L) {
   for (int i = 0; i < L.nprob; ++i) {
     const ConvProb& p = L.p[i];
     if (!p.w6 || p.nsrc != 1 || p.cin % 32 || p.cin != p.cin_pad || p.cout_pad % 32 || p.k < 1 || p.dil < 1) return false;
-    if ((p.k - 1) * p.dil > 64 || p.act == ACT_GATE) return false;
+    if ((p.k - 1) * p.dil > 64 || p.act == ACT_GATE || p.k % 2 == 0) return false;   // odd k: the ring's tap parity alternates per chunk
   }
   return true;
 }
 
-static int g_x6_tune_ck = 0;
-void conv_x6_set_tuning(int ck) { g_x6_tune_ck = ck; }
+// tuning experiments (tools/tune_x6.py through bv2_test_set_x6_tuning): forced tile per C_out class and chunk size; 0 = shipped choice
+static int g_x6_tile[3] = {0, 0, 0}, g_x6_tune_ck = 0;
+void conv_x6_set_tuning(int t256, int t128, int t64, int ck) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; g_x6_tune_ck = ck; }
 
 template <int WM, int WN, int MI, int NI, int CK, int XR>
 static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_cout_pad) {
@@ -351,6 +398,11 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
       grid = dim3(snake_n * 8, 1, 1);
     }
   }
+  if (Ls.dbg == nullptr) {                        // tools/timeline.py: a slice of the stamp buffer while one is set
+    int ks = 0;
+    for (int i = 0; i < Ls.nprob && i < 3; ++i) ks |= (Ls.p[i].k & 255) << (8 * i);
+    Ls.dbg = timeline_slice(grid.x, grid.y, grid.z, 6000000 + BM * 1000 + BN, ks, Ls.p[0].cin, Ls.L);
+  }
   const size_t lds = (size_t)3 * XR * (CK + 8) * 2;
   auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -366,23 +418,28 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
     if (L.p[i].cout_pad > max_cout_pad) max_cout_pad = L.p[i].cout_pad;
     if (L.p[i].cin % 64) ck64 = false;
   }
-  if (g_x6_tune_ck == 32) ck64 = false;
+  // 32-channel chunks by default: 138 registers / 31 KB of LDS per workgroup = three workgroups per CU (64-channel chunks: 178 / 55 KB =
+  // two) — Generator pass at batch 1 2.11 -> 1.97 ms, at B = 8 x 512 frames 20.5 -> 19.0 ms (tools/tune_x6.py, profiles/r03_tune_x6_*.txt)
+  if (g_x6_tune_ck != 64) ck64 = false;
   if (tile == TILE_X6) {
-    // wave tile 32x64 (MI = 1, NI = 2) with all four waves on the same 64 columns for >= 128 output channels; 64 channels: 2 x 2 waves
-    if (max_cout_pad % 128 == 0) tile = TILE_X6_128x64;
+    const int cls = max_cout_pad % 256 == 0 ? 0 : (max_cout_pad % 128 == 0 ? 1 : 2);
+    if (g_x6_tile[cls]) tile = g_x6_tile[cls];
+    else if (max_cout_pad % 128 == 0) tile = TILE_X6_128x64;
     else tile = TILE_X6_64x128;
   }
+#define X6_NAME(T) (ck64 ? "conv1d_x6<" T ",ck64>" : "conv1d_x6<" T ",ck32>")
   switch (tile) {
-    case TILE_X6_128x64:
-      if (variant_name) *variant_name = ck64 ? "conv1d_x6<128x64,ck64>" : "conv1d_x6<128x64,ck32>";
+    case TILE_X6_128x64:                          // wave tile 32x64, all four waves on the same 64 columns
+      if (variant_name) *variant_name = X6_NAME("128x64");
       return ck64 ? launch_x6_variant<4, 1, 1, 2, 64, 128>(stream, L, max_cout_pad) : launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
-    case TILE_X6_128x128:
+    case TILE_X6_128x128:                         // wave tile 64x64, 2 x 2 waves
       if (variant_name) *variant_name = "conv1d_x6<128x128,ck32>";
       return launch_x6_variant<2, 2, 2, 2, 32, 192>(stream, L, max_cout_pad);
-    case TILE_X6_64x128:
-      if (variant_name) *variant_name = ck64 ? "conv1d_x6<64x128,ck64>" : "conv1d_x6<64x128,ck32>";
+    case TILE_X6_64x128:                          // wave tile 32x64, 2 x 2 waves
+      if (variant_name) *variant_name = X6_NAME("64x128");
       return ck64 ? launch_x6_variant<2, 2, 1, 2, 64, 192>(stream, L, max_cout_pad) : launch_x6_variant<2, 2, 1, 2, 32, 192>(stream, L, max_cout_pad);
   }
+#undef X6_NAME
   return -1;
 }
 

@@ -29,6 +29,9 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
 
 /* v = h[0] + h[1] + h[2] exactly as bf16 bit patterns: the host-side split the packer applies to the x6 weight planes (host only) */
 void bv2_test_x6_split(float v, uint16_t* h3);
+/* where the packed blob holds x6 weight planes: float offset / float count of every region ([unit][plane 3][64 lanes][8] uint16); returns
+ * the number of regions (host only; layout is known after bv2_create) */
+int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_floats, int max_regions);
 
 /* fused ResBlock1 pair (kernels/resblock_fused.hip): out = x + conv2(lrelu(conv1(lrelu(x), k, dil) + b1), k, 1) + b2 on
  * [B][C][L]; w*_host [C][C][k], b*_host [C] are HOST pointers; wpack_dev needs 2 * bv2_test_conv_pack_floats(C, C, k) floats */
@@ -90,6 +93,8 @@ int bv2_test_dds_layer(void* stream, const float* x, const float* pre_w_host, co
 
 /* tuning experiments (tools/kbench.py): force the split-K wave count / C_in chunk / tile-count target of the fp32 conv; 0 = default */
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target);
+/* conv_x6.hip: forced tile id (9..11, see bv2_kernels.h TILE_X6_*) per C_out class (multiple of 256 / of 128 / other) and chunk (32 / 64) */
+void bv2_test_set_x6_tuning(int t256, int t128, int t64, int ck);
 /* bf16 / fp16 conv variants: cl_spec "<nt>:<id>[,...]" forces bf16 variant <id> for launches with <nt> 32-channel tiles ("" = the
  * shipped choice), cl_generic / hc_generic = 1 force the generic GEMM loop instead of the C_in-specialised tap-major one */
 void bv2_test_set_variants(const char* cl_spec, int cl_generic, int hc_generic);
