@@ -289,61 +289,73 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
   if (c < nchunks) chunk(c, 0);
   if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
-  // ---- epilogue (conv1d_mfma_kernel's, without the gate): every ConvProb field into a register first, 32-bit element offsets from
-  // wave-uniform bases, the bias / residual loads of a tile issued together, then the arithmetic, then the stores
+  // ---- epilogue: v = relu?(acc + bias + bias2) * mask_pre, (+ res | res - v), * mask_post.  Branch-free and in ONE memory round trip:
+  // every operand of the wave's MI x NI tiles (2 x 16 bias values per row block, 16 residual values per tile, the column masks) is
+  // loaded unconditionally up front — a missing operand reads a valid dummy address and is masked to +0.0 bit-wise — then the
+  // arithmetic runs on selects and the stores are predicated.  (The first form kept conv1d_mfma_kernel's runtime `act` / `res_mode`
+  // branches around every element, the erf-GELU of the BERT path included: ~10 scalar branches per row, the loads of the second tile
+  // behind the stores of the first — tools/timeline.py: 10-20k cycles of a 30-125k-cycle workgroup.)
   {
     const int cout = P.cout, Lout = L.L;
-    const int act = P.act, mask_pre = P.mask_pre, mask_post = P.mask_post, res_mode = P.res_mode;
     const unsigned o_rs = (unsigned)P.out_rstride, o_ts = (unsigned)P.out_tstride, o_to = (unsigned)P.out_toff;
     float* const outb = P.out + (int64_t)b * P.out_bstride;
-    const float* const resb = res_mode != RES_NONE ? P.res + (int64_t)b * P.res_bstride : nullptr;
-    const float* const biasp = P.bias;
-    const float* const bias2p = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
-    const float* const omaskp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : nullptr;
-    const float* const b1p = biasp ? biasp : reinterpret_cast<const float*>(P.w6);   // missing: a valid dummy address, masked to +0.0
-    const float* const b2p = bias2p ? bias2p : reinterpret_cast<const float*>(P.w6);
-    const unsigned m_b1 = biasp ? 0xffffffffu : 0u, m_b2 = bias2p ? 0xffffffffu : 0u;
+    const float* const dummy = reinterpret_cast<const float*>(P.w6);
+    const bool has_res = P.res_mode != RES_NONE;
+    const float* const resb = has_res ? P.res + (int64_t)b * P.res_bstride : dummy;
+    const float* const b1p = P.bias ? P.bias : dummy;
+    const float* const b2p = P.bias2 ? P.bias2 + (int64_t)b * P.bias2_bstride : dummy;
+    const float* const omaskp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : dummy;
+    const unsigned m_b1 = P.bias ? 0xffffffffu : 0u, m_b2 = P.bias2 ? 0xffffffffu : 0u, m_res = has_res ? 0xffffffffu : 0u;
+    const unsigned m_om = P.out_mask ? 0xffffffffu : 0u;
+    const float relu_floor = P.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const bool rsub = P.res_mode == RES_RSUB, mpre = P.mask_pre != 0, mpost = P.mask_post != 0;
+    float bs[MI][16], bs2[MI][16], rv[MI][NI][16], omr[NI];
+    unsigned off0[MI][NI];
+    bool colok[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
+      colok[ni] = col < Lout;
+      const int colc = colok[ni] ? col : Lout - 1;
+      omr[ni] = x6_ld(omaskp, m_om ? 4u * (unsigned)colc : 0u);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;
+        off0[mi][ni] = (unsigned)row0 * o_rs + (unsigned)colc * o_ts + o_to;
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;       // this lane's rows: row0 + (r & 3) + 8 * (r >> 2)
-      float bs[16], bs2[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int row = row0 + (r & 3) + 8 * (r >> 2);
-        row = row < cout ? row : cout - 1;
-        bs[r] = x6_ld(b1p, m_b1 ? 4u * (unsigned)row : 0u);
-        bs2[r] = x6_ld(b2p, m_b2 ? 4u * (unsigned)row : 0u);
+        const int dr = (r & 3) + 8 * (r >> 2);
+        const int row = row0 + dr < cout ? row0 + dr : cout - 1;       // clamped: the load is unconditional, the store is not
+        bs[mi][r] = x6_ld(b1p, m_b1 ? 4u * (unsigned)row : 0u);
+        bs2[mi][r] = x6_ld(b2p, m_b2 ? 4u * (unsigned)row : 0u);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const unsigned off = row0 + dr < cout ? off0[mi][ni] + (unsigned)dr * o_rs : off0[mi][ni];
+          rv[mi][ni][r] = x6_ld(resb, m_res ? 4u * off : 0u);
+        }
       }
-      auto bsum = [&](int r) __attribute__((always_inline)) {
-        return __uint_as_float(__float_as_uint(bs[r]) & m_b1) + __uint_as_float(__float_as_uint(bs2[r]) & m_b2);
-      };
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const int col = t0 + wn * (NI * 32) + ni * 32 + l31;
-        const bool colok = col < Lout;
-        const int colc = colok ? col : Lout - 1;
-        const float om = omaskp ? omaskp[colc] : 1.f;
-        const unsigned off0 = (unsigned)row0 * o_rs + (unsigned)colc * o_ts + o_to;
-        float rv[16];
-        if (resb) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            const unsigned off = row0 + dr < cout ? off0 + (unsigned)dr * o_rs : off0;
-            rv[r] = x6_ld(resb, 4u * off);
-          }
-        }
+        const float om = m_om ? omr[ni] : 1.f;
+        const float fpre = mpre ? om : 1.f, fpost = mpost ? om : 1.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dr = (r & 3) + 8 * (r >> 2);
-          float v = acc[mi][ni][r] + bsum(r);
-          if (act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-          if (mask_pre) v *= om;
-          if (res_mode == RES_ADD) v += rv[r];
-          else if (res_mode == RES_RSUB) v = rv[r] - v;
-          if (mask_post) v *= om;
-          if (colok && row0 + dr < cout) outb[off0 + (unsigned)dr * o_rs] = v;
+          const float bsum = __uint_as_float(__float_as_uint(bs[mi][r]) & m_b1) + __uint_as_float(__float_as_uint(bs2[mi][r]) & m_b2);
+          const float rr = __uint_as_float(__float_as_uint(rv[mi][ni][r]) & m_res);
+          float v = fmaxf(acc[mi][ni][r] + bsum, relu_floor) * fpre;
+          v = rsub ? rr - v : v + rr;
+          v *= fpost;
+          if (colok[ni] && row0 + dr < cout) outb[off0[mi][ni] + (unsigned)dr * o_rs] = v;
         }
       }
     }
@@ -366,14 +378,14 @@ bool conv_x6_supported(const ConvLaunch& L) {
   for (int i = 0; i < L.nprob; ++i) {
     const ConvProb& p = L.p[i];
     if (!p.w6 || p.nsrc != 1 || p.cin % 32 || p.cin != p.cin_pad || p.cout_pad % 32 || p.k < 1 || p.dil < 1) return false;
-    if ((p.k - 1) * p.dil > 64 || p.act == ACT_GATE || p.k % 2 == 0) return false;   // odd k: the ring's tap parity alternates per chunk
+    if ((p.k - 1) * p.dil > 64 || (p.act != ACT_NONE && p.act != ACT_RELU) || p.k % 2 == 0) return false;   // odd k: the ring's tap parity alternates per chunk
   }
   return true;
 }
 
 // tuning experiments (tools/tune_x6.py through bv2_test_set_x6_tuning): forced tile per C_out class and chunk size; 0 = shipped choice
-static int g_x6_tile[3] = {0, 0, 0}, g_x6_tune_ck = 0;
-void conv_x6_set_tuning(int t256, int t128, int t64, int ck) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; g_x6_tune_ck = ck; }
+static int g_x6_tile[3] = {0, 0, 0};
+void conv_x6_set_tuning(int t256, int t128, int t64, int) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; }
 
 template <int WM, int WN, int MI, int NI, int CK, int XR>
 static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_cout_pad) {
@@ -413,33 +425,25 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
 int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name) {
   if (!conv_x6_supported(L)) return -2;
   int max_cout_pad = 0;
-  bool ck64 = true;
-  for (int i = 0; i < L.nprob; ++i) {
+  for (int i = 0; i < L.nprob; ++i)
     if (L.p[i].cout_pad > max_cout_pad) max_cout_pad = L.p[i].cout_pad;
-    if (L.p[i].cin % 64) ck64 = false;
-  }
-  // 32-channel chunks by default: 138 registers / 31 KB of LDS per workgroup = three workgroups per CU (64-channel chunks: 178 / 55 KB =
-  // two) — Generator pass at batch 1 2.11 -> 1.97 ms, at B = 8 x 512 frames 20.5 -> 19.0 ms (tools/tune_x6.py, profiles/r03_tune_x6_*.txt)
-  if (g_x6_tune_ck != 64) ck64 = false;
   if (tile == TILE_X6) {
     const int cls = max_cout_pad % 256 == 0 ? 0 : (max_cout_pad % 128 == 0 ? 1 : 2);
     if (g_x6_tile[cls]) tile = g_x6_tile[cls];
-    else if (max_cout_pad % 128 == 0) tile = TILE_X6_128x64;
-    else tile = TILE_X6_64x128;
+    else tile = max_cout_pad % 128 == 0 ? TILE_X6_128x64 : TILE_X6_64x128;
   }
-#define X6_NAME(T) (ck64 ? "conv1d_x6<" T ",ck64>" : "conv1d_x6<" T ",ck32>")
+  // Both tiles: wave tile 32x64 (MI = 1, NI = 2), 32-channel chunks — 164 / 178 registers, 31 / 46 KB of LDS.  Measured and removed in
+  // round 3 (tools/tune_x6.py, profiles/r03_tune_x6_*.txt): 64-channel chunks (229 registers, two workgroups per CU: Generator pass
+  // 2.11 against 1.97 ms), wave tiles 64x64 as 128x128 / 256x64 / 64x256 workgroups and 32x128 (all within +-2 % at B = 8, slower at
+  // B = 1), and an eight-wave form with K split over two wave sets for the 288-workgroup launches of the C = 256 stage (no change).
   switch (tile) {
-    case TILE_X6_128x64:                          // wave tile 32x64, all four waves on the same 64 columns
-      if (variant_name) *variant_name = X6_NAME("128x64");
-      return ck64 ? launch_x6_variant<4, 1, 1, 2, 64, 128>(stream, L, max_cout_pad) : launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
-    case TILE_X6_128x128:                         // wave tile 64x64, 2 x 2 waves
-      if (variant_name) *variant_name = "conv1d_x6<128x128,ck32>";
-      return launch_x6_variant<2, 2, 2, 2, 32, 192>(stream, L, max_cout_pad);
-    case TILE_X6_64x128:                          // wave tile 32x64, 2 x 2 waves
-      if (variant_name) *variant_name = X6_NAME("64x128");
-      return ck64 ? launch_x6_variant<2, 2, 1, 2, 64, 192>(stream, L, max_cout_pad) : launch_x6_variant<2, 2, 1, 2, 32, 192>(stream, L, max_cout_pad);
+    case TILE_X6_128x64:                          // all four waves on the same 64 columns, one 32-row block each
+      if (variant_name) *variant_name = "conv1d_x6<128x64>";
+      return launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
+    case TILE_X6_64x128:                          // 2 x 2 waves
+      if (variant_name) *variant_name = "conv1d_x6<64x128>";
+      return launch_x6_variant<2, 2, 1, 2, 32, 192>(stream, L, max_cout_pad);
   }
-#undef X6_NAME
   return -1;
 }
 

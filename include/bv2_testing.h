@@ -25,7 +25,7 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
                     int64_t slab_stride);
 
 /* tile 8 = the split-bf16 form of the LDS-tiled kernel with its own tile choice (kernels/conv_x6.hip; cin % 32 == 0, nsrc == 1),
- * 9 / 10 / 11 = its 128x64 / 128x128 / 64x128 workgroup tiles forced. */
+ * 9 / 11 = its 128x64 / 64x128 workgroup tiles forced. */
 
 /* v = h[0] + h[1] + h[2] exactly as bf16 bit patterns: the host-side split the packer applies to the x6 weight planes (host only) */
 void bv2_test_x6_split(float v, uint16_t* h3);
@@ -93,7 +93,7 @@ int bv2_test_dds_layer(void* stream, const float* x, const float* pre_w_host, co
 
 /* tuning experiments (tools/kbench.py): force the split-K wave count / C_in chunk / tile-count target of the fp32 conv; 0 = default */
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target);
-/* conv_x6.hip: forced tile id (9..11, see bv2_kernels.h TILE_X6_*) per C_out class (multiple of 256 / of 128 / other) and chunk (32 / 64) */
+/* conv_x6.hip: forced tile id (9 / 11, see bv2_kernels.h TILE_X6_*) per C_out class (multiple of 256 / of 128 / other); the last argument is unused */
 void bv2_test_set_x6_tuning(int t256, int t128, int t64, int ck);
 /* bf16 / fp16 conv variants: cl_spec "<nt>:<id>[,...]" forces bf16 variant <id> for launches with <nt> 32-channel tiles ("" = the
  * shipped choice), cl_generic / hc_generic = 1 force the generic GEMM loop instead of the C_in-specialised tap-major one */
