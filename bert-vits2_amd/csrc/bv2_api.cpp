@@ -399,6 +399,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   const std::string k = key ? key : "";
   if (k == "fused_resblock") h->no_fused_resblock = value == 0;
   else if (k == "conv_x6") h->no_conv_x6 = value == 0;
+  else if (k == "conv_x6_c32") h->x6_narrow = value != 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;
   else if (k == "fused_attn_o") h->no_fused_attn_o = value == 0;
   else if (k == "attn_ksplit") h->attn_ksplit = value;

@@ -798,6 +798,8 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     // the n_rbk ResBlock1 branches run side by side
     const int nb = m.n_rbk;
     bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock;
+    // C = 32: two split-bf16 launches per pair (HBM-bound, 5 tensor passes) against one fused fp32-MFMA launch (MFMA-bound, 3 passes)
+    if (fused && c.h->x6_narrow && !c.h->no_conv_x6 && U.cout == 32 && m.rb[i][0][0][0].wx_off >= 0) fused = false;
     for (int j = 0; j < nb && fused; ++j)
       for (int d = 0; d < m.n_rbd; ++d)
         fused = fused && resblock_fused_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);

@@ -124,6 +124,7 @@ struct bv2_handle {
   int flow_dtype = BV2_F32;          // transformer-flow Encoder convs: BV2_F32 (conv_mfma.hip) or BV2_F16 (enc_f16.hip)
   // bv2_set_option switches (tests compare the fused kernels with the layer-wise ones)
   bool no_conv_x6 = false;           // "conv_x6" = 0: wide Generator convs on the fp32 matrix core (conv_mfma.hip) instead of the bf16x6 form
+  bool x6_narrow = true;             // "conv_x6_c32" = 0: the C = 32 stage on the fused fp32 pair kernel instead of layer-wise on conv_x6.hip
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
   bool no_fused_attn_o = false;      // "fused_attn_o" = 0: conv_o as its own launch after the attention kernel
   int attn_ksplit = -1;              // "attn_ksplit": key ranges per (head, query tile) of the fused attention; -1 = picked per shape, 0 / 1 = off

@@ -432,7 +432,7 @@ int pack_all(Model& m, Packer& P) {
       const int k = c.resblock_kernel_sizes[j];
       const std::string rp = "dec.resblocks." + std::to_string(i * m.n_rbk + j);
       // wide stages (the ones the LDS-tiled fp32 conv runs): the weights also as the three bf16 planes of conv_x6.hip
-      P.emit_x6 = ch >= 64 && ch % 32 == 0;
+      P.emit_x6 = ch >= 32 && ch % 32 == 0;
       for (int d = 0; d < m.n_rbd; ++d) {
         m.rb[i][j][d][0] = P.conv1d(rp + ".convs1." + std::to_string(d), ch, ch, k, true, true);
         m.rb[i][j][d][1] = P.conv1d(rp + ".convs2." + std::to_string(d), ch, ch, k, true, true);

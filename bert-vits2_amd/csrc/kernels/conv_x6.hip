@@ -430,7 +430,7 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
   if (tile == TILE_X6) {
     const int cls = max_cout_pad % 256 == 0 ? 0 : (max_cout_pad % 128 == 0 ? 1 : 2);
     if (g_x6_tile[cls]) tile = g_x6_tile[cls];
-    else tile = max_cout_pad % 128 == 0 ? TILE_X6_128x64 : TILE_X6_64x128;
+    else tile = max_cout_pad % 128 == 0 ? TILE_X6_128x64 : (max_cout_pad % 64 == 0 ? TILE_X6_64x128 : TILE_X6_32x256);
   }
   // Both tiles: wave tile 32x64 (MI = 1, NI = 2), 32-channel chunks — 164 / 178 registers, 31 / 46 KB of LDS.  Measured and removed in
   // round 3 (tools/tune_x6.py, profiles/r03_tune_x6_*.txt): 64-channel chunks (229 registers, two workgroups per CU: Generator pass
@@ -443,6 +443,9 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
     case TILE_X6_64x128:                          // 2 x 2 waves
       if (variant_name) *variant_name = "conv1d_x6<64x128>";
       return launch_x6_variant<2, 2, 1, 2, 32, 192>(stream, L, max_cout_pad);
+    case TILE_X6_32x256:                          // C = 32: the four waves side by side in time, all on the same 32-row weight stream
+      if (variant_name) *variant_name = "conv1d_x6<32x256>";
+      return launch_x6_variant<1, 4, 1, 2, 32, 320>(stream, L, max_cout_pad);
   }
   return -1;
 }

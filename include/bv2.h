@@ -30,7 +30,7 @@ extern "C" {
 
 #define BV2_ABI_VERSION 3   /* 3: bv2_decode_in.nz_tstride, the six ONNX-seam stage calls, bv2_detach_weights,
                                pack-layout version in the blob header */
-#define BV2_PACK_LAYOUT 9   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
+#define BV2_PACK_LAYOUT 10   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
                                a blob cached on disk by an older packer is rejected by bv2_attach_weights */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
@@ -251,6 +251,8 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "conv_x6"         the ResBlock convs of the wide fp32 Generator stages (C >= 64) on the bf16 matrix core: operands split exactly
  *                     into three bf16 planes, six cross products accumulated in fp32 — fp32 accuracy (dropped terms < 2^-23 of a
  *                     product) at 6/16 of the fp32-MFMA time (kernels/conv_x6.hip).  0: v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
+ *   "conv_x6_c32"     also the C = 32 stage layer-wise on conv_x6.hip (two launches per ResBlock pair, 44.6 us each at batch 1) instead
+ *                     of the fused fp32-MFMA pair kernel (one launch, 110 us); 0: resblock_fused.hip
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
  *   "fused_attn_o"    MultiHeadAttention.conv_o inside the attention kernel in the small-batch fp32 regime: head h writes partial
  *                     slab h, the LayerNorm sums the slabs (0: conv_o as its own launch)
