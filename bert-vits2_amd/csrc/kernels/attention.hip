@@ -27,6 +27,7 @@
 // costs more than a launch on this 8-XCD part: tools/probe/grid_barrier.hip).  Relative-value band terms belong to the workgroup that
 // owns the key; bias and residual move to the LayerNorm.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include "../bv2_kernels.h"
 
@@ -387,14 +388,34 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
     // h of the [B][C_out][T] output (head 0 adds the bias and the residual); the LayerNorm that follows sums the H slabs exactly as
     // it sums split-K slabs.  Removes the conv_o launch (and its HBM round trip of the attention output) from every layer.
     float* Of = Qs;
-    for (int c = tid >> 5; c < D; c += 2 * NW) {
-      float o = 0.f;
+    // The band term Σ_r p[i][i+r] * Ev[r][c]: this thread's NR probabilities are the same for every channel it handles — read ONCE
+    // into registers — and the channel loop is fully unrolled with a compile-time band bound (9 taps for the model's window 4, 17 for
+    // the kernel's maximum), unused taps contributing an exact 0.  As `for (r < NR)` with a runtime NR inside a runtime channel loop
+    // it was 6 x 9 dependent LDS round trips (tools/timeline.py: normalise + conv_o + store 14k of a 36k-cycle workgroup).
+    auto normalise = [&](auto nrm_c) __attribute__((always_inline)) {
+      constexpr int NRM = decltype(nrm_c)::value;
+      float sbv[NRM];
 #pragma unroll
-      for (int sl = 0; sl < NSLOT; ++sl) o += Os[sl * (D * AQ) + c * AQ + i];
-      o *= il;
-      for (int r = 0; r < NR; ++r) o += Sb[r * AQ + i] * Ev[r * D + c];
-      Of[c * AQ + i] = ig < T ? o : 0.f;
-    }
+      for (int r = 0; r < NRM; ++r) {
+        const float pv = Sb[(r < NR ? r : 0) * AQ + i];
+        sbv[r] = r < NR ? pv : 0.f;
+      }
+      const int c0 = tid >> 5;
+#pragma unroll 1
+      for (int it = 0; it < (D + 2 * NW - 1) / (2 * NW); ++it) {   // rolled: unrolled it keeps 6 x 21 loads live (222 registers, half the occupancy)
+        const int c = c0 + it * 2 * NW;
+        const int cc = c < D ? c : D - 1;
+        float o = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) o += Os[sl * (D * AQ) + cc * AQ + i];
+        o *= il;
+#pragma unroll
+        for (int r = 0; r < NRM; ++r) o += sbv[r] * Ev[(r < NR ? r : 0) * D + cc];
+        if (c < D) Of[c * AQ + i] = ig < T ? o : 0.f;
+      }
+    };
+    if (NR <= 9) normalise(std::integral_constant<int, 9>{});
+    else normalise(std::integral_constant<int, 2 * AMAXW + 1>{});
     const int Co = A.Co, G = A.wo_groups;
     const float* const wo = A.wo;
     const float* const bo = h == 0 ? A.bo : nullptr;

@@ -93,3 +93,33 @@ def test_conv1d_x6_resblock_shape_with_residual_in_place_like_the_generator():
     e6, e32 = rel_err(y6, ref), rel_err(y32, ref)
     assert e6 <= 2.0 * e32 + 2e-7, (e6, e32)
     assert (y6 - y32).abs().max().item() < 4e-6 * ref.abs().max().item()
+
+
+def test_generator_on_conv_x6_matches_the_fp32_mfma_generator():
+    """The whole Generator (models.py:538-557) three ways on one ragged batch: split-bf16 convs on every stage with C >= 32 (default),
+    C = 32 back on the fused fp32 pair kernel (conv_x6_c32 = 0), everything on the fp32 matrix core (conv_x6 = 0).  The waveforms
+    agree to fp32 round-off — the switch changes which matrix core forms the products, not the arithmetic."""
+    from bert_vits2_amd import hparams as H, models, synth
+    hp = H.default_v23()
+    m = models.from_hparams(hp)
+    m.load_state_dict(synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5), strict=False)
+    m = m.to("cuda").eval()
+    g = torch.Generator().manual_seed(11)
+    B, Ty = 3, 97
+    z = torch.randn(B, hp.inter_channels, Ty, generator=g).cuda()
+    yl = torch.tensor([97, 60, 33], dtype=torch.int64).cuda()
+    gv = torch.randn(B, hp.gin_channels, generator=g).cuda()
+    outs = {}
+    for name, opts in (("x6", {}), ("x6_c64", {"conv_x6_c32": 0}), ("mfma32", {"conv_x6": 0})):
+        for k, v in opts.items():
+            m.set_option(k, v)
+        outs[name] = m.stage_generator(z, yl, gv).cpu()
+        for k in opts:
+            m.set_option(k, 1)
+    ref = outs["mfma32"]
+    scale = ref.pow(2).mean().sqrt().item()
+    assert scale > 1e-3
+    for name in ("x6", "x6_c64"):
+        e = (outs[name] - ref).pow(2).mean().sqrt().item()
+        assert e <= 5e-6 * scale + 1e-7, (name, e, scale)
+    assert not torch.equal(outs["x6"], ref)      # the switch really changed the kernels
