@@ -83,7 +83,7 @@ unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int ti
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6, TILE_128x64 = 7,
        TILE_X6 = 8,            // the split-bf16 form of the LDS-tiled kernel (kernels/conv_x6.hip); TILE_AUTO picks it when every problem has w6
-       TILE_X6_128x64 = 9, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12 };   // tests / tuning: one x6 tile forced
+       TILE_X6_128x64 = 9, TILE_X6_128x64_LD = 10, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12 };   // tests / tuning: one x6 tile forced
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 // fp32 conv on the bf16 matrix core (kernels/conv_x6.hip): every fp32 operand is the exact sum of three bf16 values
 // (v = h1 + h2 + h3, 8 + 8 + 8 significand bits), and the product is accumulated from the six largest of the nine cross terms

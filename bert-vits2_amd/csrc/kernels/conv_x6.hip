@@ -53,16 +53,25 @@ constexpr int X6_UNIT = 3 * 512;          // elements of one (group, tap) unit o
 
 }  // namespace
 
-template <int WM, int WN, int MI, int NI, int CK, int XR>
-__global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ? 3 : 2) conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
+// NLD = 2: "loader waves".  Two extra waves per workgroup do nothing but the X staging — global loads of chunk c+2, split of chunk
+// c+1 into the OTHER of two LDS buffers — while the four MFMA waves run chunk c; one barrier per chunk.  In the NLD = 0 form the MFMA
+// waves stage themselves between two barriers with the matrix pipe idle: 2.5-4k cycles per chunk (tools/timeline.py), which the other
+// resident workgroups hide only partly and, in the one-workgroup-per-CU launches of the C = 256 stage, not at all.  Costs a second
+// 31 KB buffer (two workgroups per CU instead of three; with the loaders still 12 waves per CU).
+template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD>
+__global__ void __launch_bounds__(256 + 64 * NLD, (NLD > 0 || (MI * NI <= 2 && CK == 32 && XR <= 128)) ? 3 : 2)
+conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
   constexpr int PITCH = CK + 8;                    // bf16 elements per LDS row: (CK/8 + 1) * 16 B, an odd multiple of 16 B
   constexpr int PLANE = XR * PITCH;                // elements per plane
   constexpr int GR = CK / 16;                      // 16-channel groups per chunk = ring slots
   constexpr int NRG = XR / 64;                     // 64-column groups of the staged tile
-  constexpr int OPW = CK / 32;                     // channel octets per wave per column group (CK/8 octets over 4 waves)
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int STW = NLD > 0 ? NLD : 4;           // waves that stage X
+  constexpr int OPW = CK / 8 / STW;                // channel octets per staging wave per column group
+  constexpr int BUFSZ = 3 * PLANE;                 // elements of one X buffer (NLD > 0: two of them)
+  static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
+  static_assert((CK / 8) % STW == 0, "octets dealt evenly");
   static_assert(XR % 64 == 0 && XR >= BN && (CK == 32 || CK == 64), "staged tile");
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]
 
@@ -85,7 +94,9 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int wm = wid / WN, wn = wid % WN;
+  const int wm = (wid & 3) / WN, wn = (wid & 3) % WN;
+  const bool loader = NLD > 0 && wid >= 4;
+  const int sw = NLD > 0 ? wid - 4 : wid;                          // index among the staging waves (MFMA waves of NLD > 0: unused)
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsw = 0;           // timeline stamps (tools/timeline.py; L.dbg is null in the product)
   if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int b = by / mtiles;
@@ -175,14 +186,14 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
     }
 #pragma unroll
     for (int o = 0; o < OPW; ++o) {
-      const unsigned row0 = (unsigned)(c * CK + (wid + 4 * o) * 8) * x_rs4;
+      const unsigned row0 = (unsigned)(c * CK + (sw + STW * o) * 8) * x_rs4;
 #pragma unroll
       for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
         for (int e = 0; e < 8; ++e) xr[rg][o][e] = x6_ld(x0p, row0 + (unsigned)e * x_rs4 + tc[rg]);
     }
   };
-  auto store_x = [&]() __attribute__((always_inline)) {
+  auto store_x = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int rg = 0; rg < NRG; ++rg) {
       const float sc = colsc[rg] * xm[rg];
@@ -202,7 +213,7 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
           a -= x6_lo(u2); bq -= x6_hi(u2);
           p1[w] = u1; p2[w] = u2; p3[w] = x6_pack(a, bq);
         }
-        unsigned short* dst = xs + (rg * 64 + lane) * PITCH + (wid + 4 * o) * 8;
+        unsigned short* dst = xs + buf * BUFSZ + (rg * 64 + lane) * PITCH + (sw + STW * o) * 8;
         *reinterpret_cast<xu32x4*>(dst) = p1;
         *reinterpret_cast<xu32x4*>(dst + PLANE) = p2;
         *reinterpret_cast<xu32x4*>(dst + 2 * PLANE) = p3;
@@ -210,8 +221,26 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
     }
   };
 
+  if constexpr (NLD > 0) {
+    if (loader) {
+      // chunk c + 1 is split into the buffer the MFMA waves left at the previous barrier while they run chunk c; chunk c + 2's loads fly
+      // over the barrier and the whole of chunk c + 1
+      issue_x(0);
+      store_x(0);
+      if (nchunks > 1) issue_x(1);
+      __syncthreads();
+      for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) {
+          store_x((c + 1) & 1);
+          if (c + 2 < nchunks) issue_x(c + 2);
+        }
+        __syncthreads();
+      }
+      return;
+    }
+  }
   // prologue: X chunk 0 first (the long latency), then prime the ring with the first two units of every group's stream
-  issue_x(0);
+  if constexpr (NLD == 0) issue_x(0);
   {
     const int s0 = step_after(0, 0);
     const int j1 = k > 1 ? 1 : 0, c1 = k > 1 ? 0 : (nchunks > 1 ? 1 : 0);
@@ -221,7 +250,7 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
 #pragma unroll
     for (int g = 0; g < GR; ++g) { load_unit(g, 1, s1); __builtin_amdgcn_sched_barrier(0); }
   }
-  store_x();
+  if constexpr (NLD == 0) store_x(0);
   __syncthreads();
   if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
@@ -231,9 +260,11 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
   // conditional tap inside the loop made every ring register a phi (copies + spills at the merge).
   auto chunk = [&](int c, int PAR) __attribute__((always_inline)) {           // PAR: a literal at every (inlined) call site
     const bool next_chunk = (c + 1) < nchunks;
-    if (next_chunk) issue_x(c + 1);               // in flight under this chunk's MFMAs
+    if constexpr (NLD == 0) {
+      if (next_chunk) issue_x(c + 1);             // in flight under this chunk's MFMAs
+    }
     xbf16x8 bb[2][NI][3];
-    const unsigned short* xrow = xlane;
+    const unsigned short* xrow = xlane + (NLD > 0 ? (c & 1) * BUFSZ : 0);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -275,11 +306,16 @@ __global__ void __launch_bounds__(256, (MI * NI <= 2 && CK == 32 && XR <= 128) ?
     };
     for (int j = 0; j + 1 < k; j += 2) { tap(j, PAR); tap(j + 1, PAR ^ 1); }
     tap(k - 1, PAR);
-    if (next_chunk) {
+    if constexpr (NLD > 0) {
+      unsigned long long ta = 0;
+      if (L.dbg) ta = __builtin_amdgcn_s_memtime();
+      __syncthreads();                            // the loaders have the next buffer ready; this one is free for chunk c + 2
+      if (L.dbg) tsw += __builtin_amdgcn_s_memtime() - ta;
+    } else if (next_chunk) {
       unsigned long long ta = 0;
       if (L.dbg) ta = __builtin_amdgcn_s_memtime();
       __syncthreads();                            // every wave is done reading this chunk's tile
-      store_x();
+      store_x(0);
       __syncthreads();
       if (L.dbg) tsw += __builtin_amdgcn_s_memtime() - ta;
     }
@@ -387,7 +423,7 @@ bool conv_x6_supported(const ConvLaunch& L) {
 static int g_x6_tile[3] = {0, 0, 0};
 void conv_x6_set_tuning(int t256, int t128, int t64, int) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; }
 
-template <int WM, int WN, int MI, int NI, int CK, int XR>
+template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD = 0>
 static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_cout_pad) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   const int mtiles = (max_cout_pad + BM - 1) / BM;
@@ -415,10 +451,10 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
     for (int i = 0; i < Ls.nprob && i < 3; ++i) ks |= (Ls.p[i].k & 255) << (8 * i);
     Ls.dbg = timeline_slice(grid.x, grid.y, grid.z, 6000000 + BM * 1000 + BN, ks, Ls.p[0].cin, Ls.L);
   }
-  const size_t lds = (size_t)3 * XR * (CK + 8) * 2;
-  auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR>;
+  const size_t lds = (size_t)(NLD > 0 ? 2 : 1) * 3 * XR * (CK + 8) * 2;
+  auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR, NLD>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, Ls, mtiles, per_xcd, snake_n);
+  hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * NLD), lds, stream, Ls, mtiles, per_xcd, snake_n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -430,7 +466,13 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
   if (tile == TILE_X6) {
     const int cls = max_cout_pad % 256 == 0 ? 0 : (max_cout_pad % 128 == 0 ? 1 : 2);
     if (g_x6_tile[cls]) tile = g_x6_tile[cls];
-    else tile = max_cout_pad % 128 == 0 ? TILE_X6_128x64 : (max_cout_pad % 64 == 0 ? TILE_X6_64x128 : TILE_X6_32x256);
+    else if (max_cout_pad % 128 == 0) {
+      // few workgroups per CU (batch 1: 288 / 1152 on 256 CUs): the loader-wave form — Generator pass 2.045 -> 1.937 ms; with dozens per
+      // CU (B = 8 x 512 frames) the third resident workgroup of the plain form is worth more: 18.80 against 18.89 ms
+      // (tools/tune_x6.py, profiles/r03_tune_x6_loader_*.txt)
+      const long wgs = (long)((L.L + 63) / 64) * (max_cout_pad / 128) * L.B * L.nprob;
+      tile = wgs <= 2048 ? TILE_X6_128x64_LD : TILE_X6_128x64;
+    } else tile = max_cout_pad % 64 == 0 ? TILE_X6_64x128 : TILE_X6_32x256;
   }
   // Both tiles: wave tile 32x64 (MI = 1, NI = 2), 32-channel chunks — 164 / 178 registers, 31 / 46 KB of LDS.  Measured and removed in
   // round 3 (tools/tune_x6.py, profiles/r03_tune_x6_*.txt): 64-channel chunks (229 registers, two workgroups per CU: Generator pass
@@ -440,6 +482,9 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
     case TILE_X6_128x64:                          // all four waves on the same 64 columns, one 32-row block each
       if (variant_name) *variant_name = "conv1d_x6<128x64>";
       return launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
+    case TILE_X6_128x64_LD:                       // the same tile with two loader waves and two X buffers
+      if (variant_name) *variant_name = "conv1d_x6<128x64,ld>";
+      return launch_x6_variant<4, 1, 1, 2, 32, 128, 2>(stream, L, max_cout_pad);
     case TILE_X6_64x128:                          // 2 x 2 waves
       if (variant_name) *variant_name = "conv1d_x6<64x128>";
       return launch_x6_variant<2, 2, 1, 2, 32, 192>(stream, L, max_cout_pad);

@@ -25,7 +25,7 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
                     int64_t slab_stride);
 
 /* tile 8 = the split-bf16 form of the LDS-tiled kernel with its own tile choice (kernels/conv_x6.hip; cin % 32 == 0, nsrc == 1),
- * 9 / 11 / 12 = its 128x64 / 64x128 / 32x256 workgroup tiles forced. */
+ * 9 / 10 / 11 / 12 = its 128x64 / 128x64-with-loader-waves / 64x128 / 32x256 workgroup tiles forced. */
 
 /* v = h[0] + h[1] + h[2] exactly as bf16 bit patterns: the host-side split the packer applies to the x6 weight planes (host only) */
 void bv2_test_x6_split(float v, uint16_t* h3);

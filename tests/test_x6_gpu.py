@@ -32,7 +32,7 @@ def _run(lib, x, w, bias, tile, k, dil, lrelu=0.0, relu=0, res=None, res_mode=0,
     return out
 
 
-@pytest.mark.parametrize("tile", [8, 9, 11, 12])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12])
 @pytest.mark.parametrize("B,cin,cout,k,dil,L", X6_CASES)
 def test_conv1d_x6_is_as_accurate_as_the_fp32_mfma_kernel(B, cin, cout, k, dil, L, tile):
     lib = _lib()
@@ -55,7 +55,7 @@ def test_conv1d_x6_is_as_accurate_as_the_fp32_mfma_kernel(B, cin, cout, k, dil, 
     assert r6 <= 2.0 * r32 + 3e-7, (r6, r32)
 
 
-@pytest.mark.parametrize("tile", [9, 11, 12])
+@pytest.mark.parametrize("tile", [9, 10, 11, 12])
 def test_conv1d_x6_fused_epilogues(tile):
     """lrelu pre-activation, input mask, per-batch bias, ReLU, pre-mask, residual add / rsub, post-mask — conv_mfma.hip's epilogue."""
     lib = _lib()

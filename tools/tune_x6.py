@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bert_vits2_amd import hparams as H, lib as L, models, synth  # noqa: E402
 
-NAMES = {0: "shipped", 9: "128x64", 11: "64x128"}   # (256x64, 64x256 and a 32x128 wave tile were measured in round 3 and removed: profiles/r03_tune_x6_*.txt)
+NAMES = {0: "shipped", 9: "128x64", 10: "128x64ld", 11: "64x128", 12: "32x256"}   # (256x64, 64x256 and a 32x128 wave tile were measured in round 3 and removed: profiles/r03_tune_x6_*.txt)
 
 
 def main():
