@@ -75,14 +75,15 @@ int launch_bert_embed_ln(hipStream_t stream, const BertEmbedArgs& a) {
 // values per thread in registers, every load in flight at once.  Wave = 8 tokens x 8 channel groups, so each pass of the exact
 // two-pass variance is three __shfl_xor butterflies + one exchange between the 16 waves through LDS (layernorm.hip's scheme at
 // 4x the width).
-constexpr int BLN_TT = 8, BLN_G = 128;
-
-template <int CPT, int NSLAB>   // NSLAB > 0: compile-time slab count (every load of a thread in flight at once); 0: runtime loop
+// TT = 8 tokens x 128 channel groups per workgroup, or — for a single short sentence, where 8-token workgroups are only ceil(S/8) = 7
+// CUs pulling 0.9 MB through 32-byte pieces — TT = 2 tokens x 512 channel groups: 27 workgroups, two channels (x nslab loads) per thread.
+template <int CPT, int NSLAB, int TT>   // NSLAB > 0: compile-time slab count (every load of a thread in flight at once); 0: runtime loop
 __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
-  __shared__ float red[2][16][BLN_TT];
-  const int tx = threadIdx.x & (BLN_TT - 1), ty = threadIdx.x >> 3;
+  constexpr int G = 1024 / TT;              // channel groups
+  __shared__ float red[2][16][TT];
+  const int tx = threadIdx.x & (TT - 1), ty = threadIdx.x / TT;
   const int b = blockIdx.y;
-  const int t = blockIdx.x * BLN_TT + tx;
+  const int t = blockIdx.x * TT + tx;
   const int C = A.C, T = A.T;
   const bool tok = t < T;
   const int tcl = tok ? t : T - 1;
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   float v[CPT], gm[CPT], bt[CPT];
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = ty + i * BLN_G;
+    const int c = ty + i * G;
     const int off = c * T + tcl;
     float x = ap[off];
     if constexpr (NSLAB > 0) {
@@ -114,10 +115,9 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) s += v[i];
-  s += __shfl_xor(s, 8);
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
-  if ((threadIdx.x & 63) < BLN_TT) red[0][wv][tx] = s;
+#pragma unroll
+  for (int o = TT; o < 64; o <<= 1) s += __shfl_xor(s, o);       // lanes tx, tx + TT, ...: the wave's 64 / TT channel groups of token tx
+  if ((threadIdx.x & 63) < TT) red[0][wv][tx] = s;
   __syncthreads();
   float m = 0.f;
 #pragma unroll
@@ -126,10 +126,9 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) { const float d = v[i] - mean; q += d * d; }
-  q += __shfl_xor(q, 8);
-  q += __shfl_xor(q, 16);
-  q += __shfl_xor(q, 32);
-  if ((threadIdx.x & 63) < BLN_TT) red[1][wv][tx] = q;
+#pragma unroll
+  for (int o = TT; o < 64; o <<= 1) q += __shfl_xor(q, o);
+  if ((threadIdx.x & 63) < TT) red[1][wv][tx] = q;
   __syncthreads();
   float qq = 0.f;
 #pragma unroll
@@ -140,17 +139,28 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   const float mk = A.mask ? A.mask[(int64_t)b * T + t] : 1.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = ty + i * BLN_G;
+    const int c = ty + i * G;
     outp[c * T + t] = ((v[i] - mean) * rstd * gm[i] + bt[i]) * mk;
   }
 }
 
 int launch_bert_ln(hipStream_t stream, const BertLnArgs& a) {
+  constexpr int BLN_G = 128;                        // channel groups of the 8-token form
   if (a.C < BLN_G || a.C % BLN_G || a.C > 8 * BLN_G || a.T < 1 || a.B < 1 || a.nslab < 1) return -1;
   if ((int64_t)a.C * a.T >= (1ll << 31)) return -1;
-  dim3 grid((a.T + BLN_TT - 1) / BLN_TT, a.B);
+  // few tokens (one short sentence): 2-token workgroups, 4x the CUs (measured: profiles/r03_*bert*)
+  const bool narrow = (int64_t)a.B * a.T <= 128 && a.C % 512 == 0 && a.C <= 1024 && (a.nslab == 1 || a.nslab == 2 || a.nslab == 4);
+  if (narrow) {
+    dim3 grid((a.T + 1) / 2, a.B);
+#define BLN2(CPT_, NS_) hipLaunchKernelGGL((bert_ln_kernel<CPT_, NS_, 2>), grid, dim3(1024), 0, stream, a)
+    if (a.C == 512) { if (a.nslab == 1) BLN2(1, 1); else if (a.nslab == 2) BLN2(1, 2); else BLN2(1, 4); }
+    else { if (a.nslab == 1) BLN2(2, 1); else if (a.nslab == 2) BLN2(2, 2); else BLN2(2, 4); }
+#undef BLN2
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  dim3 grid((a.T + 7) / 8, a.B);
   const int cpt = a.C / BLN_G;
-#define BLN_LAUNCH(CPT_, NS_) hipLaunchKernelGGL((bert_ln_kernel<CPT_, NS_>), grid, dim3(1024), 0, stream, a)
+#define BLN_LAUNCH(CPT_, NS_) hipLaunchKernelGGL((bert_ln_kernel<CPT_, NS_, 8>), grid, dim3(1024), 0, stream, a)
 #define BLN_CPT(CPT_)                                                                                  \
   switch (a.nslab) {                                                                                   \
     case 1: BLN_LAUNCH(CPT_, 1); break;                                                                \
