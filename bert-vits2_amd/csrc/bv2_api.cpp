@@ -758,6 +758,7 @@ int bv2_test_conv_timeline_report(long long* meta, int max_launches) { return co
 
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target) { conv_set_tuning(splitk_waves, force_ck, tile_target); }
 void bv2_test_set_x6_tuning(int t256, int t128, int t64, int ck) { conv_x6_set_tuning(t256, t128, t64, ck); }
+void bv2_test_x6_occupancy(int* out4) { conv_x6_occupancy(out4); }
 void bv2_test_set_variants(const char* cl_spec, int cl_generic, int hc_generic) {
   conv_cl_set_tuning(cl_spec, cl_generic);
   conv_f16_set_tuning(hc_generic);

@@ -59,7 +59,7 @@ constexpr int X6_UNIT = 3 * 512;          // elements of one (group, tap) unit o
 // resident workgroups hide only partly and, in the one-workgroup-per-CU launches of the C = 256 stage, not at all.  Costs a second
 // 31 KB buffer (two workgroups per CU instead of three; with the loaders still 12 waves per CU).
 template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD>
-__global__ void __launch_bounds__(256 + 64 * NLD, (NLD > 0 || (MI * NI <= 2 && CK == 32 && XR <= 128)) ? 3 : 2)
+__global__ void __launch_bounds__(64 * (WM * WN + NLD), WM * WN > 4 ? 2 : ((NLD > 0 || (MI * NI <= 2 && CK == 32 && XR <= 128)) ? 3 : 2))
 conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
@@ -67,10 +67,11 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   constexpr int PLANE = XR * PITCH;                // elements per plane
   constexpr int GR = CK / 16;                      // 16-channel groups per chunk = ring slots
   constexpr int NRG = XR / 64;                     // 64-column groups of the staged tile
+  constexpr int NCW = WM * WN;                     // MFMA waves: 4, or 8 (with loader waves only)
   constexpr int STW = NLD > 0 ? NLD : 4;           // waves that stage X
   constexpr int OPW = CK / 8 / STW;                // channel octets per staging wave per column group
   constexpr int BUFSZ = 3 * PLANE;                 // elements of one X buffer (NLD > 0: two of them)
-  static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
+  static_assert(NCW == 4 || (NCW == 8 && NLD > 0), "4 MFMA waves, or 8 staged by loader waves");
   static_assert((CK / 8) % STW == 0, "octets dealt evenly");
   static_assert(XR % 64 == 0 && XR >= BN && (CK == 32 || CK == 64), "staged tile");
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]
@@ -94,9 +95,9 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int wm = (wid & 3) / WN, wn = (wid & 3) % WN;
-  const bool loader = NLD > 0 && wid >= 4;
-  const int sw = NLD > 0 ? wid - 4 : wid;                          // index among the staging waves (MFMA waves of NLD > 0: unused)
+  const int wm = (wid % NCW) / WN, wn = (wid % NCW) % WN;
+  const bool loader = NLD > 0 && wid >= NCW;
+  const int sw = NLD > 0 ? wid - NCW : wid;                          // index among the staging waves (MFMA waves of NLD > 0: unused)
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tsw = 0;           // timeline stamps (tools/timeline.py; L.dbg is null in the product)
   if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int b = by / mtiles;
@@ -454,8 +455,25 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
   const size_t lds = (size_t)(NLD > 0 ? 2 : 1) * 3 * XR * (CK + 8) * 2;
   auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR, NLD>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * NLD), lds, stream, Ls, mtiles, per_xcd, snake_n);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + NLD)), lds, stream, Ls, mtiles, per_xcd, snake_n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// workgroups per CU the runtime grants each shipped variant (tools/x6_occupancy.py): {128x64, 128x64 with loaders, 64x128, 32x256}.
+// Measured 3 / 2 / 2 / 2.  (tools/timeline.py: the 6-wave loader workgroups actually share a CU only 1.14-fold at 145 registers — a
+// second one fits only if its waves land on complementary SIMDs; a 117-register build that always fits ran two at once and each twice
+// as long: ONE loader workgroup already keeps the CU's matrix pipes ~70 % busy inside its main loop.)
+void conv_x6_occupancy(int out[4]) {
+  auto q = [](auto kern, int threads, size_t lds) {
+    int n = -1;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, lds) != hipSuccess) n = -1;
+    return n;
+  };
+  out[0] = q(conv1d_x6_kernel<4, 1, 1, 2, 32, 128, 0>, 256, (size_t)3 * 128 * 40 * 2);
+  out[1] = q(conv1d_x6_kernel<4, 1, 1, 2, 32, 128, 2>, 384, (size_t)2 * 3 * 128 * 40 * 2);
+  out[2] = q(conv1d_x6_kernel<2, 2, 1, 2, 32, 192, 0>, 256, (size_t)3 * 192 * 40 * 2);
+  out[3] = q(conv1d_x6_kernel<1, 4, 1, 2, 32, 320, 0>, 256, (size_t)3 * 320 * 40 * 2);
 }
 
 int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name) {

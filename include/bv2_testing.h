@@ -95,6 +95,8 @@ int bv2_test_dds_layer(void* stream, const float* x, const float* pre_w_host, co
 void bv2_test_set_tuning(int splitk_waves, int force_ck, long tile_target);
 /* conv_x6.hip: forced tile id (9 / 11, see bv2_kernels.h TILE_X6_*) per C_out class (multiple of 256 / of 128 / other); the last argument is unused */
 void bv2_test_set_x6_tuning(int t256, int t128, int t64, int ck);
+/* workgroups per CU hipOccupancyMaxActiveBlocksPerMultiprocessor grants the conv_x6 variants {128x64, 128x64 + loader waves, 64x128, 32x256} */
+void bv2_test_x6_occupancy(int* out4);
 /* bf16 / fp16 conv variants: cl_spec "<nt>:<id>[,...]" forces bf16 variant <id> for launches with <nt> 32-channel tiles ("" = the
  * shipped choice), cl_generic / hc_generic = 1 force the generic GEMM loop instead of the C_in-specialised tap-major one */
 void bv2_test_set_variants(const char* cl_spec, int cl_generic, int hc_generic);
