@@ -114,6 +114,7 @@ inline void x6_split(float v, uint16_t h[3]) {
 }
 bool conv_x6_supported(const ConvLaunch& L);        // every problem carries w6 and fits the staged tile
 int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
+void conv_x6_occupancy(int out[4]);                              // workgroups per CU granted to {128x64, 128x64 + loaders, 64x128, 32x256}
 void conv_x6_set_tuning(int t256, int t128, int t64, int ck);   // tuning experiments only (tools/tune_x6.py); 0 = shipped choice
 // true when TILE_AUTO will pick the split-K kernel for this launch (small-N regime); only then may ksplit exceed 1
 bool conv_use_splitk(const ConvLaunch& L);
