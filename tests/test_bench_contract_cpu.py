@@ -38,3 +38,23 @@ def test_traffic_lookups_do_not_raise():
         t = bench.pmc_traffic(kern, cfg)
         assert isinstance(t, dict) and "bytes_per_launch" in t
     assert bench.bert_traffic() is None or bench.bert_traffic() > 0
+
+
+def test_pmc_family_names_match_the_names_the_launcher_reports():
+    """`bench.py` looks a kernel's PMC traffic up by the variant name `launch_conv1d_x6` reports; `tools/collect_traffic.py` derives the
+    same name from the kernel's template arguments in the rocprofv3 trace.  The two must agree (a mismatch silently turns
+    `roofline.traffic` into null)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from collect_traffic import family
+    src = open(os.path.join(root, "bert-vits2_amd", "csrc", "kernels", "conv_x6.hip")).read()
+    cases = {"<4, 1, 1, 2, 32, 128, 0>": "conv1d_x6<128x64>", "<4, 1, 1, 2, 32, 128, 2>": "conv1d_x6<128x64,ld>",
+             "<2, 2, 1, 2, 32, 192, 0>": "conv1d_x6<64x128>", "<1, 4, 1, 2, 32, 320, 0>": "conv1d_x6<32x256>"}
+    for targs, name in cases.items():
+        assert family(f"void bv2::conv1d_x6_kernel{targs}(bv2::ConvLaunch, int, int, int)") == name
+        assert f'"{name}"' in src, name
+        a = [v.strip() for v in targs.strip("<>").split(",")]
+        inst = f"launch_x6_variant<{', '.join(a[:6])}" + (f", {a[6]}>" if a[6] != "0" else ">")
+        assert inst in src, inst
