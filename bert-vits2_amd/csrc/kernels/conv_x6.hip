@@ -15,15 +15,17 @@
 //   GEMM view:  M = C_out (rows),  N = time (columns, contiguous in HBM, fp32 [B][C][T] like every other tensor of the fp32 path),
 //   K = (C_in group of 16, tap j).
 //
-// Workgroup = 4 waves = WM x WN, wave tile = MI x NI blocks of 32x32.
+// Workgroup = 4 MFMA waves = WM x WN (+ 2 loader waves in the NLD = 2 form, below), wave tile = MI x NI blocks of 32x32 (shipped: 1 x 2).
 //   * weights: pre-split at pack time into three bf16 planes in MFMA-A fragment order (x6_w_index, bv2_kernels.h), streamed
 //     global -> registers through a ring with TWO slots per 16-channel group of the chunk (taps j and j + 1; the ring is never
 //     drained: every group's stream runs (g, 0) .. (g, k-1), then (g, 0) of the next chunk — a unit is requested 2*GR - 1 units ahead);
 //   * X: a chunk of CK input channels x (BN + halo) columns is loaded fp32 from HBM (lane = column: coalesced), pre-activated,
 //     split into its three planes ONCE per element and written CHANNELS-LAST to LDS (plane p: [column][CK + 8] bf16, row pitch an
 //     odd multiple of 16 B), so that the MFMA B operand — 8 consecutive channels of one column — is one ds_read_b128 and the k taps
-//     are row shifts of the same tile.  The next chunk's global loads fly under this chunk's MFMAs; two barriers per chunk.
-//   * per unit (16 channels x 1 tap): NI*3 ds_read_b128 + MI*3 global_load_dwordx4 feed MI*NI*6 MFMAs (24 for the 2x2 wave tile).
+//     are row shifts of the same tile.  The next chunk's global loads fly under this chunk's MFMAs; two barriers per chunk (one, and
+//     the staging off the MFMA waves altogether, with loader waves).
+//   * per unit (16 channels x 1 tap): NI*3 ds_read_b128 + MI*3 global_load_dwordx4 feed MI*NI*6 MFMAs (12 for the 32x64 wave tile).
+// Tiles and what was measured around them: launch_conv1d_x6 at the end of the file; DESIGN.md 3 / 5.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
 
