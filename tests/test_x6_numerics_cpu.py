@@ -2,7 +2,8 @@
 
 Every fp32 number is the exact sum of three bf16 numbers (round-to-nearest-even at every step); of the nine cross terms of a product
 the kernel accumulates six — w1x1, w1x2, w2x1, w1x3, w2x2, w3x1 — each exact in fp32, and drops w2x3 + w3x2 + w3x3.  Checked here:
-the dropped part is below 2^-22 of the product for every pair (2^-23.9 typical), and a long dot product accumulated that way in fp32
+the dropped part is below 2^-22 of the product for every pair (measured over 4e5 random pairs: worst 2^-24.3 — under half an fp32 ulp —
+median 2^-29), and a long dot product accumulated that way in fp32
 is as close to the fp64 result as the plain fp32 dot product.  The GPU-side twin is tests/test_x6_gpu.py (the kernel against the
 fp32-MFMA kernel); the C-side split is checked bit-exactly in tests/test_cabi_cpu.py."""
 import numpy as np
