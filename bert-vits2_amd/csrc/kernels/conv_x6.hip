@@ -300,9 +300,21 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
 #undef X6_PROD
         load_unit(g, SL, step);
         // pin the emitted order: next unit's LDS reads first (they land under this unit's MFMAs), MFMAs, ring loads
-        __builtin_amdgcn_sched_group_barrier(0x100, NI * 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI * 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, MI * 3, 0);
+        // emitted order: one LDS read (next unit's B) or one ring load behind every MFMA, so that they issue in the shadow of the
+        // 32-cycle matrix op instead of in front of / behind the block of 12 (a lone wave per SIMD ran 530 ticks per 384-cycle unit)
+        constexpr int NM = MI * NI * 6, NDS = NI * 3, NVM = MI * 3;
+        static_assert(NM >= NDS + NVM, "one memory instruction per MFMA at most");
+#pragma unroll
+        for (int q = 0; q < NDS; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NDS - NVM, 0);
+#pragma unroll
+        for (int q = 0; q < NVM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);        // keep program order: the ring's vmcnt distances stay 2*GR - 1 units
       }
       xrow = xnext;
