@@ -5,7 +5,8 @@
 
 s_memtime is per-XCD (the eight counters have different offsets), so spans are taken per XCD.  For each launch: workgroups per CU,
 per-problem (k) phase times, MFMA-pipe utilisation = sum of MFMA cycles issued by all waves / (span x SIMDs), and how the span splits
-into 'all CUs busy' vs tail."""
+into 'all CUs busy' vs tail.  conv_x6 launches (tile id 6xxxxxx): phases per k, ticks per 12-MFMA unit, time at chunk switches, and how
+many workgroups actually share a CU while it is busy."""
 import sys
 
 import numpy as np
@@ -39,8 +40,39 @@ def main():
             spans.append(v[m, 3].max() - v[m, 0].min())
         span = float(np.mean(spans))
         bm, bn = tile // 1000, tile % 1000
-        kk = [(ks >> (8 * j)) & 255 for j in range(3) if (ks >> (8 * j)) & 255]
+        kk = [int((ks >> (8 * j)) & 255) for j in range(3) if (ks >> (8 * j)) & 255]
         line = f"#{i:3d} {bm}x{bn} k={kk} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU), span {span:9.0f} (per-XCD {min(spans)}..{max(spans)})"
+        if tile // 1000000 == 6:
+            # conv_x6.hip: tile id 6000000 + BM*1000 + BN; slot 6 = taps | (ticks spent at chunk switches / barriers) << 16
+            t = tile - 6000000
+            kx, sw = v[:, 6] & 0xffff, v[:, 6] >> 16
+            conc, busy = [], []
+            for kcu in np.unique(cukey):
+                mm = cukey == kcu
+                a, b = v[mm, 0].astype(np.int64), v[mm, 3].astype(np.int64)
+                o = np.argsort(a)
+                a, b = a[o], b[o]
+                cs, ce, uni = a[0], b[0], 0
+                for s0, e0 in zip(a[1:], b[1:]):
+                    if s0 <= ce:
+                        ce = max(ce, e0)
+                    else:
+                        uni += ce - cs
+                        cs, ce = s0, e0
+                uni += ce - cs
+                conc.append((b - a).sum() / uni)
+                busy.append(b.max() - a.min())
+            life = v[:, 3] - v[:, 0]
+            print(f"#{i:3d} conv_x6 {t // 1000}x{t % 1000} k={kk} cin {cin} L {Lc}: {len(v)} wgs on {ncu} CUs ({len(v) / ncu:.2f}/CU), workgroups sharing a CU while it is busy "
+                  f"{np.mean(conc):.2f}, CU busy span {np.mean(busy):8.0f} (max {np.max(busy)}), longest workgroup {life.max()}, mean {life.mean():8.0f}")
+            for k in kk:
+                m = kx == k
+                if m.any():
+                    units = (cin / 16) * k
+                    lo = v[m, 2] - v[m, 1]
+                    print(f"      k{k}: n {m.sum()} prologue {np.mean(v[m, 1] - v[m, 0]):7.0f} loop {lo.mean():8.0f} ({lo.mean() / units:6.1f} per 12-MFMA unit; chunk switches / barrier waits "
+                          f"{np.mean(sw[m]):7.0f}) epilogue {np.mean(v[m, 3] - v[m, 2]):7.0f} life {np.mean(life[m]):8.0f}")
+            continue
         if 99000 <= tile < 100000:
             t = tile - 99000
             wn, ni, io = t // 100, (t // 10) % 10, t % 10
