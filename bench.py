@@ -77,6 +77,11 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=2, help="requests in flight for the secondary two-stream leg of config 2")
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
     ap.add_argument("--master-port", type=int, default=0, help="self-launched N>1 runs: rendezvous port on 127.0.0.1 (0 = pick a free one)")
+    ap.add_argument("--library", default=None, metavar="PATH",
+                    help="same-box A/B of two BUILDS (tools/ab_build.py): load this libbv2 (same C ABI) instead of the in-tree build")
+    ap.add_argument("--details-out", default=None, metavar="PATH",
+                    help="where the full record (launch tables, PMC families, every secondary leg in full) is written; default "
+                         "gpurun_out/bench_details.json.  stdout carries ONE compact (< 4 KB) strict-JSON line")
     ap.add_argument("--seam", default=None, help=argparse.SUPPRESS)   # tests only: module replacing the GPU-touching seam (see Seam)
     return ap.parse_args(argv)
 
@@ -181,8 +186,7 @@ def parity_block(model, hp, dev, par):
     batch, nw, nz, ref = par
     model.enable_graphs(False)
     model.set_generator_dtype(torch.float32)
-    if hp.use_transformer_flow:
-        model.set_flow_dtype(torch.float32)
+    model.set_flow_dtype(torch.float32)                  # both flow variants have an fp16 form: the block labelled fp32 is fp32
     b = {k: v.to(dev) for k, v in batch.items()}
     o, attn, y_mask, _ = model.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"],
                                      noise_w=nw, noise_z=nz.to(dev), **KW)
@@ -668,6 +672,130 @@ def dtype_label(res):
         return "f32"
     return f"gen={gd},flow={fd}"                 # what each part computes in (fp32 accumulate everywhere)
 
+HEADLINE_MAX_BYTES = 4096          # the driver parses the LAST stdout line; round 3's 36 KB line was not parsed (BENCH_r03.parsed == null)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _leg(v):
+    """One secondary leg in one line: what it reached, how long a step took, the roofline fraction of its dominant kernel."""
+    if not isinstance(v, dict):
+        return v
+    if "error" in v:
+        return dict(error=str(v["error"])[:80])
+    out = _pick(v, ("value", "ms_per_step", "ms_per_request", "ms_per_sentence", "sentences_per_sec", "launches"))
+    r = v.get("roofline")
+    if isinstance(r, dict) and "frac" in r:
+        out["frac"], out["bound"] = r["frac"], r.get("bound")
+        if r.get("kernel"):
+            out["kernel"] = r["kernel"]
+    rd = v.get("roofline_dominant_kernel")
+    if isinstance(rd, dict) and "frac" in rd:
+        out["mfma_frac"] = rd["frac"]
+    return out
+
+
+def headline(line, details_path=None):
+    """The compact form of the full record `line`: every contract key verbatim, scalar-only `roofline` / `cpu_baseline` / `parity`
+    blocks, one-line summaries of the secondary legs and of the ranks.  Always strict JSON (no NaN / Infinity) below
+    HEADLINE_MAX_BYTES; whatever does not fit lives in the details file."""
+    h = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                  "vs_baseline", "dtype", "data")}
+    cfg = line.get("config") or {}
+    h["config"] = _pick(cfg, ("workload", "utterances_per_gpu", "symbols", "frames", "parallelism", "rtf", "x_realtime_per_gpu", "hipgraph",
+                              "weight_broadcast_ms"))
+    if isinstance(h["config"].get("workload"), str):
+        h["config"]["workload"] = h["config"]["workload"][:260]
+    if isinstance(cfg.get("pcie_inclusive"), dict):
+        h["config"]["pcie_inclusive"] = _pick(cfg["pcie_inclusive"], ("value", "ms_per_step"))
+    r = line.get("roofline")
+    if isinstance(r, dict):
+        h["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac")) if "error" not in r else dict(error=str(r["error"])[:120])
+        if "error" not in r:
+            h["roofline"]["traffic"] = r.get("traffic")
+            h["roofline"].update(_pick(r, ("alg_bytes_per_launch", "flops_per_launch", "avg_launch_us", "launches_per_step",
+                                           "issued_flops_per_alg_flop", "fp32_equivalent_tflops", "generator_ms_per_step")))
+    else:
+        h["roofline"] = None
+    c = line.get("cpu_baseline")
+    if isinstance(c, dict):
+        h["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "ms_per_step"))
+        h["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:170]
+        if isinstance(c.get("reference_container"), dict):
+            h["cpu_baseline"]["reference_container"] = _pick(c["reference_container"], ("ms", "audio_s_per_s", "threads", "port_ms_same_box",
+                                                                                         "reference_over_port"))
+        if isinstance(c.get("reference_estimate_this_box"), dict):
+            h["cpu_baseline"]["reference_estimate_this_box"] = c["reference_estimate_this_box"].get("value")
+    else:
+        h["cpu_baseline"] = None
+    if isinstance(line.get("parity"), dict):
+        h["parity"] = _pick(line["parity"], ("w_ceil_match", "wave_rms", "wave_max_abs", "signal_rms", "mel_l1", "attn_equal", "error"))
+        for k, v in list(h["parity"].items()):
+            if isinstance(v, float):
+                h["parity"][k] = float(f"{v:.4g}")
+            elif isinstance(v, str):
+                h["parity"][k] = v[:120]
+    u = line.get("upsampling_roofline")
+    if isinstance(u, dict) and "error" not in u:
+        h["upsampling_roofline"] = _pick(u, ("bound", "achieved", "peak", "unit", "frac", "ms_per_step"))
+        h["upsampling_roofline"]["traffic"] = u.get("traffic")
+    sec = line.get("secondary")
+    if isinstance(sec, dict):
+        h["secondary"] = {k: _leg(v) for k, v in sec.items()}
+        ctl = sec.get("config2_fp32_mfma")
+        if isinstance(ctl, dict) and ctl.get("value"):
+            # the same step with the round-2 kernel on the SAME box: box-to-box spread cancels in the ratio
+            h["control_ratio_vs_fp32_mfma"] = round(line["value"] / ctl["value"], 4)
+    if line.get("per_rank") is not None:
+        h["ranks_seen"], h["launcher"] = line.get("ranks_seen"), line.get("launcher")
+        h["per_rank"] = [None if r is None else dict(_pick(r, ("rank", "ms_per_step", "audio_s_per_step", "utterances", "symbols_total")),
+                                                      roofline=_pick(r.get("roofline") or {}, ("frac", "avg_launch_us")))
+                         for r in line["per_rank"]]
+        h["weight_broadcast_ms"] = line.get("weight_broadcast_ms")
+        h["collectives_in_timed_region"] = "none"
+    if details_path:
+        h["details"] = details_path
+    txt = json.dumps(h, allow_nan=False, separators=(",", ":"))
+    # belt and braces: shed optional blocks rather than ever print a line the driver cannot take
+    for drop in ("upsampling_roofline", "secondary", "per_rank", "parity"):
+        if len(txt) < HEADLINE_MAX_BYTES:
+            break
+        if drop in h:
+            h[drop] = "see details"
+            txt = json.dumps(h, allow_nan=False, separators=(",", ":"))
+    assert len(txt) < HEADLINE_MAX_BYTES, len(txt)
+    return txt
+
+
+def _finite(o):
+    """Strict JSON has no NaN / Infinity: map them to null wherever they occur."""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def emit(line, details_out=None):
+    """Full record -> details file; compact headline -> the ONE line on stdout, the last thing this process prints there."""
+    line = _finite(line)
+    path = details_out or os.path.join("gpurun_out", "bench_details.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(line, f, allow_nan=False)
+    except OSError as e:
+        log(f"details file not written: {e}")
+        path = None
+    txt = headline(line, path)
+    sys.stdout.write(txt + "\n")
+    sys.stdout.flush()
+    return txt
+
 
 class Seam:
     """Everything in the N-rank driver that touches a GPU, so that a CPU test can drive the SAME launcher / reduction code with
@@ -736,6 +864,10 @@ def rank_main(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or with no launcher at all")
+    if args.library:
+        from bert_vits2_amd import lib as _bv2lib
+        _bv2lib.load(path=os.path.abspath(args.library))
+        log(f"A/B: library {args.library}")
     seam = Seam()
     if args.seam:
         import importlib
@@ -888,7 +1020,7 @@ def rank_main(args):
             line["secondary"] = secondary
         if res.get("full"):
             line["kernel_families_untimed_pass"] = res["full"]
-        print(json.dumps(line), flush=True)
+        emit(line, args.details_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

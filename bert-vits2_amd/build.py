@@ -14,7 +14,7 @@ import shutil
 import subprocess
 import sys
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.realpath(__file__))     # bert_vits2_amd is a symlink to bert-vits2_amd: one directory, one stamp
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libbv2.so")

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
         for (int r = 0; r < 16; ++r) {
           const int dr = (r & 3) + 8 * (r >> 2);
           float v = acc[mi][ni][r] + bsum(r);
-          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          if (act == ACT_RELU) v = v < 0.f ? 0.f : v;     // a select: NaN stays NaN (torch.relu), v_max would return 0
           else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
           if (mask_pre) v *= om;
           if (res_mode == RES_ADD) v += rv[r];
@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
       for (int w = 0; w < NWV; w += 4)
         vv += (red[w][rl][tid & 31] + red[w + 1][rl][tid & 31]) + (red[w + 2][rl][tid & 31] + red[w + 3][rl][tid & 31]);
       vv += bsv[i] + b2v[i];
-      if (act == ACT_RELU) vv = fmaxf(vv, 0.f);             // host guarantees act == NONE when ksplit > 1
+      if (act == ACT_RELU) vv = vv < 0.f ? 0.f : vv;             // host guarantees act == NONE when ksplit > 1
       else if (act == ACT_GELU) vv = 0.5f * vv * (1.0f + erff(vv * 0.70710678118654752440f));
       if (mask_pre) vv *= om;
       if (z == 0) {

@@ -358,7 +358,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     const float* const omaskp = P.out_mask ? P.out_mask + (int64_t)b * P.out_mask_bstride : dummy;
     const unsigned m_b1 = P.bias ? 0xffffffffu : 0u, m_b2 = P.bias2 ? 0xffffffffu : 0u, m_res = has_res ? 0xffffffffu : 0u;
     const unsigned m_om = P.out_mask ? 0xffffffffu : 0u;
-    const float relu_floor = P.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const bool relu = P.act == ACT_RELU;          // ACT_GATE / ACT_GELU never get here (conv_x6_supported admits NONE and RELU only)
     const bool rsub = P.res_mode == RES_RSUB, mpre = P.mask_pre != 0, mpost = P.mask_post != 0;
     float bs[MI][16], bs2[MI][16], rv[MI][NI][16], omr[NI];
     unsigned off0[MI][NI];
@@ -403,7 +403,8 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
           const int dr = (r & 3) + 8 * (r >> 2);
           const float bsum = __uint_as_float(__float_as_uint(bs[mi][r]) & m_b1) + __uint_as_float(__float_as_uint(bs2[mi][r]) & m_b2);
           const float rr = __uint_as_float(__float_as_uint(rv[mi][ni][r]) & m_res);
-          float v = fmaxf(acc[mi][ni][r] + bsum, relu_floor) * fpre;
+          const float pre = acc[mi][ni][r] + bsum;
+          float v = ((relu && pre < 0.f) ? 0.f : pre) * fpre;        // a select, not v_max: a NaN accumulator stays NaN (as in conv_mfma.hip / torch.relu)
           v = rsub ? rr - v : v + rr;
           v *= fpost;
           if (colok[ni] && row0 + dr < cout) outb[off0[mi][ni] + (unsigned)dr * o_rs] = v;

@@ -135,10 +135,14 @@ def lib_path() -> str:
     return _build.LIB
 
 
-def load(build_if_missing: bool = True) -> C.CDLL:
-    """Load libbv2.so (building it with hipcc first if the sources changed).  Raises if impossible."""
+def load(build_if_missing: bool = True, path: Optional[str] = None) -> C.CDLL:
+    """Load libbv2.so (building it with hipcc first if the sources changed).  Raises if impossible.  ``path``: measurement tooling
+    only (tools/ab_build.py through ``bench.py --library``) — the FIRST load of the process binds that file (same C ABI) instead of
+    the stamped in-tree build; no environment variable changes what the product loads."""
     global _lib
     if _lib is not None:
+        if path is not None and os.path.abspath(path) != os.path.abspath(getattr(_lib, "_name", "")):
+            raise RuntimeError("libbv2 is already loaded from " + getattr(_lib, "_name", "?"))
         return _lib
     # PyTorch bundles its own libamdhip64.so (soname libamdhip64.so.7).  It must be in the process BEFORE libbv2.so is
     # dlopen'ed so that libbv2's NEEDED libamdhip64.so.7 binds to the SAME HIP runtime that owns torch's device
@@ -163,14 +167,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if not os.path.exists(_build.LIB):
         raise RuntimeError(f"{_build.LIB} is missing: the HIP extension must be built (python -m bert_vits2_amd.build); "
                            "there is no CPU fallback")
-    path = _build.LIB
-    alt = os.environ.get("BV2_AB_LIBRARY")
-    if alt:
-        # same-box A/B of two BUILDS (tools/ab_build.py): a reference libbv2 built from an older commit, same ABI.  Measurement
-        # tooling only — the product loads the stamped in-tree library.
-        path = alt if os.path.isabs(alt) else os.path.join(os.path.dirname(_build.LIB), alt)
-        if not os.path.exists(path):
-            raise RuntimeError(f"BV2_AB_LIBRARY={alt}: no such library")
+    if path is None:
+        path = _build.LIB
+    elif not os.path.exists(path):
+        raise RuntimeError(f"{path}: no such library")
     lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)         # AttributeError if the .so does not export a declared symbol

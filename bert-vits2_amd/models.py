@@ -403,14 +403,18 @@ class SynthesizerTrn(nn.Module):
         okeys = ("o", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")
 
         def mk_out():
-            # ONE allocation carved into the seven outputs: this runs between the reference's host sync and the first launch of
+            # ONE allocation carved into the six secondary outputs (+ one for the waveform): this runs between the reference's host sync and the first launch of
             # phase B, i.e. with the GPU idle — seven caching-allocator calls there cost ~25 us of a 4.5 ms step at batch 1
             shapes = dict(o=(B, 1, S), attn=(B, 1, Ty, T) if want_attn else None, y_mask=(B, 1, Ty), z=(B, Ci, Ty), z_p=(B, Ci, Ty),
                           m_p=(B, Ci, Ty), logs_p=(B, Ci, Ty))
-            sizes = {k: (0 if sh is None else (math.prod(sh) + 63) // 64 * 64) for k, sh in shapes.items()}     # 256-byte aligned views
+            # The waveform gets its OWN allocation: a caller that keeps only `o` (the serving case) must not pin attn and the four
+            # [B,Ci,Ty] latents with it.
+            sizes = {k: (0 if sh is None or k == "o" else (math.prod(sh) + 63) // 64 * 64) for k, sh in shapes.items()}   # 256-byte aligned views
             flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=dev)
-            out, off = {}, 0
+            out, off = {"o": torch.empty(shapes["o"], dtype=torch.float32, device=dev)}, 0
             for k, sh in shapes.items():
+                if k == "o":
+                    continue
                 out[k] = None if sh is None else flat[off:off + math.prod(sh)].view(*sh)
                 off += sizes[k]
             return out

@@ -116,8 +116,10 @@ def replicas(model, n: int) -> list:
     for m, _ in reps[1:]:                                # replicas follow the weights, precision switches and options of the model they serve
         if m._blob is not model._blob:
             m.attach_blob(model._blob)
-        m.set_generator_dtype(model.generator_dtype)
-        if model.hp.use_transformer_flow:
+        # the setters drop captured graphs: only call them on a real change (both flow variants have an fp16 form)
+        if m.generator_dtype != model.generator_dtype:
+            m.set_generator_dtype(model.generator_dtype)
+        if m.flow_dtype != model.flow_dtype:
             m.set_flow_dtype(model.flow_dtype)
         for key, val in getattr(model, "_options", {}).items():
             if getattr(m, "_options", {}).get(key) != val:

@@ -248,7 +248,7 @@ void bv2_graph_destroy(bv2_graph* graph);
 /* ---- debugging / measurement ------------------------------------------------------------------------------ */
 /* Kernel-selection switches, for tests that hold the fused kernels to the layer-wise ones (default 1 = fused):
  *   "fused_resblock"  the narrow Generator stages as whole-ResBlock / fused-pair kernels (0: one conv per launch)
- *   "conv_x6"         the ResBlock convs of the wide fp32 Generator stages (C >= 64) on the bf16 matrix core: operands split exactly
+ *   "conv_x6"         the ResBlock convs of the fp32 Generator stages with C >= 32 on the bf16 matrix core: operands split exactly
  *                     into three bf16 planes, six cross products accumulated in fp32 — fp32 accuracy (dropped terms < 2^-23 of a
  *                     product) at 6/16 of the fp32-MFMA time (kernels/conv_x6.hip).  0: v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
  *   "conv_x6_c32"     also the C = 32 stage layer-wise on conv_x6.hip (two launches per ResBlock pair, 44.6 us each at batch 1) instead

@@ -58,3 +58,71 @@ def test_pmc_family_names_match_the_names_the_launcher_reports():
         a = [v.strip() for v in targs.strip("<>").split(",")]
         inst = f"launch_x6_variant<{', '.join(a[:6])}" + (f", {a[6]}>" if a[6] != "0" else ">")
         assert inst in src, inst
+
+
+def _strict(txt):
+    def fail(name):
+        raise AssertionError(f"non-strict JSON constant {name}")
+    return json.loads(txt, parse_constant=fail)
+
+
+def _full_record(n_gpus):
+    """The full record of the last committed run, with a per-rank table of n_gpus entries grafted on for N > 1 — the shape
+    rank_main() hands to emit()."""
+    _, d = _latest_full()
+    d = dict(d, n_gpus=n_gpus)
+    if n_gpus > 1:
+        d["per_rank"] = [dict(rank=r, local_rank=r, device="AMD Instinct MI355X", ms_per_step=18.1234 + r, audio_s_per_step=126.2345,
+                              utterances=32, symbols_total=3584 + r, weight_broadcast_ms=123.456,
+                              roofline=dict(bound="mfma", kernel="conv_cl_bf16<4x1>", achieved=832.123, peak=2500.0, unit="TFLOP/s",
+                                            frac=0.3328, avg_launch_us=575.12)) for r in range(n_gpus)]
+        d["ranks_seen"], d["launcher"], d["weight_broadcast_ms"] = n_gpus, "torch.distributed.run", 123.456
+    return d
+
+
+def _latest_full():
+    """Newest committed record that still has the full (pre-headline) shape: launch tables and per-leg roofline blocks."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_details.json")) or
+                   [os.path.join(ROOT, "profiles", "r03_k_bench.json")])
+    return files[-1], json.load(open(files[-1]))
+
+
+def test_headline_is_compact_strict_json_for_1_and_8_gpus(tmp_path, capsys):
+    """Round 3's stdout line was 36 KB and the driver's record came back `parsed: null`.  The line bench.py prints now goes through
+    headline(): < 4 KB, strict JSON, contract keys + scalar roofline / cpu_baseline / parity, per-rank table at N = 8 — and it is
+    the LAST line on stdout."""
+    import bench
+    for n in (1, 8):
+        rec = _full_record(n)
+        rec["parity"] = dict(rec.get("parity") or {}, wave_max_abs=float("nan"))          # a NaN must not leak into the line
+        print("some earlier chatter on stdout")
+        txt = bench.emit(rec, str(tmp_path / f"d{n}.json"))
+        out = capsys.readouterr().out
+        last = out.rstrip("\n").splitlines()[-1]
+        assert last == txt and len(last) < 4096, len(last)
+        h = _strict(last)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in h, k
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in h["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in h["cpu_baseline"], k
+        assert not any(isinstance(v, (list, dict)) for v in h["roofline"].values())          # scalars only: no launch / family tables
+        assert "model" not in h["config"] and "workload" in h["config"]
+        assert h["parity"].get("wave_max_abs") is None and "NaN" not in last
+        if n == 8:
+            assert len(h["per_rank"]) == 8 and h["ranks_seen"] == 8 and all(r["roofline"]["frac"] > 0 for r in h["per_rank"])
+        else:
+            assert h["secondary"]["config3"]["value"] > 0 and "frac" in h["secondary"]["config3"]
+            assert abs(h["control_ratio_vs_fp32_mfma"] - rec["value"] / rec["secondary"]["config2_fp32_mfma"]["value"]) < 1e-3
+        full = _strict(open(tmp_path / f"d{n}.json").read())                                 # nothing is lost: the full record is on disk
+        assert full["roofline"].get("families") == rec["roofline"].get("families")
+
+
+def test_headline_sheds_blocks_rather_than_overflow():
+    import bench
+    rec = _full_record(1)
+    rec["secondary"] = {f"leg{i}": dict(value=1.0, ms_per_step=2.0, roofline=dict(frac=0.5, bound="mfma", kernel="k" * 40)) for i in range(80)}
+    txt = bench.headline(rec)
+    assert len(txt) < 4096 and _strict(txt)["secondary"] == "see details" and _strict(txt)["roofline"]["frac"] > 0

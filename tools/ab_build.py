@@ -5,7 +5,7 @@
   on the GPU box:  python tools/ab_build.py [--args "<bench args>"] [--rounds N]
                    runs bench.py alternately with the in-tree library and the reference one and prints both series.
 
-The reference library must have the same C ABI and pack layout as the current host code (it is loaded through BV2_AB_LIBRARY)."""
+The reference library must have the same C ABI and pack layout as the current host code (it is loaded through `bench.py --library`)."""
 import json
 import os
 import shutil
@@ -41,15 +41,15 @@ def make(rev):
 
 
 def run(extra, ref):
-    env = dict(os.environ)
-    if ref:
-        env["BV2_AB_LIBRARY"] = REF
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-secondary", "--no-cpu-baseline"] + extra, env=env,
+    det = os.path.join(ROOT, "gpurun_out", f"ab_build_details_{os.getpid()}.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-secondary", "--no-cpu-baseline", "--details-out", det] +
+                       (["--library", REF] if ref else []) + extra,
                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if not line:
+    if not line or not os.path.exists(det):
         return None
-    d = json.loads(line[-1])
+    d = json.load(open(det))            # the full record (stdout carries the compact headline only)
+    os.remove(det)
     fam = {f["name"]: f["ms_per_step"] for f in (d.get("roofline") or {}).get("families", [])}
     return d["ms_per_step"], d["value"], fam
 
