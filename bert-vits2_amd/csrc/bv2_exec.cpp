@@ -985,7 +985,43 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
         if (r) c.fail("dec.resblock.whole", r);
       }
     }
-    for (int d = 0; d < m.n_rbd && !whole; ++d) {
+    // wide stages: one (dilated conv, conv) pair per launch, the intermediate in LDS (respair_cl_bf16.hip).  A tile's halo rows are
+    // another tile's outputs, so a pair never runs in place: branch j ping-pongs between S[1 + j] and S[1 + nb + j] and ends in S[1 + j]
+    bool pairs = !whole && nb <= 3 && !c.h->no_fused_respair;
+    for (int j = 0; j < nb && pairs; ++j)
+      for (int d = 0; d < m.n_rbd && pairs; ++d)
+        pairs = respair_cl_bf16_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]) &&
+                m.rb[i][j][d][0].k == m.rb[i][j][d][1].k;
+    for (int d = 0; d < m.n_rbd && pairs; ++d) {
+      RpClLaunch F;
+      std::memset(&F, 0, sizeof(F));
+      F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.slope = 0.1f; F.lens = lens; F.len_mul = up * U.u;
+      F.mix = c.h->respair_problem_major ? 0 : 1;
+      F.form = c.h->respair_form;
+      const bool to_cur = ((m.n_rbd - 1 - d) & 1) == 0;
+      for (int jj = 0; jj < nb; ++jj) {
+        const int j = nb - 1 - jj;                                // widest kernel first
+        uint16_t* cur = U16(S[1 + j]);
+        uint16_t* tmp = U16(S[1 + nb + j]);
+        RpClProb& p = F.p[jj];
+        p.x = d == 0 ? x : (to_cur ? tmp : cur);
+        p.out = to_cur ? cur : tmp;
+        p.w1 = Wb(m.rb[i][j][d][0]); p.w2 = Wb(m.rb[i][j][d][1]);
+        p.b1 = c.W(m.rb[i][j][d][0].b_off); p.b2 = c.W(m.rb[i][j][d][1].b_off);
+        p.k = m.rb[i][j][d][0].k; p.dil = cf.resblock_dilation_sizes[j][d];
+      }
+      if (!c.rc) {
+        const char* vn = "respair_cl_bf16";
+        const int pi = c.prof_begin("dec.resblock.pair");
+        if (pi >= 0 && c.h->prof_mode >= 3)
+          c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
+                        std::to_string(Lo) + " B" + std::to_string(B);
+        const int r = launch_respair_cl_bf16(c.s, F, &vn);
+        c.prof_end(pi, vn, respair_cl_bf16_flops(F), respair_cl_bf16_bytes(F));
+        if (r) c.fail("dec.resblock.pair", r);
+      }
+    }
+    for (int d = 0; d < m.n_rbd && !whole && !pairs; ++d) {
       ClLaunch c1, c2;
       c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
       c1.lens = c2.lens = lens; c1.len_mul = c2.len_mul = up * U.u;

@@ -204,6 +204,19 @@ int launch_resblock_cl_bf16(hipStream_t stream, const RbClLaunch& L);
 double resblock_cl_bf16_flops(const RbClLaunch& L);
 double resblock_cl_bf16_bytes(const RbClLaunch& L);
 
+// one (dilated conv, conv) pair of ResBlock1 with its residual at C = 64 / 128 / 256 in one launch, bf16 channels-last, the
+// intermediate in LDS (kernels/respair_cl_bf16.hip).  x / out: [B][L][C], out != x; w1 / w2: the convs' ordinary fragment streams
+// (cl_w_index), b1 / b2 fp32 [C]; conv1 has dilation dil, conv2 dilation 1, both k taps.
+struct RpClProb { const uint16_t* x; uint16_t* out; const uint16_t* w1; const uint16_t* w2; const float* b1; const float* b2; int k, dil; };
+struct RpClLaunch { RpClProb p[3]; int nprob, B, C, L; float slope; const int64_t* lens = nullptr; int len_mul = 1;
+                    int form = 1;    // 1: 64-channel x 128-row wave tiles on the swizzled tile, 0: 32-channel waves on the padded tile
+                    int mix = 1;     // 1: the problems interleaved in dispatch order (every CU holds tiles of all branches), 0: problem-major
+                    unsigned long long* dbg = nullptr; };
+bool respair_cl_bf16_supported(int C, int k, int dil);
+int launch_respair_cl_bf16(hipStream_t stream, const RpClLaunch& L, const char** variant_name);
+double respair_cl_bf16_flops(const RpClLaunch& L);
+double respair_cl_bf16_bytes(const RpClLaunch& L);
+
 // z[b][c][t] * mask[b][t] (fp32, channel stride z_rstride) -> bf16 channels-last out[b][t][c], t < L
 int launch_cast_cl(hipStream_t stream, const float* z, int z_rstride, int64_t z_bstride, const float* mask, int mask_bstride,
                    uint16_t* out, int B, int C, int L);

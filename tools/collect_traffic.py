@@ -31,6 +31,9 @@ def family(kname):
                      "<1, 4, 1, 4,": "conv_cl_bf16<1x4>", "<1, 8, 2, 2,": "conv_cl_bf16<1x8,2x2>"}.items():
             if "conv_cl_bf16_kernel" + k in kname:
                 return v
+    if "respair_cl_bf16_kernel<" in kname:      # <WN, WM, NI, G>: C = 16 G -> the name launch_respair_cl_bf16 reports
+        a = [int(v) for v in kname.split("respair_cl_bf16_kernel<")[1].split(">")[0].split(",")]
+        return f"respair_cl_bf16<{16 * a[3]}>"
     if "resblock_cl_bf16_kernel" in kname:
         return "resblock_cl_bf16<C32>" if "<32," in kname else "resblock_cl_bf16<C16>"
     if "conv_f16_kernel" in kname:

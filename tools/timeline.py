@@ -67,6 +67,14 @@ def main():
         if not len(v):
             continue
         span = v[:, 3].max() - v[:, 0].min()
+        if tile <= -90000:
+            # respair_cl_bf16.hip (tile id -(90000 + C)): slot 6 = taps | (ticks of conv1's GEMM) << 16; "loop" = conv1 + h epilogue + conv2
+            for kk in np.unique(v[:, 6] & 0xffff):
+                w = v[(v[:, 6] & 0xffff) == kk]
+                c1 = w[:, 6] >> 16
+                print(f"     respair C={-tile - 90000} k={kk:2d}: {len(w):6d} wgs  stage {np.mean(w[:, 1] - w[:, 0]):7.0f}  conv1 {np.mean(c1):7.0f}  "
+                      f"h-epilogue + conv2 {np.mean(w[:, 2] - w[:, 1] - c1):7.0f}  epilogue {np.mean(w[:, 3] - w[:, 2]):7.0f}  "
+                      f"life {np.mean(w[:, 3] - w[:, 0]):8.0f} ticks (MFMA-only time of the two GEMMs: {2 * kk * (-tile - 90000) // 16 * 4 * 32} cycles)")
         print(f"#{i:3d} tile {tile:6d} k={ks & 255},{(ks >> 8) & 255},{(ks >> 16) & 255} cin {cin:4d} L {Lc:6d} wgs {len(v):5d}/{len(s):5d} span {span:8d} ticks "
               f"prologue {np.mean(v[:, 1] - v[:, 0]):8.0f} loop {np.mean(v[:, 2] - v[:, 1]):9.0f} epilogue {np.mean(v[:, 3] - v[:, 2]):8.0f}")
 
