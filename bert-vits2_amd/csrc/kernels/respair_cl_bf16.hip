@@ -355,7 +355,7 @@ __device__ __forceinline__ void rp2_run(f32x16 (&acc)[2][4], bf16x8 (&ar)[RP2_RS
 }  // namespace
 
 template <int WN, int WM, int G>
-__global__ void __launch_bounds__(64 * WN * WM, WN * WM == 4 ? 2 : 1)
+__global__ void __launch_bounds__(64 * WN * WM, WN * WM <= 4 ? 2 : 1)
 respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   constexpr int NT = 64 * WN * WM;
   constexpr int C = 16 * G;
@@ -399,7 +399,7 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   bf16x8 ar[RP2_RS][2];
   const uint16_t* wq[RP2_RS][2];
   rp2_prime<NP>(ar, wq, P.w1 + (2 * wn) * mstream, P.w1 + (2 * wn + 1) * mstream, wlane, k);
-  rp2_stage<C, NT, 10>(xsb, xg, L.slope, t0 - p2 - p1, HT + (k - 1) * dil, Lin, tid);
+  rp2_stage<C, NT, 20>(xsb, xg, L.slope, t0 - p2 - p1, HT + (k - 1) * dil, Lin, tid);
   __syncthreads();
   if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
@@ -621,7 +621,7 @@ int launch_respair_cl_bf16(hipStream_t stream, const RpClLaunch& L, const char**
     const RpClProb& p = L.p[i];
     if (!respair_cl_bf16_supported(L.C, p.k, p.dil) || !p.x || !p.out || p.x == p.out || !p.w1 || !p.w2 || !p.b1 || !p.b2) return -1;
   }
-  if (L.form == 1) {
+  if (L.form >= 1) {
     switch (L.C) {
       case 64:
         if (variant_name) *variant_name = "respair_cl_bf16<64,64x128>";

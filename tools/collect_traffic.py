@@ -34,6 +34,9 @@ def family(kname):
     if "respair_cl_bf16_kernel<" in kname:      # <WN, WM, NI, G>: C = 16 G -> the name launch_respair_cl_bf16 reports
         a = [int(v) for v in kname.split("respair_cl_bf16_kernel<")[1].split(">")[0].split(",")]
         return f"respair_cl_bf16<{16 * a[3]}>"
+    if "respair2_cl_bf16_kernel<" in kname:     # <WN, WM, G>: the 64 x 128 wave-tile form
+        a = [int(v) for v in kname.split("respair2_cl_bf16_kernel<")[1].split(">")[0].split(",")]
+        return f"respair_cl_bf16<{16 * a[2]},64x128>"
     if "resblock_cl_bf16_kernel" in kname:
         return "resblock_cl_bf16<C32>" if "<32," in kname else "resblock_cl_bf16<C16>"
     if "conv_f16_kernel" in kname:
