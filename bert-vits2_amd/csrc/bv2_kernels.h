@@ -97,13 +97,17 @@ inline int64_t x6_w_index(int j, int ci, int co, int cin, int k, int plane) {
   return ((((int64_t)(co >> 5) * U + u) * 3 + plane) * 64 + lane) * 8 + (ci % 8);
 }
 inline int64_t x6_w_elems(int cin, int cout_pad, int k) { return (int64_t)(cout_pad / 32) * (cin / 16) * k * 3 * 512; }
-// v = h[0] + h[1] + h[2] exactly (round-to-nearest-even at every step), as bf16 bit patterns
+// v = h[0] + h[1] + h[2] exactly (round-to-nearest-even at every step), as bf16 bit patterns.  The FIRST plane saturates: a finite
+// |v| above the largest bf16 (0x7f7f = 3.3895e38; RNE would round the top 0.2 % of the fp32 range to +-inf and the remainder v - inf
+// to NaN) takes +-0x7f7f and the remainder v - h[0] < 2^120 is still exact in the two planes that follow — so every FINITE fp32
+// splits into three finite planes.  +-inf splits into (+-0x7f7f, +-inf, NaN), NaN into NaN: non-finite stays non-finite.
 inline void x6_split(float v, uint16_t h[3]) {
   for (int p = 0; p < 3; ++p) {
     uint32_t u;
     __builtin_memcpy(&u, &v, 4);
     uint16_t b;
     if ((u & 0x7fffffffu) > 0x7f800000u) b = (uint16_t)((u >> 16) | 0x40u);
+    else if (p == 0 && (u & 0x7fffffffu) > 0x7f7f0000u) b = (uint16_t)((u >> 16) & 0x8000u) | 0x7f7fu;
     else { u += 0x7fffu + ((u >> 16) & 1u); b = (uint16_t)(u >> 16); }
     h[p] = b;
     const uint32_t w = (uint32_t)b << 16;

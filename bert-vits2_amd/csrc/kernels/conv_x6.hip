@@ -7,7 +7,12 @@
 // step), every bf16 x bf16 product is exact in fp32, and of the nine cross terms of w*x the six largest
 //      w1x1 + (w1x2 + w2x1) + (w1x3 + w2x2 + w3x1)
 // leave out |w2x3 + w3x2 + w3x3| < 2^-23 |wx| — less than the rounding of ONE fp32 multiply-add — so the conv is computed to fp32
-// accuracy with 6 bf16 MFMAs (6/16 of the fp32 MFMA time) per 16 channels instead of 8 fp32 MFMAs.  tests/test_x6_gpu.py compares
+// accuracy with 6 bf16 MFMAs (6/16 of the fp32 MFMA time) per 16 channels instead of 8 fp32 MFMAs.
+// Envelope (tests/test_x6_gpu.py::test_conv1d_x6_envelope): every FINITE fp32 operand splits exactly — plane 1 saturates at the
+// largest bf16 instead of rounding the top 0.2 % of the range to inf — so finite inputs give the fp32 kernel's result up to FLT_MAX;
+// +-0 and fp32 denormals behave as in fp32 except that bits below 2^-133 (the bf16 denormal step) of a tiny operand are dropped: an
+// ABSOLUTE error <= 2^-134 |other operand| per term; a NaN operand gives NaN; an infinite operand gives a non-finite result that may
+// be NaN where fp32 arithmetic gives +-inf (its remainder planes are inf - finite and inf - inf).  tests/test_x6_gpu.py compares
 // it against the fp32-MFMA kernel and the oracle; the end-to-end parity numbers (bench.py `parity`) are the same to the last digit
 // shown.  (The same technique as the BF16x9 / x6 fp32-emulation modes of vendor BLAS libraries; no reference counterpart — the
 // reference runs these convs through MIOpen / cuDNN fp32.)
@@ -51,6 +56,7 @@ __device__ __forceinline__ unsigned x6_pack(float a, float b) {     // round-to-
 __device__ __forceinline__ float x6_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float x6_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+constexpr float X6_BF16_MAX = 3.38953139e38f;   // 0x7f7f0000
 constexpr int X6_UNIT = 3 * 512;          // elements of one (group, tap) unit of one m-tile: 3 planes x 64 lanes x 8
 
 }  // namespace
@@ -210,7 +216,9 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
           a = (lrelu && a < 0.f) ? an : a;
           bq = (lrelu && bq < 0.f) ? bn : bq;
           a *= sc; bq *= sc;
-          const unsigned u1 = x6_pack(a, bq);
+          // plane 1 saturates at the largest bf16 (x6_split, bv2_kernels.h): a finite value never rounds to +-inf, its remainder
+          // a - h1 (< 2^120) is exact in planes 2 and 3; inf / NaN leave the clamp finite but their remainders are inf / NaN
+          const unsigned u1 = x6_pack(__builtin_amdgcn_fmed3f(a, -X6_BF16_MAX, X6_BF16_MAX), __builtin_amdgcn_fmed3f(bq, -X6_BF16_MAX, X6_BF16_MAX));
           a -= x6_lo(u1); bq -= x6_hi(u1);
           const unsigned u2 = x6_pack(a, bq);
           a -= x6_lo(u2); bq -= x6_hi(u2);

@@ -304,3 +304,18 @@ def test_x6_split_is_exact_and_round_to_nearest():
         for i in range(3):
             assert h[i] == rne(rest), (v, i)
             rest = np.float32(rest - planes[i])
+    # the top of the range: plane 1 saturates at the largest bf16 (RNE would give inf and a NaN remainder); still exact, all finite
+    fmax = np.finfo(np.float32).max
+    with np.errstate(over="ignore", invalid="ignore"):
+        for v in (fmax, -fmax, np.float32(3.3962e38), np.float32(-3.3962e38), np.float32(3.3961e38), np.nextafter(np.float32(bf(0x7f7f)), np.float32(np.inf))):
+            lib.bv2_test_x6_split(float(v), h)
+            assert (h[0] & 0x7fff) == 0x7f7f and (h[0] >> 15) == int(v < 0), (v, hex(h[0]))
+            planes = [bf(h[i]) for i in range(3)]
+            assert all(np.isfinite(p) for p in planes)
+            assert float(np.float64(planes[0]) + np.float64(planes[1]) + np.float64(planes[2])) == float(v), (v, planes)
+        lib.bv2_test_x6_split(float(bf(0x7f7f)), h)                       # the largest bf16 itself: unchanged
+        assert (h[0], h[1], h[2]) == (0x7f7f, 0, 0)
+        lib.bv2_test_x6_split(float("inf"), h)                           # non-finite stays non-finite
+        assert h[0] == 0x7f7f and not np.isfinite(bf(h[1]))
+        lib.bv2_test_x6_split(float("nan"), h)
+        assert np.isnan(bf(h[0]))

@@ -76,6 +76,67 @@ def test_conv1d_x6_fused_epilogues(tile):
         assert rel_err(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("tile", [8, 9, 10, 11])
+def test_conv1d_x6_envelope(tile):
+    """Off the comfortable range (VERDICT r3 #8 / ADVICE r3): the contract of conv_x6.hip's header, element by element against the
+    fp32-MFMA kernel on the same inputs.
+      * finite operands up to FLT_MAX: plane 1 of the split saturates at the largest bf16 instead of rounding to inf, so wherever
+        the fp32 kernel's result is finite the x6 result is finite and equal to fp32 accuracy;
+      * NaN in, NaN out (also under the fused ReLU: a select, not v_max);  +-inf in: non-finite out at exactly the same positions
+        (inf may surface as NaN: the remainder planes of inf are inf - finite and inf - inf);
+      * +-0 and fp32 denormals: as fp32 up to an absolute 2^-133 |w| per term (bits below the bf16 denormal step)."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(100 + tile)
+    B, cin, cout, k, dil, L = 1, 64, 128, 5, 2, 200
+    ref_tile = 3
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias = torch.randn(cout, generator=g)
+    FMAX = torch.finfo(torch.float32).max
+
+    # ---- finite, huge: values on both sides of the bf16 rounding boundary (3.3961e38) with weights small enough that sums stay finite
+    x = torch.randn(B, cin, L, generator=g)
+    big = [FMAX, -FMAX, 3.3962e38, -3.3962e38, 3.3960e38, 3.39e38, -3.3896e38, 3.0e38]
+    for i, v in enumerate(big):
+        x[0, (7 * i) % cin, 10 + 13 * i] = v
+    ws = w * 1e-3
+    y6 = _run(lib, x.cuda(), ws, bias, tile, k, dil)
+    y32 = _run(lib, x.cuda(), ws, bias, ref_tile, k, dil)
+    assert torch.isfinite(y32).all() and torch.isfinite(y6).all()
+    ref = F.conv1d(x.double(), ws.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil)
+    scale = ref.abs().amax(dim=2, keepdim=True)
+    r6 = ((y6.double().cpu() - ref).abs() / scale).max().item()
+    r32 = ((y32.double().cpu() - ref).abs() / scale).max().item()
+    assert r6 <= 2.0 * r32 + 3e-7, (r6, r32)
+
+    # ---- NaN / inf operands: the same positions go non-finite; NaN stays NaN (ACT_NONE and ReLU)
+    for special, relu in ((float("nan"), 0), (float("nan"), 1), (float("inf"), 0), (float("-inf"), 0)):
+        x = torch.randn(B, cin, L, generator=g)
+        x[0, 5, 50] = special
+        x[0, 40, 150] = special
+        y6 = _run(lib, x.cuda(), w, bias, tile, k, dil, relu=relu).cpu()
+        y32 = _run(lib, x.cuda(), w, bias, ref_tile, k, dil, relu=relu).cpu()
+        bad6, bad32 = ~torch.isfinite(y6), ~torch.isfinite(y32)
+        assert bad32.any() and torch.equal(bad6, bad32), (special, relu, bad6.sum().item(), bad32.sum().item())
+        if special != special:
+            assert torch.equal(torch.isnan(y6), torch.isnan(y32))
+        ok = ~bad32
+        assert (y6[ok] - y32[ok]).abs().max().item() < 1e-4
+
+    # ---- +-0 and denormals
+    x = torch.zeros(B, cin, L)
+    x[0, :, ::2] = -0.0
+    tiny = torch.tensor([1e-45, -1e-45, 3e-42, 1e-40, -5e-39, 1.1e-38, 1.2e-38])            # denormals and the smallest normals
+    for i, v in enumerate(tiny):
+        x[0, (5 * i) % cin, 20 + 11 * i] = v
+    y6 = _run(lib, x.cuda(), w, None, tile, k, dil).cpu()
+    y32 = _run(lib, x.cuda(), w, None, ref_tile, k, dil).cpu()
+    assert torch.isfinite(y6).all()
+    bound = cin * k * 2.0 ** -133 * w.abs().max().item()
+    assert (y6.double() - y32.double()).abs().max().item() <= bound + 1e-45, ((y6.double() - y32.double()).abs().max().item(), bound)
+    z = torch.zeros(B, cin, L)
+    assert torch.equal(_run(lib, z.cuda(), w, None, tile, k, dil).cpu(), torch.zeros(B, cout, L))
+
+
 def test_conv1d_x6_resblock_shape_with_residual_in_place_like_the_generator():
     """convs2 of a wide stage: out = x + conv(lrelu(t)) with k = 11 — the launch the Generator issues, at a length that is not a
     multiple of any tile, compared with the fp32-MFMA kernel element by element."""
