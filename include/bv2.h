@@ -253,6 +253,10 @@ void bv2_graph_destroy(bv2_graph* graph);
  *                     product) at 6/16 of the fp32-MFMA time (kernels/conv_x6.hip).  0: v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
  *   "conv_x6_c32"     also the C = 32 stage layer-wise on conv_x6.hip (two launches per ResBlock pair, 44.6 us each at batch 1) instead
  *                     of the fused fp32-MFMA pair kernel (one launch, 110 us); 0: resblock_fused.hip
+ *   "fused_respair"   the wide bf16 Generator stages (C = 64 / 128 / 256) one (dilated conv, conv) ResBlock pair per launch, the
+ *                     intermediate in LDS (kernels/respair_cl_bf16.hip; bit-identical to the layer-wise path); 0: one conv per launch
+ *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
+ *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
  *   "fused_attn_o"    MultiHeadAttention.conv_o inside the attention kernel in the small-batch fp32 regime: head h writes partial
  *                     slab h, the LayerNorm sums the slabs (0: conv_o as its own launch)
