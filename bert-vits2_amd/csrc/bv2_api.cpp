@@ -401,6 +401,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "fused_respair") h->no_fused_respair = value == 0;
   else if (k == "respair_mix") h->respair_problem_major = value == 0;
   else if (k == "respair_form") h->respair_form = value;
+  else if (k == "respair_c32") h->no_respair_c32 = value == 0;
   else if (k == "conv_x6") h->no_conv_x6 = value == 0;
   else if (k == "conv_x6_c32") h->x6_narrow = value != 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;

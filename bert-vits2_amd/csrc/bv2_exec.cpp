@@ -962,6 +962,11 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     const int nb = m.n_rbk;
     bool whole = nb <= 3 && !c.h->no_fused_resblock;
     for (int j = 0; j < nb && whole; ++j) whole = m.rbcl_w_off[i][j] >= 0;
+    // C = 32: pair by pair (respair_cl_bf16.hip, one wave owns all 32 channels) — six tensor passes per ResBlock instead of two, but
+    // every launch streams near the HBM rate with three workgroups per CU, where the whole-ResBlock kernel's one resident workgroup
+    // runs its six GEMM / epilogue / barrier phases in lock-step: 1.58 -> 1.36 ms per step at B = 32.  (C = 16 through the same kernel
+    // on a half-empty MFMA block: 1.49 -> 1.72 ms, not kept.)
+    if (whole && U.cout == 32 && !c.h->no_respair_c32 && !c.h->no_fused_respair) whole = false;
     if (whole) {
       // narrow stages: every branch's whole ResBlock (all dilation pairs) in ONE launch, intermediates in LDS
       RbClLaunch F;

@@ -126,6 +126,7 @@ struct bv2_handle {
   bool no_conv_x6 = false;           // "conv_x6" = 0: wide Generator convs on the fp32 matrix core (conv_mfma.hip) instead of the bf16x6 form
   bool x6_narrow = true;             // "conv_x6_c32" = 0: the C = 32 stage on the fused fp32 pair kernel instead of layer-wise on conv_x6.hip
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
+  bool no_respair_c32 = false;       // "respair_c32" = 0: the C = 32 bf16 stage as whole-ResBlock launches (resblock_cl_bf16.hip) instead of pair by pair
   int respair_form = 1;              // "respair_form": 1 = 64 x 128 wave tiles (respair2_cl_bf16_kernel), 0 = 32-channel waves
   bool respair_problem_major = false; // "respair_mix" = 0: the pair kernel's branches dispatched one after the other (A/B only)
   bool no_fused_respair = false;     // "fused_respair" = 0: the wide bf16 Generator stages one conv per launch (gen_bf16.hip) instead of one pair per launch

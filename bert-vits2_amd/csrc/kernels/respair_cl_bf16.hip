@@ -117,12 +117,14 @@ respair_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
         o.x = bf_pack(a0, a1); o.y = bf_pack(a2, a3);
         if (!inside) o = u32x2{0u, 0u};
         *reinterpret_cast<u32x2*>(xs + r * PITCH + wn * 32 + 8 * g + 4 * lh) = o;
-        acc[ni][4 * g] = 0.f; acc[ni][4 * g + 1] = 0.f; acc[ni][4 * g + 2] = 0.f; acc[ni][4 * g + 3] = 0.f;
       }
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) acc[ni][r16] = 0.f;
     }
   }
   __syncthreads();
-  cl_tm_run<NI, G>(acc, ar, wq, wlane, k, xlane, 1);   // out row r = time t0 + r needs h rows r .. r + k - 1
+  // out row r = time t0 + r needs h rows r .. r + k - 1
+  cl_tm_run<NI, G>(acc, ar, wq, wlane, k, xlane, 1);
   if (L.dbg) ts3 = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: out = bf16(acc + b2 + x), the tile [BT][C] assembled in LDS, 16-byte row pieces to / from HBM (gen_bf16.hip)
@@ -551,8 +553,9 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
 }
 
 bool respair_cl_bf16_supported(int C, int k, int dil) {
-  if (C != 64 && C != 128 && C != 256) return false;
+  if (C != 32 && C != 64 && C != 128 && C != 256) return false;
   if (k < 3 || k % 2 == 0 || dil < 1) return false;
+  if (C == 32) return (int64_t)(512 + (k - 1) * dil) * (C + 8) * 2 <= 64 * 1024;   // first form only: one wave owns all 32 channels
   const int HT = C == 64 ? 256 : 128;             // the smaller of the two forms' tiles
   if (HT - (k - 1) < HT / 2) return false;        // at least half of conv1's rows are outputs
   const int HT2 = C == 64 ? 512 : 256;            // second form: (HT2 + (k-1) dil) rows of 2 C bytes
@@ -621,7 +624,7 @@ int launch_respair_cl_bf16(hipStream_t stream, const RpClLaunch& L, const char**
     const RpClProb& p = L.p[i];
     if (!respair_cl_bf16_supported(L.C, p.k, p.dil) || !p.x || !p.out || p.x == p.out || !p.w1 || !p.w2 || !p.b1 || !p.b2) return -1;
   }
-  if (L.form >= 1) {
+  if (L.form >= 1 && L.C >= 64) {
     switch (L.C) {
       case 64:
         if (variant_name) *variant_name = "respair_cl_bf16<64,64x128>";
@@ -636,6 +639,9 @@ int launch_respair_cl_bf16(hipStream_t stream, const RpClLaunch& L, const char**
     return -1;
   }
   switch (L.C) {
+    case 32:                                      // HBM-bound: 4 waves side by side in time, 512 rows of t per tile, 45 KB
+      if (variant_name) *variant_name = "respair_cl_bf16<32>";
+      return launch_rp<1, 4, 4, 2>(stream, L);
     case 64:
       if (variant_name) *variant_name = "respair_cl_bf16<64>";
       return launch_rp<2, 2, 4, 4>(stream, L);

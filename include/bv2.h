@@ -255,6 +255,7 @@ void bv2_graph_destroy(bv2_graph* graph);
  *                     of the fused fp32-MFMA pair kernel (one launch, 110 us); 0: resblock_fused.hip
  *   "fused_respair"   the wide bf16 Generator stages (C = 64 / 128 / 256) one (dilated conv, conv) ResBlock pair per launch, the
  *                     intermediate in LDS (kernels/respair_cl_bf16.hip; bit-identical to the layer-wise path); 0: one conv per launch
+ *   "respair_c32"     1 (default): also the C = 32 stage pair by pair (one wave owns all channels); 0: whole-ResBlock launches
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
