@@ -159,7 +159,7 @@ inline int qkv_rows(const EncoderW& e) { return 3 * e.hidden + e.heads * (2 * kA
 inline int n_slabs(int B, int T);
 void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask, const float* spk, int spk_bstride,
                  int B, int T, const char* tapname, bool f16 = false, float* out2 = nullptr, const float* vec2 = nullptr,
-                 int vec2_bstride = 0) {
+                 int vec2_bstride = 0, FbArgs* fb = nullptr) {
   const int H = e.hidden, ld = attn_ld(T), R = qkv_rows(e);
   // cond_layer_idx == 2 > 0: the speaker add always rides on the previous layer's LN2 epilogue
   for (int i = 0; i < e.n_layers; ++i) {
@@ -241,6 +241,12 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       l.mask = mask;
       if (out2) { l.out2 = out2; l.vec2 = vec2; l.vec2_bstride = vec2_bstride; }   // (x + vec2) * mask beside x * mask
     }
+    if (fb && i + 1 == e.n_layers) {
+      // the flow: this LayerNorm, the coupling's post and the next coupling's pre in one launch (flow_boundary.hip)
+      fb->a = l.a; fb->nslab = l.nslab; fb->slab_stride = l.slab_stride; fb->gamma = l.gamma; fb->beta = l.beta; fb->eps = l.eps;
+      fb->mask = mask; fb->B = B; fb->C = H; fb->T = T;
+      if (!c.rc) { if (int r = launch_flow_boundary(c.s, *fb)) c.fail("flow.boundary", r); }
+    } else
     c.ln(l, "enc.ln2");
     if (tapname) {
       const std::string tn = std::string(tapname) + ".layer." + std::to_string(i);
@@ -675,17 +681,41 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
   const bv2_config& cf = m.cfg;
   const int H = cf.hidden_channels, C = cf.inter_channels, half = C / 2;
   float* gv_flow = P.gv + cf.upsample_initial_channel;
+  bool pre_done = false;                            // the previous coupling's boundary launch already wrote this coupling's h
   for (int a = 0; a < m.n_coupling; ++a) {
     const CouplingW& K = m.coupling[a];
     float* x0 = z + (K.flipped ? (int64_t)half * Ty : 0);
     float* x1 = z + (K.flipped ? 0 : (int64_t)half * Ty);
-    ConvProb p = c.prob(K.pre, x0, P.h, Ty);
-    p.x_bstride = (int64_t)C * Ty;
-    p.out_mask = ymask; p.mask_post = 1;
-    c.conv1(p, B, Ty, "flow.pre");
+    // small-N fp32 regime: LayerNorm-2 of the last Encoder layer + post + the NEXT coupling's pre run as one launch (flow_boundary.hip);
+    // the next coupling's x0 is this coupling's x1 (the Flip is folded into the weights), so its `h` is ready when its turn comes
+    bool fuse_b = cf.use_transformer_flow && c.h->flow_dtype != BV2_F16 && !c.h->no_fused_boundary && c.h->taps.empty() &&
+                  n_slabs(B, Ty) > 1 && H == 192 && half * 2 == C && K.post.cin == H && K.post.cout == half && K.post.k == 1 &&
+                  K.pre.cin == half && K.pre.cout == H && K.pre.k == 1 && K.post.cin_pad == H && K.pre.cin_pad == half;
+    const CouplingW* Kn = a + 1 < m.n_coupling ? &m.coupling[a + 1] : nullptr;
+    if (fuse_b && Kn) {
+      const float* x0n = z + (Kn->flipped ? (int64_t)half * Ty : 0);
+      fuse_b = x0n == x1 && Kn->pre.cin == half && Kn->pre.cout == H && Kn->pre.k == 1 && Kn->pre.cin_pad == half;
+    }
+    ConvProb p;
+    if (!pre_done) {
+      p = c.prob(K.pre, x0, P.h, Ty);
+      p.x_bstride = (int64_t)C * Ty;
+      p.out_mask = ymask; p.mask_post = 1;
+      c.conv1(p, B, Ty, "flow.pre");
+    }
+    pre_done = false;
     const float* hres = P.h;
     if (cf.use_transformer_flow) {
-      run_encoder(c, K.enc, P.enc, ymask, gv_flow + a * H, P.gv_stride, B, Ty, nullptr, c.h->flow_dtype == BV2_F16);
+      FbArgs F;
+      std::memset(&F, 0, sizeof(F));
+      if (fuse_b) {
+        F.x1 = x1; F.x1_out = x1; F.z_bstride = (int64_t)C * Ty;
+        F.post_w = c.W(K.post.w_off); F.post_b = c.W(K.post.b_off);
+        if (Kn) { F.pre_w = c.W(Kn->pre.w_off); F.pre_b = c.W(Kn->pre.b_off); F.pre_out = P.h; pre_done = true; }
+      }
+      run_encoder(c, K.enc, P.enc, ymask, gv_flow + a * H, P.gv_stride, B, Ty, nullptr, c.h->flow_dtype == BV2_F16, nullptr, nullptr, 0,
+                  fuse_b ? &F : nullptr);
+      if (fuse_b) continue;                                      // post (and the next pre) are done
     } else if (c.h->flow_dtype == BV2_F16) {
       // WN.forward on the fp16 matrix core (bv2_set_flow_dtype(BV2_F16)): in_layer reads the fp32 x (rounded while staged), adds
       // bias + g_l and gates in fp32, writes the gate output as fp16 channels-last — it is only ever res_skip's input; res_skip

@@ -310,6 +310,23 @@ struct LnArgs {
 };
 int launch_layernorm(hipStream_t stream, const LnArgs& a);
 
+// The boundary between two coupling layers of the transformer flow in one launch (kernels/flow_boundary.hip): LayerNorm-2 of the
+// coupling's last Encoder layer (slab sum + LayerNorm + mask), post (1x1, C -> C/2, x1 = (x1 - post(h) - b) * mask, in place in z) and —
+// unless pre_w is null (last coupling) — pre of the next coupling (1x1, C/2 -> C, (pre(x1) + b) * mask -> pre_out).  Weights in the
+// packed conv layout (conv_w_index, k = 1).  h_out: optional copy of the LayerNorm output (debug taps).
+struct FbArgs {
+  const float* a; int nslab; int64_t slab_stride;      // LayerNorm input: nslab slabs [B][C][T]
+  const float* gamma; const float* beta; float eps;
+  const float* mask;                                   // [B][T]
+  const float* x1; float* x1_out; int64_t z_bstride;   // [C/2 rows][T] inside z (floats between batch items)
+  const float* post_w; const float* post_b;
+  const float* pre_w; const float* pre_b; float* pre_out;   // pre_out [B][C][T]
+  float* h_out;
+  int B, C, T;
+};
+bool flow_boundary_supported(const FbArgs& a);
+int launch_flow_boundary(hipStream_t stream, const FbArgs& a);
+
 // --------------------------------------------------------------------------------------------------------------
 // BERT feature extractor (kernels/bert.hip; include/bv2_bert.h)
 struct BertEmbedArgs {

@@ -259,6 +259,8 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
+ *   "fused_boundary"  transformer flow, small-batch fp32 regime: LayerNorm-2 of a coupling's last Encoder layer, its `post` and the next
+ *                     coupling's `pre` in one launch (kernels/flow_boundary.hip); 0: three launches
  *   "fused_attn_o"    MultiHeadAttention.conv_o inside the attention kernel in the small-batch fp32 regime: head h writes partial
  *                     slab h, the LayerNorm sums the slabs (0: conv_o as its own launch)
  *   "overlap_dp"      default 0: 1 runs the DurationPredictor on an internal side stream beside the stochastic one (fork / join
