@@ -433,6 +433,44 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     return res
 
 
+def run_batches_in_flight(model, hp, dev, steps, nstreams=2, num=3):
+    """BASELINE config `num`'s batch with `nstreams` REQUESTS in flight (each a full batch of that config, eager): one request's flow —
+    memory / latency-bound fp16 convs and attention — runs beside the other's Generator — MFMA-bound pair kernels.  The serving
+    pipeline's throughput (serving.synthesize(requests_in_flight=n)); reported beside the one-request figure, never instead of it."""
+    cfg = CONFIGS[num]
+    ms = [model]
+    for _ in range(nstreams - 1):
+        m2 = models.from_hparams(hp)
+        m2.attach_blob(model._blob)
+        ms.append(m2)
+    for m in ms:
+        m.enable_graphs(False)
+        m.set_generator_dtype(torch.bfloat16 if cfg["dtype"] == "bf16" else torch.float32)
+        m.set_flow_dtype(torch.float16 if cfg["flow"] == "f16" else torch.float32)
+    batch, lengths = make_batch(cfg, cfg["batch"], cfg["symbols"], 0)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    streams = [torch.cuda.Stream(dev) for _ in ms]
+
+    def step(i):
+        with torch.cuda.stream(streams[i % nstreams]):
+            return ms[i % nstreams].infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"], **KW)
+
+    for i in range(3 * nstreams):
+        out = step(i)
+    torch.cuda.synchronize()
+    frames = int(out[2].sum().item())
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    audio = frames * hp.total_upsample / hp.sampling_rate
+    return dict(workload=f"BASELINE config {num}'s batch (B={cfg['batch']} x T={cfg['symbols']}, bf16 Generator + fp16 flow, eager), {nstreams} "
+                         f"requests in flight on {nstreams} HIP streams ({nstreams} handles, one weight blob)", requests_in_flight=nstreams,
+                value=round(audio * steps / dt, 2), unit="audio-seconds/sec", ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
+                note="throughput of a request pipeline; per-request latency is about twice ms_per_step")
+
+
 def run_two_streams(model, hp, dev, steps, nstreams=2):
     """Config 2's utterance with TWO requests in flight: two shim instances share the packed weight blob, each owns a HIP stream and
     its workspace, and the host alternates between them — while one request's phase A / flow (a chain of small kernels that leaves
@@ -965,6 +1003,11 @@ def rank_main(args):
         except Exception as e:
             secondary["residual_flow_error"] = repr(e)[:300]
 
+        try:
+            secondary["config3_2_requests_in_flight"] = run_batches_in_flight(model, hp, dev, 10, 2, 3)
+            log(f"secondary config 3, 2 requests in flight: {secondary['config3_2_requests_in_flight']['value']} audio-s/s")
+        except Exception as e:
+            secondary["config3_2_requests_in_flight"] = dict(error=repr(e)[:300])
         for ns in sorted({args.streams, 4}):
             key = f"config2_{ns}_requests_in_flight"
             try:
