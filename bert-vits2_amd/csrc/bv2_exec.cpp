@@ -829,8 +829,14 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     const int nb = m.n_rbk;
     bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock;
     // C = 32: two split-bf16 launches per pair (HBM-bound, 5 tensor passes) against one fused fp32-MFMA launch (MFMA-bound, 3 passes)
-    if (fused && c.h->x6_narrow && !c.h->no_conv_x6 && U.cout == 32 && m.rb[i][0][0][0].wx_off >= 0) fused = false;
-    for (int j = 0; j < nb && fused; ++j)
+    // C = 32 with the planes packed: the pair in ONE launch on the bf16 matrix core (respair_x6.hip: two passes AND the fast pipe)
+    bool x6pair = fused && !c.h->no_conv_x6 && !c.h->no_x6_pair && U.cout == 32;
+    for (int j = 0; j < nb && x6pair; ++j)
+      for (int d = 0; d < m.n_rbd && x6pair; ++d)
+        x6pair = m.rb[i][j][d][0].wx_off >= 0 && m.rb[i][j][d][1].wx_off >= 0 && m.rb[i][j][d][0].k == m.rb[i][j][d][1].k &&
+                 respair_x6_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
+    if (fused && !x6pair && c.h->x6_narrow && !c.h->no_conv_x6 && U.cout == 32 && m.rb[i][0][0][0].wx_off >= 0) fused = false;
+    for (int j = 0; j < nb && fused && !x6pair; ++j)
       for (int d = 0; d < m.n_rbd; ++d)
         fused = fused && resblock_fused_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
     float* branch_out[BV2_MAX_RESBLOCK_KERNELS];
@@ -853,6 +859,10 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
           p.w1 = c.W(m.rb[i][j][d][0].w_off); p.b1 = c.W(m.rb[i][j][d][0].b_off);
           p.w2 = c.W(m.rb[i][j][d][1].w_off); p.b2 = c.W(m.rb[i][j][d][1].b_off);
           p.k = m.rb[i][j][d][0].k; p.dil = cf.resblock_dilation_sizes[j][d];
+          if (x6pair) {
+            p.w61 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off));
+            p.w62 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][1].wx_off));
+          }
           branch_out[j] = xout;
         }
         if (!c.rc) {
@@ -860,8 +870,8 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
           if (pi >= 0 && c.h->prof_mode >= 3)
             c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
                           std::to_string(Lo) + " B" + std::to_string(B);
-          const int r = launch_resblock_fused(c.s, F);
-          c.prof_end(pi, "resblock_fused", resblock_fused_flops(F), resblock_fused_bytes(F));
+          const int r = x6pair ? launch_respair_x6(c.s, F) : launch_resblock_fused(c.s, F);
+          c.prof_end(pi, x6pair ? "respair_x6<32>" : "resblock_fused", resblock_fused_flops(F), resblock_fused_bytes(F));
           if (r) c.fail("dec.resblock.fused", r);
         }
       }

@@ -141,6 +141,7 @@ struct FusedProb {
   const float* w1; const float* b1;               // packed weights (conv_w_index) / bias of convs1[d]
   const float* w2; const float* b2;               // ... of convs2[d]
   int k, dil;
+  const uint16_t* w61; const uint16_t* w62;       // respair_x6.hip only: the two convs' split-bf16 weight planes (x6_w_index)
 };
 struct FusedLaunch { FusedProb p[3]; int nprob, B, C, L; float slope; const int64_t* lens = nullptr; int len_mul = 1;
                      unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
@@ -148,6 +149,9 @@ bool resblock_fused_supported(int C, int k, int dil);
 int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F);
 double resblock_fused_flops(const FusedLaunch& F);
 double resblock_fused_bytes(const FusedLaunch& F);
+// the same pair at C = 32 with both convs on the bf16 matrix core from exact three-way bf16 splits (kernels/respair_x6.hip)
+bool respair_x6_supported(int C, int k, int dil);
+int launch_respair_x6(hipStream_t stream, const FusedLaunch& F);
 
 // --------------------------------------------------------------------------------------------------------------
 // bf16 Generator (kernels/gen_bf16.hip): channels-last activations [B][L][C] (C contiguous, bf16), bf16 MFMA

@@ -1,0 +1,290 @@
+// respair_x6.hip — one (dilated conv, conv) pair of ResBlock1 with its residual (reference modules.py:296-309) of the C = 32 fp32
+// Generator stage in ONE launch, both convs on the bf16 matrix core from exact three-way bf16 splits (conv_x6.hip's arithmetic:
+// fp32 operands, fp32 results, six of the nine cross products), the intermediate in LDS.
+//
+// Why.  At C = 32 the layer-wise split-bf16 convs (conv1d_x6<32x256>, two launches per pair) move five fp32 tensor passes per
+// pair at 2.2 TB/s and are as much HBM- / latency- as MFMA-bound (PMC: MFMA busy 0.23); the fused fp32-MFMA pair kernel
+// (resblock_fused.hip) has three passes but runs on the 16x slower fp32 matrix pipe (110 us per launch against 2 x 42).  Here: two
+// passes AND the bf16 pipe.  The x tile ([32 channels][256 + (k-1)(d+1) columns]) is loaded once (lane = column: coalesced),
+// pre-activated, split into its three planes and written channels-last to LDS; conv1 runs on it; t = acc + b1, h = lrelu(t) (zero
+// outside [0, L): conv2's padding) is split into its planes in registers and written OVER the dead x planes; conv2 runs on h; the
+// epilogue adds b2 and the fp32 residual (re-read from L2, coalesced) and stores fp32 [B][C][T].  A tile computes 256 columns of h
+// and 256 - (k-1) outputs (the k-1 halo columns are recomputed by the neighbour: 1-4 %).  Same unit order and the same values at
+// every step as the two layer-wise launches: bit-identical to them (tests/test_x6_gpu.py).
+// out must not alias x (a tile's halo columns are another tile's outputs): the host ping-pongs between two buffers per branch.
+#include <hip/hip_runtime.h>
+#include "../bv2_kernels.h"
+
+namespace bv2 {
+
+namespace {
+
+typedef __bf16 pxbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pxbf16x2 __attribute__((ext_vector_type(2)));
+typedef float pxf32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned pxu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned pxu32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) pxbf16x8 PxGlobalFrag;
+
+__device__ __forceinline__ float px_ld(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ unsigned px_pack(float a, float b) {     // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  pxbf16x2 r;
+  r[0] = (__bf16)a; r[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float px_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float px_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// the three planes of a pair of values (conv_x6.hip store_x: plane 1 saturates at the largest bf16)
+__device__ __forceinline__ void px_split2(float a, float b, unsigned& u1, unsigned& u2, unsigned& u3) {
+  constexpr float M = 3.38953139e38f;
+  u1 = px_pack(__builtin_amdgcn_fmed3f(a, -M, M), __builtin_amdgcn_fmed3f(b, -M, M));
+  a -= px_lo(u1); b -= px_hi(u1);
+  u2 = px_pack(a, b);
+  a -= px_lo(u2); b -= px_hi(u2);
+  u3 = px_pack(a, b);
+}
+
+constexpr int PX_C = 32;                  // channels
+constexpr int PX_HT = 256;                // columns of h per tile (4 waves x 64)
+constexpr int PX_XR = 320;                // staged columns: 256 + (k-1)(d+1) <= 316
+constexpr int PX_PITCH = PX_C + 8;        // bf16 elements per LDS row (80 B: odd multiple of 16 B)
+constexpr int PX_PLANE = PX_XR * PX_PITCH;
+constexpr int PX_UNIT = 3 * 512;          // elements of one (group, tap) unit: 3 planes x 64 lanes x 8
+constexpr int PX_GR = PX_C / 16;          // 16-channel groups = ring slots
+
+}  // namespace
+
+__global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
+  constexpr int NI = 2, NRG = PX_XR / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]: x planes, then h planes
+  const FusedProb P = L.p[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int k = P.k, dil = P.dil;
+  const int BT = PX_HT - (k - 1);
+  const int bx = blockIdx.x;
+  const int vt = per_xcd ? (bx & 7) * per_xcd + (bx >> 3) : bx;
+  const int t0 = vt * BT;
+  if (t0 >= L.L) return;
+  const int b = blockIdx.y;
+  int Lin = L.L;
+  if (L.lens) {
+    const int64_t lv = L.lens[b] * L.len_mul;
+    Lin = lv < Lin ? (int)lv : Lin;
+    if (t0 >= Lin) return;
+  }
+  const int p2 = (k - 1) / 2, p1 = p2 * dil;
+  const float slope = L.slope;
+  const int64_t bstride = (int64_t)PX_C * L.L;
+  const float* const x0p = P.x + (int64_t)b * bstride;
+  const unsigned x_rs4 = 4u * (unsigned)L.L;
+  const unsigned wlane = 16u * (unsigned)lane;
+
+  // ---- weight ring (conv_x6.hip): two slots per 16-channel group, the stream of a group runs over its k taps
+  pxbf16x8 ar[PX_GR][2][3];
+  const uint16_t* wq[PX_GR];
+  auto load_unit = [&](int g, int SL, int step) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      ar[g][SL][p] = *(const PxGlobalFrag*)(reinterpret_cast<const char*>(wq[g]) + wlane + 1024u * (unsigned)p);
+    wq[g] += step;
+  };
+  const int wrap_step = -((k - 1) * PX_UNIT);      // past a group's last tap: back to its first (valid memory, values unused)
+  auto prime = [&](const uint16_t* w6) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < PX_GR; ++g) wq[g] = w6 + (int64_t)g * k * PX_UNIT;
+#pragma unroll
+    for (int g = 0; g < PX_GR; ++g) { load_unit(g, 0, PX_UNIT); __builtin_amdgcn_sched_barrier(0); }
+    const int s1 = 2 < k ? PX_UNIT : wrap_step;    // k >= 3
+#pragma unroll
+    for (int g = 0; g < PX_GR; ++g) { load_unit(g, 1, s1); __builtin_amdgcn_sched_barrier(0); }
+  };
+  prime(P.w61);
+
+  // ---- stage x: wave `wid` loads channel octet `wid` of every 64-column group (lane = column), lrelu, split, channels-last planes
+  {
+    const int tbase = t0 - p2 - p1;
+    const int XW = PX_HT + (k - 1) * dil;
+    float xr[NRG][8];
+    float colsc[NRG];
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg) {
+      const int r = rg * 64 + lane;
+      const int t = tbase + r;
+      const bool tok = r < XW && t >= 0 && t < Lin;
+      colsc[rg] = tok ? 1.f : 0.f;
+      const unsigned tc = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
+      const unsigned row0 = (unsigned)(wid * 8) * x_rs4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xr[rg][e] = px_ld(x0p, row0 + (unsigned)e * x_rs4 + tc);
+    }
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg) {
+      pxu32x4 q1, q2, q3;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float a = xr[rg][2 * w], bq = xr[rg][2 * w + 1];
+        const float an = a * slope, bn = bq * slope;
+        a = a < 0.f ? an : a;
+        bq = bq < 0.f ? bn : bq;
+        a *= colsc[rg]; bq *= colsc[rg];
+        unsigned u1, u2, u3;
+        px_split2(a, bq, u1, u2, u3);
+        q1[w] = u1; q2[w] = u2; q3[w] = u3;
+      }
+      unsigned short* dst = xs + (rg * 64 + lane) * PX_PITCH + wid * 8;
+      *reinterpret_cast<pxu32x4*>(dst) = q1;
+      *reinterpret_cast<pxu32x4*>(dst + PX_PLANE) = q2;
+      *reinterpret_cast<pxu32x4*>(dst + 2 * PX_PLANE) = q3;
+    }
+  }
+  __syncthreads();
+
+  pxf32x16 acc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+  const unsigned short* const xlane = xs + (wid * 64 + l31) * PX_PITCH + lh * 8;
+
+  // one GEMM over the tile in LDS: acc[ni] += sum over (tap j, group g) of the six cross products (conv_x6.hip's unit)
+  auto gemm = [&](int tap_step) __attribute__((always_inline)) {
+    pxbf16x8 bb[2][NI][3];
+    const unsigned short* xrow = xlane;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const pxbf16x8*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
+    auto tap = [&](int j, int SL) __attribute__((always_inline)) {
+      const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;
+      const int jl = j + 2;                         // the unit loaded during this tap
+      const int step = jl + 1 < k ? PX_UNIT : (jl < k ? wrap_step : (jl == k ? PX_UNIT : wrap_step));
+#pragma unroll
+      for (int g = 0; g < PX_GR; ++g) {
+        {
+          const unsigned short* xn = (g + 1 < PX_GR) ? xrow + (g + 1) * 16 : xnext;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              bb[(g & 1) ^ 1][ni][p] = *reinterpret_cast<const pxbf16x8*>(xn + ni * 32 * PX_PITCH + p * PX_PLANE);
+        }
+#define PX_PROD(WP, XP)                                                                                              \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                            \
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][SL][WP], bb[g & 1][ni][XP], acc[ni], 0, 0, 0);
+        PX_PROD(2, 0) PX_PROD(1, 1) PX_PROD(0, 2) PX_PROD(1, 0) PX_PROD(0, 1) PX_PROD(0, 0)
+#undef PX_PROD
+        load_unit(g, SL, step);
+        constexpr int NM = NI * 6, NDS = NI * 3, NVM = 3;
+#pragma unroll
+        for (int q = 0; q < NDS; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NDS - NVM, 0);
+#pragma unroll
+        for (int q = 0; q < NVM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      xrow = xnext;
+    };
+    for (int j = 0; j + 1 < k; j += 2) { tap(j, 0); tap(j + 1, 1); }
+    tap(k - 1, 0);
+  };
+  gemm(dil * PX_PITCH);
+
+  // ---- h = lrelu(conv1 + b1), zero outside [0, L) (conv2's padding), split into its planes, written over the x planes
+  prime(P.w62);
+  float b1v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) b1v[r] = P.b1[4 * lh + (r & 3) + 8 * (r >> 2)];
+  __syncthreads();                                // every wave is done reading the x planes
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int hc = wid * 64 + ni * 32 + l31;      // column of h: time t0 - p2 + hc
+    const int th = t0 - p2 + hc;
+    const float ok = (th >= 0 && th < Lin) ? 1.f : 0.f;
+    unsigned short* dst = xs + hc * PX_PITCH + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                 // channels 8 j + 4 lh + {0, 1, 2, 3} = registers 4 j .. 4 j + 3
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t = acc[ni][4 * j + i] + b1v[4 * j + i];
+        const float tn = t * slope;
+        t = t < 0.f ? tn : t;
+        v[i] = t * ok;
+        acc[ni][4 * j + i] = 0.f;
+      }
+      unsigned a1, a2, a3, c1, c2, c3;
+      px_split2(v[0], v[1], a1, a2, a3);
+      px_split2(v[2], v[3], c1, c2, c3);
+      *reinterpret_cast<pxu32x2*>(dst + 8 * j) = pxu32x2{a1, c1};
+      *reinterpret_cast<pxu32x2*>(dst + 8 * j + PX_PLANE) = pxu32x2{a2, c2};
+      *reinterpret_cast<pxu32x2*>(dst + 8 * j + 2 * PX_PLANE) = pxu32x2{a3, c3};
+    }
+  }
+  // the epilogue's operands: in flight under conv2
+  float b2v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) b2v[r] = P.b2[4 * lh + (r & 3) + 8 * (r >> 2)];
+  __syncthreads();
+  gemm(PX_PITCH);
+
+  // ---- out = conv2 + b2 + x: fp32 [B][C][T], lane = column (coalesced residual reads and stores)
+  {
+    float* const outb = P.out + (int64_t)b * bstride;
+    const int rows = L.L - t0 < BT ? L.L - t0 : BT;
+    float rv[NI][16];
+    bool colok[NI];
+    unsigned off0[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int oc = wid * 64 + ni * 32 + l31;
+      colok[ni] = oc < rows;
+      const int t = t0 + (colok[ni] ? oc : 0);
+      off0[ni] = (unsigned)(4 * lh) * (unsigned)L.L + (unsigned)t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[ni][r] = px_ld(x0p, 4u * (off0[ni] + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L.L));
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (acc[ni][r] + b2v[r]) + rv[ni][r];
+        if (colok[ni]) outb[off0[ni] + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L.L] = v;
+      }
+  }
+}
+
+bool respair_x6_supported(int C, int k, int dil) {
+  if (C != PX_C || k < 3 || k % 2 == 0 || dil < 1) return false;
+  return PX_HT + (k - 1) * dil <= PX_XR && PX_HT - (k - 1) >= PX_HT / 2;
+}
+
+int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
+  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1 || F.C != PX_C) return -1;
+  if ((int64_t)F.C * F.L >= (1ll << 29)) return -1;               // 32-bit byte offsets inside a batch item
+  int ntx = 0;
+  for (int i = 0; i < F.nprob; ++i) {
+    const FusedProb& p = F.p[i];
+    if (!respair_x6_supported(F.C, p.k, p.dil) || !p.x || !p.out || p.x == p.out || !p.w61 || !p.w62 || !p.b1 || !p.b2) return -1;
+    const int BT = PX_HT - (p.k - 1);
+    const int n = (F.L + BT - 1) / BT;
+    ntx = n > ntx ? n : ntx;
+  }
+  const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
+  const size_t lds = (size_t)3 * PX_PLANE * 2;
+  dim3 grid(per_xcd ? per_xcd * 8 : ntx, F.B, F.nprob);
+  (void)hipFuncSetAttribute((const void*)respair_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(respair_x6_kernel, grid, dim3(256), lds, stream, F, per_xcd);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace bv2

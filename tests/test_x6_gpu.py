@@ -184,3 +184,49 @@ def test_generator_on_conv_x6_matches_the_fp32_mfma_generator():
         e = (outs[name] - ref).pow(2).mean().sqrt().item()
         assert e <= 5e-6 * scale + 1e-7, (name, e, scale)
     assert not torch.equal(outs["x6"], ref)      # the switch really changed the kernels
+
+
+@pytest.mark.parametrize("B,Ty,lens", [(1, 384, [384]), (3, 97, [97, 60, 33]), (1, 5, [5])])
+def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
+    """kernels/respair_x6.hip (C = 32 fp32 stage: dilated conv -> LDS -> conv + residual in one launch, both convs on the bf16 matrix
+    core from three-way splits) against the two conv_x6 launches it replaces ("x6_pair" = 0): the same unit order and the same values
+    at every step — the stage's three ResBlock outputs and the waveform bit for bit; exact lengths and the masked tail too."""
+    from bert_vits2_amd import hparams as H, models, synth
+    hp = H.default_v23()
+    m = models.from_hparams(hp)
+    m.load_state_dict(synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5), strict=False)
+    m = m.to("cuda").eval()
+    g = torch.Generator().manual_seed(B * 100 + Ty)
+    z = torch.randn(B, hp.inter_channels, Ty, generator=g).cuda()
+    yl = torch.tensor(lens, dtype=torch.int64).cuda()
+    gv = torch.randn(B, hp.gin_channels, generator=g).cuda()
+    up = 1
+    for u in hp.upsample_rates[:4]:
+        up *= u
+    res = {}
+    for pair in (1, 0):
+        m.set_option("x6_pair", pair)
+        taps = {f"dec.rb.3.{j}": torch.full((B, 32, Ty * up), float("nan"), device="cuda") for j in range(3)}
+        for k, t in taps.items():
+            m.set_tap(k, t)
+        try:
+            o = m.stage_generator(z, yl, gv)
+            torch.cuda.synchronize()
+        finally:
+            m.set_tap(None)
+        res[pair] = (o, taps)
+    m.set_option("x6_pair", 1)
+    # a stage of <= 4096 columns runs its layer-wise convs on the split-K fp32-MFMA kernel (small-N regime), not on conv_x6: there the
+    # two paths agree to fp32 round-off, not bit for bit
+    exact = B * Ty * up > 4096
+    for k in res[0][1]:
+        a, b = res[1][1][k], res[0][1][k]
+        assert torch.isfinite(a).all(), k
+        if exact:
+            assert torch.equal(a, b), (k, (a - b).abs().max().item(), (a != b).float().mean().item())
+        else:
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item(), k
+    if exact:
+        assert torch.equal(res[1][0], res[0][0])
+    else:
+        assert (res[1][0] - res[0][0]).abs().max().item() <= 1e-5
