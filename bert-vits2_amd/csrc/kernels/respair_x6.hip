@@ -46,22 +46,25 @@ __device__ __forceinline__ void px_split2(float a, float b, unsigned& u1, unsign
   u3 = px_pack(a, b);
 }
 
-constexpr int PX_C = 32;                  // channels
-constexpr int PX_HT = 256;                // columns of h per tile (4 waves x 64)
+constexpr int PX_HT = 256;                // columns of h per tile (4 waves x 64 along time)
 constexpr int PX_XR = 320;                // staged columns: 256 + (k-1)(d+1) <= 316
-constexpr int PX_PITCH = PX_C + 8;        // bf16 elements per LDS row (80 B: odd multiple of 16 B)
-constexpr int PX_PLANE = PX_XR * PX_PITCH;
 constexpr int PX_UNIT = 3 * 512;          // elements of one (group, tap) unit: 3 planes x 64 lanes x 8
-constexpr int PX_GR = PX_C / 16;          // 16-channel groups = ring slots
 
 }  // namespace
 
-__global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
+// C = 32: 4 waves side by side in time, 77 KB, two workgroups per CU.  C = 64: 2 (row blocks) x 4 (time) waves, 138 KB, one 8-wave
+// workgroup per CU (two waves per SIMD).  Wave `wid` stages channel octet `wid` in both.
+template <int PX_C>
+__global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
   constexpr int NI = 2, NRG = PX_XR / 64;
+  constexpr int PX_PITCH = PX_C + 8;              // bf16 elements per LDS row (80 / 144 B: odd multiples of 16 B)
+  constexpr int PX_PLANE = PX_XR * PX_PITCH;
+  constexpr int PX_GR = PX_C / 16;                // 16-channel groups = ring slots
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]: x planes, then h planes
   const FusedProb P = L.p[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;          // 32-row block, 64-column block of this wave's tile
   const int l31 = lane & 31, lh = lane >> 5;
   const int k = P.k, dil = P.dil;
   const int BT = PX_HT - (k - 1);
@@ -95,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L,
   const int wrap_step = -((k - 1) * PX_UNIT);      // past a group's last tap: back to its first (valid memory, values unused)
   auto prime = [&](const uint16_t* w6) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < PX_GR; ++g) wq[g] = w6 + (int64_t)g * k * PX_UNIT;
+    for (int g = 0; g < PX_GR; ++g) wq[g] = w6 + (int64_t)(wm * PX_GR + g) * k * PX_UNIT;
 #pragma unroll
     for (int g = 0; g < PX_GR; ++g) { load_unit(g, 0, PX_UNIT); __builtin_amdgcn_sched_barrier(0); }
     const int s1 = 2 < k ? PX_UNIT : wrap_step;    // k >= 3
@@ -148,54 +151,59 @@ __global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L,
   for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-  const unsigned short* const xlane = xs + (wid * 64 + l31) * PX_PITCH + lh * 8;
+  const unsigned short* const xlane = xs + (wn * 64 + l31) * PX_PITCH + lh * 8;
 
-  // one GEMM over the tile in LDS: acc[ni] += sum over (tap j, group g) of the six cross products (conv_x6.hip's unit)
+  // one GEMM over the tile in LDS: acc[ni] += sum over (pass c, tap j, group g of the pass) of the six cross products (conv_x6.hip's
+  // unit).  The groups run in passes of two — conv_x6's 32-channel chunks — so that the fp32 sums see the layer-wise kernel's order.
   auto gemm = [&](int tap_step) __attribute__((always_inline)) {
     pxbf16x8 bb[2][NI][3];
-    const unsigned short* xrow = xlane;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int c = 0; c < PX_GR / 2; ++c) {
+      const unsigned short* xrow = xlane + c * 32;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const pxbf16x8*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
-    auto tap = [&](int j, int SL) __attribute__((always_inline)) {
-      const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;
-      const int jl = j + 2;                         // the unit loaded during this tap
-      const int step = jl + 1 < k ? PX_UNIT : (jl < k ? wrap_step : (jl == k ? PX_UNIT : wrap_step));
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int g = 0; g < PX_GR; ++g) {
-        {
-          const unsigned short* xn = (g + 1 < PX_GR) ? xrow + (g + 1) * 16 : xnext;
+        for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const pxbf16x8*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
+      auto tap = [&](int j, int SL) __attribute__((always_inline)) {
+        const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;
+        const int jl = j + 2;                       // the unit loaded during this tap
+        const int step = jl + 1 < k ? PX_UNIT : (jl < k ? wrap_step : (jl == k ? PX_UNIT : wrap_step));
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
+        for (int gl = 0; gl < 2; ++gl) {
+          const int g = 2 * c + gl;
+          {
+            const unsigned short* xn = (gl == 0) ? xrow + 16 : xnext;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-              bb[(g & 1) ^ 1][ni][p] = *reinterpret_cast<const pxbf16x8*>(xn + ni * 32 * PX_PITCH + p * PX_PLANE);
-        }
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+                bb[gl ^ 1][ni][p] = *reinterpret_cast<const pxbf16x8*>(xn + ni * 32 * PX_PITCH + p * PX_PLANE);
+          }
 #define PX_PROD(WP, XP)                                                                                              \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                            \
-          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][SL][WP], bb[g & 1][ni][XP], acc[ni], 0, 0, 0);
-        PX_PROD(2, 0) PX_PROD(1, 1) PX_PROD(0, 2) PX_PROD(1, 0) PX_PROD(0, 1) PX_PROD(0, 0)
+          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                          \
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][SL][WP], bb[gl][ni][XP], acc[ni], 0, 0, 0);
+          PX_PROD(2, 0) PX_PROD(1, 1) PX_PROD(0, 2) PX_PROD(1, 0) PX_PROD(0, 1) PX_PROD(0, 0)
 #undef PX_PROD
-        load_unit(g, SL, step);
-        constexpr int NM = NI * 6, NDS = NI * 3, NVM = 3;
+          load_unit(g, SL, step);
+          constexpr int NM = NI * 6, NDS = NI * 3, NVM = 3;
 #pragma unroll
-        for (int q = 0; q < NDS; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - NDS - NVM, 0);
+          for (int q = 0; q < NDS; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NM - NDS - NVM, 0);
 #pragma unroll
-        for (int q = 0; q < NVM; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          for (int q = 0; q < NVM; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      xrow = xnext;
-    };
-    for (int j = 0; j + 1 < k; j += 2) { tap(j, 0); tap(j + 1, 1); }
-    tap(k - 1, 0);
+        xrow = xnext;
+      };
+      for (int j = 0; j + 1 < k; j += 2) { tap(j, 0); tap(j + 1, 1); }
+      tap(k - 1, 0);
+    }
   };
   gemm(dil * PX_PITCH);
 
@@ -203,14 +211,14 @@ __global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L,
   prime(P.w62);
   float b1v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) b1v[r] = P.b1[4 * lh + (r & 3) + 8 * (r >> 2)];
+  for (int r = 0; r < 16; ++r) b1v[r] = P.b1[wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
   __syncthreads();                                // every wave is done reading the x planes
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int hc = wid * 64 + ni * 32 + l31;      // column of h: time t0 - p2 + hc
+    const int hc = wn * 64 + ni * 32 + l31;       // column of h: time t0 - p2 + hc
     const int th = t0 - p2 + hc;
     const float ok = (th >= 0 && th < Lin) ? 1.f : 0.f;
-    unsigned short* dst = xs + hc * PX_PITCH + 4 * lh;
+    unsigned short* dst = xs + hc * PX_PITCH + wm * 32 + 4 * lh;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                 // channels 8 j + 4 lh + {0, 1, 2, 3} = registers 4 j .. 4 j + 3
       float v[4];
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L,
   // the epilogue's operands: in flight under conv2
   float b2v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) b2v[r] = P.b2[4 * lh + (r & 3) + 8 * (r >> 2)];
+  for (int r = 0; r < 16; ++r) b2v[r] = P.b2[wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
   __syncthreads();
   gemm(PX_PITCH);
 
@@ -246,10 +254,10 @@ __global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L,
     unsigned off0[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int oc = wid * 64 + ni * 32 + l31;
+      const int oc = wn * 64 + ni * 32 + l31;
       colok[ni] = oc < rows;
       const int t = t0 + (colok[ni] ? oc : 0);
-      off0[ni] = (unsigned)(4 * lh) * (unsigned)L.L + (unsigned)t;
+      off0[ni] = (unsigned)(wm * 32 + 4 * lh) * (unsigned)L.L + (unsigned)t;
 #pragma unroll
       for (int r = 0; r < 16; ++r) rv[ni][r] = px_ld(x0p, 4u * (off0[ni] + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L.L));
     }
@@ -264,12 +272,12 @@ __global__ void __launch_bounds__(256, 2) respair_x6_kernel(const FusedLaunch L,
 }
 
 bool respair_x6_supported(int C, int k, int dil) {
-  if (C != PX_C || k < 3 || k % 2 == 0 || dil < 1) return false;
+  if ((C != 32 && C != 64) || k < 3 || k % 2 == 0 || dil < 1) return false;
   return PX_HT + (k - 1) * dil <= PX_XR && PX_HT - (k - 1) >= PX_HT / 2;
 }
 
 int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
-  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1 || F.C != PX_C) return -1;
+  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1 || (F.C != 32 && F.C != 64)) return -1;
   if ((int64_t)F.C * F.L >= (1ll << 29)) return -1;               // 32-bit byte offsets inside a batch item
   int ntx = 0;
   for (int i = 0; i < F.nprob; ++i) {
@@ -280,10 +288,15 @@ int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
     ntx = n > ntx ? n : ntx;
   }
   const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
-  const size_t lds = (size_t)3 * PX_PLANE * 2;
+  const size_t lds = (size_t)3 * PX_XR * (F.C + 8) * 2;
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, F.B, F.nprob);
-  (void)hipFuncSetAttribute((const void*)respair_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(respair_x6_kernel, grid, dim3(256), lds, stream, F, per_xcd);
+  if (F.C == 32) {
+    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(respair_x6_kernel<32>, grid, dim3(256), lds, stream, F, per_xcd);
+  } else {
+    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(respair_x6_kernel<64>, grid, dim3(512), lds, stream, F, per_xcd);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -188,7 +188,7 @@ def test_generator_on_conv_x6_matches_the_fp32_mfma_generator():
 
 @pytest.mark.parametrize("B,Ty,lens", [(1, 384, [384]), (3, 97, [97, 60, 33]), (1, 5, [5])])
 def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
-    """kernels/respair_x6.hip (C = 32 fp32 stage: dilated conv -> LDS -> conv + residual in one launch, both convs on the bf16 matrix
+    """kernels/respair_x6.hip (C = 32 and C = 64 fp32 stages: dilated conv -> LDS -> conv + residual in one launch, both convs on the bf16 matrix
     core from three-way splits) against the two conv_x6 launches it replaces ("x6_pair" = 0): the same unit order and the same values
     at every step — the stage's three ResBlock outputs and the waveform bit for bit; exact lengths and the masked tail too."""
     from bert_vits2_amd import hparams as H, models, synth
@@ -203,10 +203,12 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
     up = 1
     for u in hp.upsample_rates[:4]:
         up *= u
+    up2 = up // hp.upsample_rates[3]
     res = {}
     for pair in (1, 0):
         m.set_option("x6_pair", pair)
         taps = {f"dec.rb.3.{j}": torch.full((B, 32, Ty * up), float("nan"), device="cuda") for j in range(3)}
+        taps.update({f"dec.rb.2.{j}": torch.full((B, 64, Ty * up2), float("nan"), device="cuda") for j in range(3)})   # C = 64: the 8-wave form
         for k, t in taps.items():
             m.set_tap(k, t)
         try:
@@ -218,7 +220,7 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
     m.set_option("x6_pair", 1)
     # a stage of <= 4096 columns runs its layer-wise convs on the split-K fp32-MFMA kernel (small-N regime), not on conv_x6: there the
     # two paths agree to fp32 round-off, not bit for bit
-    exact = B * Ty * up > 4096
+    exact = B * Ty * up2 > 4096
     for k in res[0][1]:
         a, b = res[1][1][k], res[0][1][k]
         assert torch.isfinite(a).all(), k
