@@ -48,7 +48,7 @@ CONFIGS = {
 }
 WN_FLOW_B32 = "f16"               # flow arithmetic of secondary.config3_residual_flow: the WN convolutions on the fp16 matrix core
 KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
-KERNEL_SOURCES = {"conv1d_x6": "conv_x6.hip", "conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
+KERNEL_SOURCES = {"conv1d_x6": "conv_x6.hip", "respair_x6": "respair_x6.hip", "conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
                   "conv_cl_bf16": "gen_bf16.hip", "respair_cl_bf16": "respair_cl_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "conv_f16": "enc_f16.hip",
                   "attention": "attention.hip"}
 
@@ -273,7 +273,7 @@ def roofline_block(prof, psteps, config=2):
         ach, peak, unit, bound = dom["bytes"] / secs / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
     tr = pmc_traffic(dom["name"], config)
     x6 = {}
-    if dom["name"].startswith("conv1d_x6") and bound == "mfma":
+    if (dom["name"].startswith("conv1d_x6") or dom["name"].startswith("respair_x6")) and bound == "mfma":
         # kernels/conv_x6.hip computes the fp32 conv with SIX bf16 MFMA products per multiply-add (exact three-way bf16 splits of both
         # operands): the roof that binds it is the bf16 matrix core, and what it must issue per launch is 6x the conv's FLOPs.
         # `achieved` / `frac` are in those issued bf16 FLOPs against the 2.5 PF bf16 peak; the fp32-equivalent rate (the conv's own
@@ -284,7 +284,8 @@ def roofline_block(prof, psteps, config=2):
                   frac_of_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                   measured_mfma_ceiling="tools/probe/mfma_bf16_probe.hip on this chip: 0.75-0.80 of 2.5 PF with operands in registers "
                                         "(clock drops to ~1.8 GHz under dense bf16 MFMA), 0.60-0.65 with this kernel's operand traffic "
-                                        "(profiles/r03_mfma_bf16_probe.txt)")
+                                        "(profiles/r03_mfma_bf16_probe.txt; round 4, full-range random operands: 0.68-0.73 in registers, "
+                                        "0.57-0.64 with this operand traffic, profiles/r04_mfma_bf16_probe.txt)")
         ach, peak = 6.0 * ach, PEAK_BF16_MFMA_TFLOPS
     return dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 4), **x6,
                 arithmetic_intensity_flop_per_byte=round(ai, 1), traffic=tr.get("bytes_per_launch"), traffic_detail=tr,

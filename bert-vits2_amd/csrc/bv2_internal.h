@@ -129,6 +129,7 @@ struct bv2_handle {
   bool no_respair_c32 = false;       // "respair_c32" = 0: the C = 32 bf16 stage as whole-ResBlock launches (resblock_cl_bf16.hip) instead of pair by pair
   int respair_form = 1;              // "respair_form": 1 = 64 x 128 wave tiles (respair2_cl_bf16_kernel), 0 = 32-channel waves
   bool respair_problem_major = false; // "respair_mix" = 0: the pair kernel's branches dispatched one after the other (A/B only)
+  bool x6_pair_c128 = false;         // "x6_pair_c128" = 1: the pair kernel also on the C = 128 stage (one 8-wave workgroup per CU; measured, see DESIGN)
   bool no_x6_pair_c64 = false;       // "x6_pair_c64" = 0: the pair kernel on the C = 32 stage only
   bool no_x6_pair = false;           // "x6_pair" = 0: the C = 32 fp32 stage as two conv_x6 launches per ResBlock pair instead of one respair_x6 launch
   bool no_fused_boundary = false;    // "fused_boundary" = 0: LayerNorm-2, post and the next pre of the transformer flow as three launches

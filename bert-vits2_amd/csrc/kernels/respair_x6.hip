@@ -46,25 +46,29 @@ __device__ __forceinline__ void px_split2(float a, float b, unsigned& u1, unsign
   u3 = px_pack(a, b);
 }
 
-constexpr int PX_HT = 256;                // columns of h per tile (4 waves x 64 along time)
-constexpr int PX_XR = 320;                // staged columns: 256 + (k-1)(d+1) <= 316
 constexpr int PX_UNIT = 3 * 512;          // elements of one (group, tap) unit: 3 planes x 64 lanes x 8
 
 }  // namespace
 
-// C = 32: 4 waves side by side in time, 77 KB, two workgroups per CU.  C = 64: 2 (row blocks) x 4 (time) waves, 138 KB, one 8-wave
-// workgroup per CU (two waves per SIMD).  Wave `wid` stages channel octet `wid` in both.
-template <int PX_C>
-__global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
-  constexpr int NI = 2, NRG = PX_XR / 64;
-  constexpr int PX_PITCH = PX_C + 8;              // bf16 elements per LDS row (80 / 144 B: odd multiples of 16 B)
+// Workgroup = (C / 32 row blocks) x (WNT 64-column blocks) waves; HT = 64 WNT columns of h per tile, XR = HT + 64 staged columns.
+//   C = 32 : 1 x 4 waves, HT 256,  77 KB, two workgroups per CU          C = 128: 4 x 2 waves, HT 128, 157 KB, one workgroup per CU
+//   C = 64 : 2 x 4 waves, HT 256, 138 KB, one workgroup per CU (two waves per SIMD)
+// The 16-channel groups run in passes of two (conv_x6's 32-channel chunks: the layer-wise kernel's fp32 summation order) through a
+// ring of 2 groups x 2 taps whose streams jump from one pass's groups to the next's — the registers do not grow with C.
+template <int PX_C, int WNT>
+__global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
+  constexpr int NI = 2, PX_HT = 64 * WNT, PX_XR = PX_HT + 64, NRG = PX_XR / 64;
+  constexpr int NW = PX_C / 32 * WNT;             // waves
+  constexpr int OPW = PX_C / 8 / NW;              // channel octets a wave stages per column group
+  static_assert(PX_C / 8 % NW == 0, "octets dealt evenly");
+  constexpr int PX_PITCH = PX_C + 8;              // bf16 elements per LDS row (80 / 144 / 272 B: odd multiples of 16 B)
   constexpr int PX_PLANE = PX_XR * PX_PITCH;
-  constexpr int PX_GR = PX_C / 16;                // 16-channel groups = ring slots
+  constexpr int NPASS = PX_C / 32;                // passes of two 16-channel groups
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]: x planes, then h planes
   const FusedProb P = L.p[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;          // 32-row block, 64-column block of this wave's tile
+  const int wm = wid / WNT, wn = wid % WNT;       // 32-row block, 64-column block of this wave's tile
   const int l31 = lane & 31, lh = lane >> 5;
   const int k = P.k, dil = P.dil;
   const int BT = PX_HT - (k - 1);
@@ -86,24 +90,29 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
   const unsigned x_rs4 = 4u * (unsigned)L.L;
   const unsigned wlane = 16u * (unsigned)lane;
 
-  // ---- weight ring (conv_x6.hip): two slots per 16-channel group, the stream of a group runs over its k taps
-  pxbf16x8 ar[PX_GR][2][3];
-  const uint16_t* wq[PX_GR];
-  auto load_unit = [&](int g, int SL, int step) __attribute__((always_inline)) {
+  // ---- weight ring (conv_x6.hip): ring group gl carries group 2 c + gl of pass c through its k taps (two slots: taps j, j + 1), then
+  // jumps to the next pass's group; k is odd, so pass c starts at slot parity c & 1
+  pxbf16x8 ar[2][2][3];
+  const uint16_t* wq[2];
+  auto load_unit = [&](int gl, int SL, int step) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      ar[g][SL][p] = *(const PxGlobalFrag*)(reinterpret_cast<const char*>(wq[g]) + wlane + 1024u * (unsigned)p);
-    wq[g] += step;
+      ar[gl][SL][p] = *(const PxGlobalFrag*)(reinterpret_cast<const char*>(wq[gl]) + wlane + 1024u * (unsigned)p);
+    wq[gl] += step;
   };
-  const int wrap_step = -((k - 1) * PX_UNIT);      // past a group's last tap: back to its first (valid memory, values unused)
+  const int last_step = (k + 1) * PX_UNIT;                            // from (g, k-1) to (g + 2, 0)
+  const int wrap_step = -(((NPASS - 1) * 2 * k + (k - 1)) * PX_UNIT); // from the last pass back to the first (valid memory, values unused)
+  auto step_after = [&](int jl, int cl) __attribute__((always_inline)) {
+    return jl + 1 < k ? PX_UNIT : (cl + 1 < NPASS ? last_step : wrap_step);
+  };
   auto prime = [&](const uint16_t* w6) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < PX_GR; ++g) wq[g] = w6 + (int64_t)(wm * PX_GR + g) * k * PX_UNIT;
+    for (int gl = 0; gl < 2; ++gl) wq[gl] = w6 + (int64_t)(wm * (PX_C / 16) + gl) * k * PX_UNIT;
+    const int s0 = step_after(0, 0), s1 = step_after(1, 0);          // k >= 3
 #pragma unroll
-    for (int g = 0; g < PX_GR; ++g) { load_unit(g, 0, PX_UNIT); __builtin_amdgcn_sched_barrier(0); }
-    const int s1 = 2 < k ? PX_UNIT : wrap_step;    // k >= 3
+    for (int gl = 0; gl < 2; ++gl) { load_unit(gl, 0, s0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-    for (int g = 0; g < PX_GR; ++g) { load_unit(g, 1, s1); __builtin_amdgcn_sched_barrier(0); }
+    for (int gl = 0; gl < 2; ++gl) { load_unit(gl, 1, s1); __builtin_amdgcn_sched_barrier(0); }
   };
   prime(P.w61);
 
@@ -111,7 +120,7 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
   {
     const int tbase = t0 - p2 - p1;
     const int XW = PX_HT + (k - 1) * dil;
-    float xr[NRG][8];
+    float xr[NRG][OPW][8];
     float colsc[NRG];
 #pragma unroll
     for (int rg = 0; rg < NRG; ++rg) {
@@ -120,29 +129,34 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
       const bool tok = r < XW && t >= 0 && t < Lin;
       colsc[rg] = tok ? 1.f : 0.f;
       const unsigned tc = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
-      const unsigned row0 = (unsigned)(wid * 8) * x_rs4;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xr[rg][e] = px_ld(x0p, row0 + (unsigned)e * x_rs4 + tc);
-    }
+      for (int o = 0; o < OPW; ++o) {
+        const unsigned row0 = (unsigned)((wid + NW * o) * 8) * x_rs4;
 #pragma unroll
-    for (int rg = 0; rg < NRG; ++rg) {
-      pxu32x4 q1, q2, q3;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        float a = xr[rg][2 * w], bq = xr[rg][2 * w + 1];
-        const float an = a * slope, bn = bq * slope;
-        a = a < 0.f ? an : a;
-        bq = bq < 0.f ? bn : bq;
-        a *= colsc[rg]; bq *= colsc[rg];
-        unsigned u1, u2, u3;
-        px_split2(a, bq, u1, u2, u3);
-        q1[w] = u1; q2[w] = u2; q3[w] = u3;
+        for (int e = 0; e < 8; ++e) xr[rg][o][e] = px_ld(x0p, row0 + (unsigned)e * x_rs4 + tc);
       }
-      unsigned short* dst = xs + (rg * 64 + lane) * PX_PITCH + wid * 8;
-      *reinterpret_cast<pxu32x4*>(dst) = q1;
-      *reinterpret_cast<pxu32x4*>(dst + PX_PLANE) = q2;
-      *reinterpret_cast<pxu32x4*>(dst + 2 * PX_PLANE) = q3;
     }
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg)
+#pragma unroll
+      for (int o = 0; o < OPW; ++o) {
+        pxu32x4 q1, q2, q3;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float a = xr[rg][o][2 * w], bq = xr[rg][o][2 * w + 1];
+          const float an = a * slope, bn = bq * slope;
+          a = a < 0.f ? an : a;
+          bq = bq < 0.f ? bn : bq;
+          a *= colsc[rg]; bq *= colsc[rg];
+          unsigned u1, u2, u3;
+          px_split2(a, bq, u1, u2, u3);
+          q1[w] = u1; q2[w] = u2; q3[w] = u3;
+        }
+        unsigned short* dst = xs + (rg * 64 + lane) * PX_PITCH + (wid + NW * o) * 8;
+        *reinterpret_cast<pxu32x4*>(dst) = q1;
+        *reinterpret_cast<pxu32x4*>(dst + PX_PLANE) = q2;
+        *reinterpret_cast<pxu32x4*>(dst + 2 * PX_PLANE) = q3;
+      }
   }
   __syncthreads();
 
@@ -153,12 +167,10 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
   const unsigned short* const xlane = xs + (wn * 64 + l31) * PX_PITCH + lh * 8;
 
-  // one GEMM over the tile in LDS: acc[ni] += sum over (pass c, tap j, group g of the pass) of the six cross products (conv_x6.hip's
-  // unit).  The groups run in passes of two — conv_x6's 32-channel chunks — so that the fp32 sums see the layer-wise kernel's order.
+  // one GEMM over the tile in LDS: acc[ni] += sum over (pass c, tap j, group gl of the pass) of the six cross products (conv_x6.hip's unit)
   auto gemm = [&](int tap_step) __attribute__((always_inline)) {
     pxbf16x8 bb[2][NI][3];
-#pragma unroll
-    for (int c = 0; c < PX_GR / 2; ++c) {
+    auto pass = [&](int c, int PAR) __attribute__((always_inline)) {              // PAR: a literal at every (inlined) call site
       const unsigned short* xrow = xlane + c * 32;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -166,11 +178,12 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
         for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const pxbf16x8*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
       auto tap = [&](int j, int SL) __attribute__((always_inline)) {
         const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;
-        const int jl = j + 2;                       // the unit loaded during this tap
-        const int step = jl + 1 < k ? PX_UNIT : (jl < k ? wrap_step : (jl == k ? PX_UNIT : wrap_step));
+        int jl = j + 2, cl = c;                     // the unit loaded during this tap: tap jl of pass cl (branch-free wrap)
+        if (jl >= k) { jl -= k; ++cl; }
+        if (cl >= NPASS) cl -= NPASS;
+        const int step = step_after(jl, cl);
 #pragma unroll
         for (int gl = 0; gl < 2; ++gl) {
-          const int g = 2 * c + gl;
           {
             const unsigned short* xn = (gl == 0) ? xrow + 16 : xnext;
 #pragma unroll
@@ -181,10 +194,10 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
           }
 #define PX_PROD(WP, XP)                                                                                              \
           _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                          \
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][SL][WP], bb[gl][ni][XP], acc[ni], 0, 0, 0);
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[gl][SL][WP], bb[gl][ni][XP], acc[ni], 0, 0, 0);
           PX_PROD(2, 0) PX_PROD(1, 1) PX_PROD(0, 2) PX_PROD(1, 0) PX_PROD(0, 1) PX_PROD(0, 0)
 #undef PX_PROD
-          load_unit(g, SL, step);
+          load_unit(gl, SL, step);
           constexpr int NM = NI * 6, NDS = NI * 3, NVM = 3;
 #pragma unroll
           for (int q = 0; q < NDS; ++q) {
@@ -201,9 +214,12 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
         }
         xrow = xnext;
       };
-      for (int j = 0; j + 1 < k; j += 2) { tap(j, 0); tap(j + 1, 1); }
-      tap(k - 1, 0);
-    }
+      for (int j = 0; j + 1 < k; j += 2) { tap(j, PAR); tap(j + 1, PAR ^ 1); }
+      tap(k - 1, PAR);
+    };
+    int c = 0;
+    for (; c + 1 < NPASS; c += 2) { pass(c, 0); pass(c + 1, 1); }
+    if (c < NPASS) pass(c, 0);
   };
   gemm(dil * PX_PITCH);
 
@@ -272,30 +288,35 @@ __global__ void __launch_bounds__(PX_C * 8, PX_C == 32 ? 2 : 1) respair_x6_kerne
 }
 
 bool respair_x6_supported(int C, int k, int dil) {
-  if ((C != 32 && C != 64) || k < 3 || k % 2 == 0 || dil < 1) return false;
-  return PX_HT + (k - 1) * dil <= PX_XR && PX_HT - (k - 1) >= PX_HT / 2;
+  if ((C != 32 && C != 64 && C != 128) || k < 3 || k % 2 == 0 || dil < 1) return false;
+  const int HT = C == 128 ? 128 : 256;
+  return (k - 1) * dil <= 64 && HT - (k - 1) >= HT / 2;
 }
 
 int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
-  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1 || (F.C != 32 && F.C != 64)) return -1;
+  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1 || (F.C != 32 && F.C != 64 && F.C != 128)) return -1;
+  const int HT = F.C == 128 ? 128 : 256;
   if ((int64_t)F.C * F.L >= (1ll << 29)) return -1;               // 32-bit byte offsets inside a batch item
   int ntx = 0;
   for (int i = 0; i < F.nprob; ++i) {
     const FusedProb& p = F.p[i];
     if (!respair_x6_supported(F.C, p.k, p.dil) || !p.x || !p.out || p.x == p.out || !p.w61 || !p.w62 || !p.b1 || !p.b2) return -1;
-    const int BT = PX_HT - (p.k - 1);
+    const int BT = HT - (p.k - 1);
     const int n = (F.L + BT - 1) / BT;
     ntx = n > ntx ? n : ntx;
   }
   const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
-  const size_t lds = (size_t)3 * PX_XR * (F.C + 8) * 2;
+  const size_t lds = (size_t)3 * (HT + 64) * (F.C + 8) * 2;
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, F.B, F.nprob);
   if (F.C == 32) {
-    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(respair_x6_kernel<32>, grid, dim3(256), lds, stream, F, per_xcd);
+    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((respair_x6_kernel<32, 4>), grid, dim3(256), lds, stream, F, per_xcd);
+  } else if (F.C == 64) {
+    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((respair_x6_kernel<64, 4>), grid, dim3(512), lds, stream, F, per_xcd);
   } else {
-    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(respair_x6_kernel<64>, grid, dim3(512), lds, stream, F, per_xcd);
+    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((respair_x6_kernel<128, 2>), grid, dim3(512), lds, stream, F, per_xcd);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

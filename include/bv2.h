@@ -259,6 +259,9 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
+ *   "x6_pair"         fp32 mode, the C = 32 and C = 64 Generator stages one (dilated conv, conv) ResBlock pair per launch with both convs on
+ *                     the bf16 matrix core and the intermediate planes in LDS (kernels/respair_x6.hip; bit-identical to the two conv_x6
+ *                     launches); 0: two launches per pair.  "x6_pair_c64" = 0: C = 32 only; "x6_pair_c128" = 1: also C = 128 (no gain)
  *   "fused_boundary"  transformer flow, small-batch fp32 regime: LayerNorm-2 of a coupling's last Encoder layer, its `post` and the next
  *                     coupling's `pre` in one launch (kernels/flow_boundary.hip); 0: three launches
  *   "fused_attn_o"    MultiHeadAttention.conv_o inside the attention kernel in the small-batch fp32 regime: head h writes partial

@@ -204,11 +204,14 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
     for u in hp.upsample_rates[:4]:
         up *= u
     up2 = up // hp.upsample_rates[3]
+    up1 = up2 // hp.upsample_rates[2]
     res = {}
     for pair in (1, 0):
         m.set_option("x6_pair", pair)
+        m.set_option("x6_pair_c128", pair)                   # the C = 128 form (4 x 2 waves; an option, not the default)
         taps = {f"dec.rb.3.{j}": torch.full((B, 32, Ty * up), float("nan"), device="cuda") for j in range(3)}
         taps.update({f"dec.rb.2.{j}": torch.full((B, 64, Ty * up2), float("nan"), device="cuda") for j in range(3)})   # C = 64: the 8-wave form
+        taps.update({f"dec.rb.1.{j}": torch.full((B, 128, Ty * up1), float("nan"), device="cuda") for j in range(3)})
         for k, t in taps.items():
             m.set_tap(k, t)
         try:
@@ -218,9 +221,10 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
             m.set_tap(None)
         res[pair] = (o, taps)
     m.set_option("x6_pair", 1)
+    m.set_option("x6_pair_c128", 0)
     # a stage of <= 4096 columns runs its layer-wise convs on the split-K fp32-MFMA kernel (small-N regime), not on conv_x6: there the
     # two paths agree to fp32 round-off, not bit for bit
-    exact = B * Ty * up2 > 4096
+    exact = B * Ty * up1 > 4096
     for k in res[0][1]:
         a, b = res[1][1][k], res[0][1][k]
         assert torch.isfinite(a).all(), k

@@ -24,6 +24,8 @@ def family(kname):
     if "conv1d_x6_kernel<" in kname:            # <WM, WN, MI, NI, CK, XR> -> the name bench.py / launch_conv1d_x6 report
         a = [int(v) for v in kname.split("conv1d_x6_kernel<")[1].split(">")[0].split(",")]
         return f"conv1d_x6<{a[0] * a[2] * 32}x{a[1] * a[3] * 32}{',ld' if len(a) > 6 and a[6] > 0 else ''}>"
+    if "respair_x6_kernel<" in kname:           # <C, WNT> -> the name bv2_exec.cpp reports
+        return f"respair_x6<{int(kname.split('respair_x6_kernel<')[1].split(',')[0])}>"
     if "conv1d_splitk_kernel" in kname:
         return "conv1d_splitk<32x32>"
     if "conv_cl_bf16_kernel" in kname:
