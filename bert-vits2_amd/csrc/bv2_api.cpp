@@ -402,6 +402,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "fused_boundary") h->no_fused_boundary = value == 0;
   else if (k == "x6_pair") h->no_x6_pair = value == 0;
   else if (k == "x6_pair_c64") h->no_x6_pair_c64 = value == 0;
+  else if (k == "x6_pair_c16") h->no_x6_pair_c16 = value == 0;
   else if (k == "x6_pair_c128") h->x6_pair_c128 = value != 0;
   else if (k == "respair_mix") h->respair_problem_major = value == 0;
   else if (k == "respair_form") h->respair_form = value;

@@ -831,7 +831,8 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     // C = 32: two split-bf16 launches per pair (HBM-bound, 5 tensor passes) against one fused fp32-MFMA launch (MFMA-bound, 3 passes)
     // C = 32 with the planes packed: the pair in ONE launch on the bf16 matrix core (respair_x6.hip: two passes AND the fast pipe)
     bool x6pair = nb <= 3 && !c.h->no_fused_resblock && !c.h->no_conv_x6 && !c.h->no_x6_pair &&
-                  (U.cout == 32 || (U.cout == 64 && !c.h->no_x6_pair_c64) || (U.cout == 128 && c.h->x6_pair_c128));
+                  (U.cout == 32 || (U.cout == 16 && !c.h->no_x6_pair_c16) || (U.cout == 64 && !c.h->no_x6_pair_c64) ||
+                   (U.cout == 128 && c.h->x6_pair_c128));
     for (int j = 0; j < nb && x6pair; ++j)
       for (int d = 0; d < m.n_rbd && x6pair; ++d)
         x6pair = m.rb[i][j][d][0].wx_off >= 0 && m.rb[i][j][d][1].wx_off >= 0 && m.rb[i][j][d][0].k == m.rb[i][j][d][1].k &&
@@ -873,7 +874,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
             c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
                           std::to_string(Lo) + " B" + std::to_string(B);
           const int r = x6pair ? launch_respair_x6(c.s, F) : launch_resblock_fused(c.s, F);
-          c.prof_end(pi, x6pair ? (U.cout == 32 ? "respair_x6<32>" : (U.cout == 64 ? "respair_x6<64>" : "respair_x6<128>")) : "resblock_fused", resblock_fused_flops(F), resblock_fused_bytes(F));
+          c.prof_end(pi, x6pair ? (U.cout == 16 ? "respair_x6<16>" : U.cout == 32 ? "respair_x6<32>" : (U.cout == 64 ? "respair_x6<64>" : "respair_x6<128>")) : "resblock_fused", resblock_fused_flops(F), resblock_fused_bytes(F));
           if (r) c.fail("dec.resblock.fused", r);
         }
       }

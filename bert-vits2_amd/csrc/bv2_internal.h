@@ -130,6 +130,7 @@ struct bv2_handle {
   int respair_form = 1;              // "respair_form": 1 = 64 x 128 wave tiles (respair2_cl_bf16_kernel), 0 = 32-channel waves
   bool respair_problem_major = false; // "respair_mix" = 0: the pair kernel's branches dispatched one after the other (A/B only)
   bool x6_pair_c128 = false;         // "x6_pair_c128" = 1: the pair kernel also on the C = 128 stage (one 8-wave workgroup per CU; measured, see DESIGN)
+  bool no_x6_pair_c16 = false;       // "x6_pair_c16" = 0: the C = 16 stage on the fused fp32-MFMA pair kernel (resblock_fused.hip)
   bool no_x6_pair_c64 = false;       // "x6_pair_c64" = 0: the pair kernel on the C = 32 stage only
   bool no_x6_pair = false;           // "x6_pair" = 0: the C = 32 fp32 stage as two conv_x6 launches per ResBlock pair instead of one respair_x6 launch
   bool no_fused_boundary = false;    // "fused_boundary" = 0: LayerNorm-2, post and the next pre of the transformer flow as three launches

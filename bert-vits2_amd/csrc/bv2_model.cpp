@@ -122,7 +122,7 @@ struct Packer {
     c.b_off = bias ? alloc(c.cout_pad) : -1;
     if (emit_bf16 && cin % 16 == 0) c.wb_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (emit_f16 && cin % 16 == 0) c.wh_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
-    if (emit_x6 && cin % 32 == 0) c.wx_off = alloc((x6_w_elems(cin, c.cout_pad, k) + 1) / 2);
+    if (emit_x6 && cin % 16 == 0) c.wx_off = alloc((x6_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (fill() && ok) {
       for (int j = 0; j < k; ++j)
         for (int ci = 0; ci < cin; ++ci)
@@ -432,7 +432,7 @@ int pack_all(Model& m, Packer& P) {
       const int k = c.resblock_kernel_sizes[j];
       const std::string rp = "dec.resblocks." + std::to_string(i * m.n_rbk + j);
       // wide stages (the ones the LDS-tiled fp32 conv runs): the weights also as the three bf16 planes of conv_x6.hip
-      P.emit_x6 = ch >= 32 && ch % 32 == 0;
+      P.emit_x6 = ch >= 16 && ch % 16 == 0;        // C = 16: the pair kernel only (respair_x6.hip; conv_x6.hip wants whole 32-channel chunks)
       for (int d = 0; d < m.n_rbd; ++d) {
         m.rb[i][j][d][0] = P.conv1d(rp + ".convs1." + std::to_string(d), ch, ch, k, true, true);
         m.rb[i][j][d][1] = P.conv1d(rp + ".convs2." + std::to_string(d), ch, ch, k, true, true);

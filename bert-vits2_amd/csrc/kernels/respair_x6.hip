@@ -55,15 +55,23 @@ constexpr int PX_UNIT = 3 * 512;          // elements of one (group, tap) unit: 
 //   C = 64 : 2 x 4 waves, HT 256, 138 KB, one workgroup per CU (two waves per SIMD)
 // The 16-channel groups run in passes of two (conv_x6's 32-channel chunks: the layer-wise kernel's fp32 summation order) through a
 // ring of 2 groups x 2 taps whose streams jump from one pass's groups to the next's — the registers do not grow with C.
+//   C = 16 : 1 x 4 waves, HT 256,  46 KB, three per CU: ONE 16-channel group (passes of one), the upper half of the 32-row block is padding
 template <int PX_C, int WNT>
-__global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
+__global__ void __launch_bounds__((PX_C >= 32 ? PX_C / 32 : 1) * WNT * 64, PX_C <= 32 ? 2 : 1)
+respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
   constexpr int NI = 2, PX_HT = 64 * WNT, PX_XR = PX_HT + 64, NRG = PX_XR / 64;
-  constexpr int NW = PX_C / 32 * WNT;             // waves
-  constexpr int OPW = PX_C / 8 / NW;              // channel octets a wave stages per column group
-  static_assert(PX_C / 8 % NW == 0, "octets dealt evenly");
-  constexpr int PX_PITCH = PX_C + 8;              // bf16 elements per LDS row (80 / 144 / 272 B: odd multiples of 16 B)
+  constexpr int MB = PX_C >= 32 ? PX_C / 32 : 1;  // 32-row blocks
+  constexpr int NW = MB * WNT;                    // waves
+  constexpr int OCT = PX_C / 8;                   // channel octets
+  constexpr int OPW = OCT >= NW ? OCT / NW : 1;   // octets a wave stages per column group ...
+  constexpr int CGS = OCT >= NW ? 1 : NW / OCT;   // ... of every CGS-th column group (C = 16: two waves share an octet's column groups)
+  constexpr int NRGW = (NRG + CGS - 1) / CGS;     // column groups per wave
+  static_assert(OCT >= NW ? OCT % NW == 0 : NW % OCT == 0, "octets dealt evenly");
+  constexpr int PX_PITCH = PX_C + 8;              // bf16 elements per LDS row (48 / 80 / 144 / 272 B: odd multiples of 16 B)
   constexpr int PX_PLANE = PX_XR * PX_PITCH;
-  constexpr int NPASS = PX_C / 32;                // passes of two 16-channel groups
+  constexpr int GPP = PX_C >= 32 ? 2 : 1;         // 16-channel groups per pass
+  constexpr int NPASS = PX_C / 16 / GPP;          // passes
+  constexpr int NJ = PX_C >= 32 ? 4 : PX_C / 8;   // 8-channel sub-blocks of a row block that exist
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]: x planes, then h planes
   const FusedProb P = L.p[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,27 +100,27 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
 
   // ---- weight ring (conv_x6.hip): ring group gl carries group 2 c + gl of pass c through its k taps (two slots: taps j, j + 1), then
   // jumps to the next pass's group; k is odd, so pass c starts at slot parity c & 1
-  pxbf16x8 ar[2][2][3];
-  const uint16_t* wq[2];
+  pxbf16x8 ar[GPP][2][3];
+  const uint16_t* wq[GPP];
   auto load_unit = [&](int gl, int SL, int step) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       ar[gl][SL][p] = *(const PxGlobalFrag*)(reinterpret_cast<const char*>(wq[gl]) + wlane + 1024u * (unsigned)p);
     wq[gl] += step;
   };
-  const int last_step = (k + 1) * PX_UNIT;                            // from (g, k-1) to (g + 2, 0)
-  const int wrap_step = -(((NPASS - 1) * 2 * k + (k - 1)) * PX_UNIT); // from the last pass back to the first (valid memory, values unused)
+  const int last_step = ((GPP - 1) * k + 1) * PX_UNIT;                  // from (g, k-1) to (g + GPP, 0)
+  const int wrap_step = -(((NPASS - 1) * GPP * k + (k - 1)) * PX_UNIT); // from the last pass back to the first (valid memory, values unused)
   auto step_after = [&](int jl, int cl) __attribute__((always_inline)) {
     return jl + 1 < k ? PX_UNIT : (cl + 1 < NPASS ? last_step : wrap_step);
   };
   auto prime = [&](const uint16_t* w6) __attribute__((always_inline)) {
 #pragma unroll
-    for (int gl = 0; gl < 2; ++gl) wq[gl] = w6 + (int64_t)(wm * (PX_C / 16) + gl) * k * PX_UNIT;
+    for (int gl = 0; gl < GPP; ++gl) wq[gl] = w6 + (int64_t)(wm * (PX_C / 16) + gl) * k * PX_UNIT;
     const int s0 = step_after(0, 0), s1 = step_after(1, 0);          // k >= 3
 #pragma unroll
-    for (int gl = 0; gl < 2; ++gl) { load_unit(gl, 0, s0); __builtin_amdgcn_sched_barrier(0); }
+    for (int gl = 0; gl < GPP; ++gl) { load_unit(gl, 0, s0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-    for (int gl = 0; gl < 2; ++gl) { load_unit(gl, 1, s1); __builtin_amdgcn_sched_barrier(0); }
+    for (int gl = 0; gl < GPP; ++gl) { load_unit(gl, 1, s1); __builtin_amdgcn_sched_barrier(0); }
   };
   prime(P.w61);
 
@@ -120,43 +128,50 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
   {
     const int tbase = t0 - p2 - p1;
     const int XW = PX_HT + (k - 1) * dil;
-    float xr[NRG][OPW][8];
-    float colsc[NRG];
+    float xr[NRGW][OPW][8];
+    float colsc[NRGW];
+    const int rg0 = OCT >= NW ? 0 : wid / OCT;    // this wave's first column group
+    const int oct0 = OCT >= NW ? wid : wid % OCT; // ... and first octet
 #pragma unroll
-    for (int rg = 0; rg < NRG; ++rg) {
+    for (int i = 0; i < NRGW; ++i) {
+      const int rg = rg0 + CGS * i;
       const int r = rg * 64 + lane;
       const int t = tbase + r;
       const bool tok = r < XW && t >= 0 && t < Lin;
-      colsc[rg] = tok ? 1.f : 0.f;
+      colsc[i] = tok ? 1.f : 0.f;
       const unsigned tc = 4u * (unsigned)(t < 0 ? 0 : (t >= Lin ? Lin - 1 : t));
 #pragma unroll
       for (int o = 0; o < OPW; ++o) {
-        const unsigned row0 = (unsigned)((wid + NW * o) * 8) * x_rs4;
+        const unsigned row0 = (unsigned)((oct0 + NW * o) * 8) * x_rs4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xr[rg][o][e] = px_ld(x0p, row0 + (unsigned)e * x_rs4 + tc);
+        for (int e = 0; e < 8; ++e) xr[i][o][e] = px_ld(x0p, row0 + (unsigned)e * x_rs4 + tc);
       }
     }
 #pragma unroll
-    for (int rg = 0; rg < NRG; ++rg)
+    for (int i = 0; i < NRGW; ++i) {
+      const int rg = rg0 + CGS * i;
 #pragma unroll
       for (int o = 0; o < OPW; ++o) {
         pxu32x4 q1, q2, q3;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          float a = xr[rg][o][2 * w], bq = xr[rg][o][2 * w + 1];
+          float a = xr[i][o][2 * w], bq = xr[i][o][2 * w + 1];
           const float an = a * slope, bn = bq * slope;
           a = a < 0.f ? an : a;
           bq = bq < 0.f ? bn : bq;
-          a *= colsc[rg]; bq *= colsc[rg];
+          a *= colsc[i]; bq *= colsc[i];
           unsigned u1, u2, u3;
           px_split2(a, bq, u1, u2, u3);
           q1[w] = u1; q2[w] = u2; q3[w] = u3;
         }
-        unsigned short* dst = xs + (rg * 64 + lane) * PX_PITCH + (wid + NW * o) * 8;
-        *reinterpret_cast<pxu32x4*>(dst) = q1;
-        *reinterpret_cast<pxu32x4*>(dst + PX_PLANE) = q2;
-        *reinterpret_cast<pxu32x4*>(dst + 2 * PX_PLANE) = q3;
+        if (CGS == 1 || rg < NRG) {
+          unsigned short* dst = xs + (rg * 64 + lane) * PX_PITCH + (oct0 + NW * o) * 8;
+          *reinterpret_cast<pxu32x4*>(dst) = q1;
+          *reinterpret_cast<pxu32x4*>(dst + PX_PLANE) = q2;
+          *reinterpret_cast<pxu32x4*>(dst + 2 * PX_PLANE) = q3;
+        }
       }
+    }
   }
   __syncthreads();
 
@@ -171,11 +186,13 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
   auto gemm = [&](int tap_step) __attribute__((always_inline)) {
     pxbf16x8 bb[2][NI][3];
     auto pass = [&](int c, int PAR) __attribute__((always_inline)) {              // PAR: a literal at every (inlined) call site
-      const unsigned short* xrow = xlane + c * 32;
+      const unsigned short* xrow = xlane + c * (16 * GPP);
+      // B double buffer: alternates with the group inside a tap (two groups per pass) or with the tap's ring slot (one group per pass)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const pxbf16x8*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
+        for (int p = 0; p < 3; ++p)
+          bb[GPP == 2 ? 0 : PAR][ni][p] = *reinterpret_cast<const pxbf16x8*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
       auto tap = [&](int j, int SL) __attribute__((always_inline)) {
         const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;
         int jl = j + 2, cl = c;                     // the unit loaded during this tap: tap jl of pass cl (branch-free wrap)
@@ -183,18 +200,19 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
         if (cl >= NPASS) cl -= NPASS;
         const int step = step_after(jl, cl);
 #pragma unroll
-        for (int gl = 0; gl < 2; ++gl) {
+        for (int gl = 0; gl < GPP; ++gl) {
+          const int cur = GPP == 2 ? gl : SL;
           {
-            const unsigned short* xn = (gl == 0) ? xrow + 16 : xnext;
+            const unsigned short* xn = (gl + 1 < GPP) ? xrow + 16 : xnext;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
               for (int p = 0; p < 3; ++p)
-                bb[gl ^ 1][ni][p] = *reinterpret_cast<const pxbf16x8*>(xn + ni * 32 * PX_PITCH + p * PX_PLANE);
+                bb[cur ^ 1][ni][p] = *reinterpret_cast<const pxbf16x8*>(xn + ni * 32 * PX_PITCH + p * PX_PLANE);
           }
 #define PX_PROD(WP, XP)                                                                                              \
           _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                          \
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[gl][SL][WP], bb[gl][ni][XP], acc[ni], 0, 0, 0);
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[gl][SL][WP], bb[cur][ni][XP], acc[ni], 0, 0, 0);
           PX_PROD(2, 0) PX_PROD(1, 1) PX_PROD(0, 2) PX_PROD(1, 0) PX_PROD(0, 1) PX_PROD(0, 0)
 #undef PX_PROD
           load_unit(gl, SL, step);
@@ -236,7 +254,7 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
     const float ok = (th >= 0 && th < Lin) ? 1.f : 0.f;
     unsigned short* dst = xs + hc * PX_PITCH + wm * 32 + 4 * lh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                 // channels 8 j + 4 lh + {0, 1, 2, 3} = registers 4 j .. 4 j + 3
+    for (int j = 0; j < NJ; ++j) {                // channels 8 j + 4 lh + {0, 1, 2, 3} = registers 4 j .. 4 j + 3
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -244,7 +262,6 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
         const float tn = t * slope;
         t = t < 0.f ? tn : t;
         v[i] = t * ok;
-        acc[ni][4 * j + i] = 0.f;
       }
       unsigned a1, a2, a3, c1, c2, c3;
       px_split2(v[0], v[1], a1, a2, a3);
@@ -254,6 +271,10 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
       *reinterpret_cast<pxu32x2*>(dst + 8 * j + 2 * PX_PLANE) = pxu32x2{a3, c3};
     }
   }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
   // the epilogue's operands: in flight under conv2
   float b2v[16];
 #pragma unroll
@@ -275,12 +296,12 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
       const int t = t0 + (colok[ni] ? oc : 0);
       off0[ni] = (unsigned)(wm * 32 + 4 * lh) * (unsigned)L.L + (unsigned)t;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rv[ni][r] = px_ld(x0p, 4u * (off0[ni] + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L.L));
+      for (int r = 0; r < 4 * NJ; ++r) rv[ni][r] = px_ld(x0p, 4u * (off0[ni] + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L.L));
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 4 * NJ; ++r) {           // rows (r & 3) + 8 (r >> 2) + 4 lh < C
         const float v = (acc[ni][r] + b2v[r]) + rv[ni][r];
         if (colok[ni]) outb[off0[ni] + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L.L] = v;
       }
@@ -288,13 +309,13 @@ __global__ void __launch_bounds__(PX_C * 2 * WNT, PX_C == 32 ? 2 : 1) respair_x6
 }
 
 bool respair_x6_supported(int C, int k, int dil) {
-  if ((C != 32 && C != 64 && C != 128) || k < 3 || k % 2 == 0 || dil < 1) return false;
+  if ((C != 16 && C != 32 && C != 64 && C != 128) || k < 3 || k % 2 == 0 || dil < 1) return false;
   const int HT = C == 128 ? 128 : 256;
   return (k - 1) * dil <= 64 && HT - (k - 1) >= HT / 2;
 }
 
 int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
-  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1 || (F.C != 32 && F.C != 64 && F.C != 128)) return -1;
+  if (F.nprob < 1 || F.nprob > 3 || F.B < 1 || F.L < 1 || (F.C != 16 && F.C != 32 && F.C != 64 && F.C != 128)) return -1;
   const int HT = F.C == 128 ? 128 : 256;
   if ((int64_t)F.C * F.L >= (1ll << 29)) return -1;               // 32-bit byte offsets inside a batch item
   int ntx = 0;
@@ -308,7 +329,10 @@ int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
   const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
   const size_t lds = (size_t)3 * (HT + 64) * (F.C + 8) * 2;
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, F.B, F.nprob);
-  if (F.C == 32) {
+  if (F.C == 16) {
+    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((respair_x6_kernel<16, 4>), grid, dim3(256), lds, stream, F, per_xcd);
+  } else if (F.C == 32) {
     (void)hipFuncSetAttribute((const void*)respair_x6_kernel<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((respair_x6_kernel<32, 4>), grid, dim3(256), lds, stream, F, per_xcd);
   } else if (F.C == 64) {

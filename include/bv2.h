@@ -30,7 +30,7 @@ extern "C" {
 
 #define BV2_ABI_VERSION 3   /* 3: bv2_decode_in.nz_tstride, the six ONNX-seam stage calls, bv2_detach_weights,
                                pack-layout version in the blob header */
-#define BV2_PACK_LAYOUT 10   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
+#define BV2_PACK_LAYOUT 11   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
                                a blob cached on disk by an older packer is rejected by bv2_attach_weights */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
@@ -259,9 +259,10 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
- *   "x6_pair"         fp32 mode, the C = 32 and C = 64 Generator stages one (dilated conv, conv) ResBlock pair per launch with both convs on
+ *   "x6_pair"         fp32 mode, the C = 64 / 32 / 16 Generator stages one (dilated conv, conv) ResBlock pair per launch with both convs on
  *                     the bf16 matrix core and the intermediate planes in LDS (kernels/respair_x6.hip; bit-identical to the two conv_x6
- *                     launches); 0: two launches per pair.  "x6_pair_c64" = 0: C = 32 only; "x6_pair_c128" = 1: also C = 128 (no gain)
+ *                     launches); 0: two launches per pair.  "x6_pair_c64" / "x6_pair_c16" = 0: without that stage (C = 16: back on
+ *                     resblock_fused.hip); "x6_pair_c128" = 1: also C = 128 (no gain)
  *   "fused_boundary"  transformer flow, small-batch fp32 regime: LayerNorm-2 of a coupling's last Encoder layer, its `post` and the next
  *                     coupling's `pre` in one launch (kernels/flow_boundary.hip); 0: three launches
  *   "fused_attn_o"    MultiHeadAttention.conv_o inside the attention kernel in the small-batch fp32 regime: head h writes partial

@@ -206,6 +206,7 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
     up2 = up // hp.upsample_rates[3]
     up1 = up2 // hp.upsample_rates[2]
     res = {}
+    m.set_option("x6_pair_c16", 0)                           # the C = 16 stage has no layer-wise x6 form to be identical to: own test below
     for pair in (1, 0):
         m.set_option("x6_pair", pair)
         m.set_option("x6_pair_c128", pair)                   # the C = 128 form (4 x 2 waves; an option, not the default)
@@ -222,6 +223,7 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
         res[pair] = (o, taps)
     m.set_option("x6_pair", 1)
     m.set_option("x6_pair_c128", 0)
+    m.set_option("x6_pair_c16", 1)
     # a stage of <= 4096 columns runs its layer-wise convs on the split-K fp32-MFMA kernel (small-N regime), not on conv_x6: there the
     # two paths agree to fp32 round-off, not bit for bit
     exact = B * Ty * up1 > 4096
@@ -236,3 +238,43 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
         assert torch.equal(res[1][0], res[0][0])
     else:
         assert (res[1][0] - res[0][0]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("B,Ty,lens", [(1, 384, [384]), (2, 50, [50, 21])])
+def test_x6_pair_kernel_on_the_c16_stage_matches_the_fp32_mfma_pair_kernel(B, Ty, lens):
+    """C = 16 (the last stage: 512 samples per latent frame): respair_x6.hip with ONE 16-channel group — the upper half of the 32-row
+    MFMA block is zero padding — against resblock_fused.hip (fp32 matrix core, the round-1 kernel of that stage).  Different matrix
+    cores, the same fp32 arithmetic: the stage's outputs and the waveform agree to fp32 round-off."""
+    from bert_vits2_amd import hparams as H, models, synth
+    hp = H.default_v23()
+    m = models.from_hparams(hp)
+    m.load_state_dict(synth.synthetic_state_dict(hp, seed=0, pin_durations=2.5), strict=False)
+    m = m.to("cuda").eval()
+    g = torch.Generator().manual_seed(B * 7 + Ty)
+    z = torch.randn(B, hp.inter_channels, Ty, generator=g).cuda()
+    yl = torch.tensor(lens, dtype=torch.int64).cuda()
+    gv = torch.randn(B, hp.gin_channels, generator=g).cuda()
+    up = 1
+    for u in hp.upsample_rates:
+        up *= u
+    res = {}
+    for c16 in (1, 0):
+        m.set_option("x6_pair_c16", c16)
+        taps = {f"dec.rb.4.{j}": torch.full((B, 16, Ty * up), float("nan"), device="cuda") for j in range(3)}
+        for k, t in taps.items():
+            m.set_tap(k, t)
+        try:
+            o = m.stage_generator(z, yl, gv)
+            torch.cuda.synchronize()
+        finally:
+            m.set_tap(None)
+        res[c16] = (o, taps)
+    m.set_option("x6_pair_c16", 1)
+    for k in res[0][1]:
+        a, b = res[1][1][k].double(), res[0][1][k].double()
+        assert torch.isfinite(res[1][1][k]).all(), k
+        scale = b.pow(2).mean().sqrt().item()
+        e = (a - b).pow(2).mean().sqrt().item()
+        assert e <= 5e-6 * scale + 1e-7 and (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), (k, e, scale)
+    assert not torch.equal(res[1][0], res[0][0])             # the switch really changed the kernel
+    assert (res[1][0] - res[0][0]).abs().max().item() <= 2e-5
