@@ -1,16 +1,18 @@
-// respair_x6.hip — one (dilated conv, conv) pair of ResBlock1 with its residual (reference modules.py:296-309) of the C = 32 fp32
-// Generator stage in ONE launch, both convs on the bf16 matrix core from exact three-way bf16 splits (conv_x6.hip's arithmetic:
-// fp32 operands, fp32 results, six of the nine cross products), the intermediate in LDS.
+// respair_x6.hip — one (dilated conv, conv) pair of ResBlock1 with its residual (reference modules.py:296-309) of an fp32 Generator
+// stage (C = 64 / 32 / 16; C = 128 behind an option) in ONE launch, both convs on the bf16 matrix core from exact three-way bf16
+// splits (conv_x6.hip's arithmetic: fp32 operands, fp32 results, six of the nine cross products), the intermediate in LDS.
 //
-// Why.  At C = 32 the layer-wise split-bf16 convs (conv1d_x6<32x256>, two launches per pair) move five fp32 tensor passes per
-// pair at 2.2 TB/s and are as much HBM- / latency- as MFMA-bound (PMC: MFMA busy 0.23); the fused fp32-MFMA pair kernel
-// (resblock_fused.hip) has three passes but runs on the 16x slower fp32 matrix pipe (110 us per launch against 2 x 42).  Here: two
-// passes AND the bf16 pipe.  The x tile ([32 channels][256 + (k-1)(d+1) columns]) is loaded once (lane = column: coalesced),
-// pre-activated, split into its three planes and written channels-last to LDS; conv1 runs on it; t = acc + b1, h = lrelu(t) (zero
-// outside [0, L): conv2's padding) is split into its planes in registers and written OVER the dead x planes; conv2 runs on h; the
-// epilogue adds b2 and the fp32 residual (re-read from L2, coalesced) and stores fp32 [B][C][T].  A tile computes 256 columns of h
-// and 256 - (k-1) outputs (the k-1 halo columns are recomputed by the neighbour: 1-4 %).  Same unit order and the same values at
-// every step as the two layer-wise launches: bit-identical to them (tests/test_x6_gpu.py).
+// Why.  At C <= 64 the layer-wise split-bf16 convs (conv1d_x6<64x128> / <32x256>, two launches per pair) move five fp32 tensor
+// passes per pair at 1.6-2.2 TB/s and are as much HBM- / latency- as MFMA-bound (PMC: MFMA busy 0.36 / 0.23); the fused fp32-MFMA pair
+// kernel (resblock_fused.hip, C <= 32) has three passes but runs on the 16x slower fp32 matrix pipe.  Here: two passes AND the bf16
+// pipe.  The x tile ([C channels][HT + (k-1)(d+1) columns]) is loaded once (lane = column: coalesced), pre-activated, split into its
+// three planes and written channels-last to LDS; conv1 runs on it; t = acc + b1, h = lrelu(t) (zero outside [0, L): conv2's padding)
+// is split into its planes in registers and written OVER the dead x planes; conv2 runs on h; the epilogue adds b2 and the fp32
+// residual (re-read from L2, coalesced) and stores fp32 [B][C][T].  A tile computes HT columns of h and HT - (k-1) outputs (the k-1
+// halo columns are recomputed by the neighbour: 1-8 %).  Same unit order (conv_x6's 32-channel chunks) and the same values at every
+// step as the two layer-wise launches: bit-identical to them for C >= 32 (tests/test_x6_gpu.py); C = 16 has no layer-wise x6 form and
+// is held to the fp32-MFMA pair kernel at fp32 round-off.  Measured (same-box A/Bs, config 2): C = 32 3.769 -> 3.681 ms per step,
+// C = 64 3.72 -> 3.64, C = 16 3.640 -> 3.541; C = 128 no gain against the loader-wave kernel (profiles/r04_ab_x6_pair*.txt).
 // out must not alias x (a tile's halo columns are another tile's outputs): the host ping-pongs between two buffers per branch.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
