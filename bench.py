@@ -988,6 +988,12 @@ def rank_main(args):
             model.set_option("conv_x6", 0)
             r = run_config(2, model, hp, dev, 0, 1, max(5, min(args.steps, 20)), 3, {})
             secondary["config2_fp32_mfma"] = summary(r, hp, 1)
+            rf = secondary["config2_fp32_mfma"].get("roofline")
+            if isinstance(rf, dict) and rf.get("traffic") is not None:
+                # the PMC traffic files are collected with the DEFAULT options, where the conv1d_mfma<64x64> symbol only runs two
+                # ConvTranspose1d launches — not this leg's 18 ResBlock launches: that family average is not evidence here
+                rf["traffic"] = None
+                rf["traffic_detail"] = dict(note="no PMC profile of this leg's option set (conv_x6 = 0); the committed traffic files describe the default path")
             log(f"secondary config 2 on the fp32 matrix core: {secondary['config2_fp32_mfma']['value']} audio-s/s")
         except Exception as e:
             secondary["config2_fp32_mfma"] = dict(error=repr(e)[:300])
