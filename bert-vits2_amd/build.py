@@ -24,7 +24,8 @@ SOURCES = [
     "bv2_api.cpp", "bv2_model.cpp", "bv2_exec.cpp", "bv2_bert.cpp",
     "kernels/conv_mfma.hip", "kernels/conv_x6.hip", "kernels/respair_x6.hip", "kernels/resblock_fused.hip", "kernels/gen_bf16.hip", "kernels/resblock_cl_bf16.hip", "kernels/respair_cl_bf16.hip", "kernels/enc_f16.hip", "kernels/layernorm.hip", "kernels/attention.hip", "kernels/misc.hip", "kernels/dds_fused.hip", "kernels/flow_boundary.hip", "kernels/bert.hip", "kernels/deberta_attn.hip",
 ]
-HEADERS = ["bv2_internal.h", "bv2_kernels.h", "kernels/spline.h", "kernels/cl_bf16.h", os.path.join(ROOT, "include", "bv2.h"),
+EXPORTS = "libbv2.map"     # linker version script: export bv2_* only
+HEADERS = [EXPORTS, "bv2_internal.h", "bv2_kernels.h", "kernels/spline.h", "kernels/cl_bf16.h", os.path.join(ROOT, "include", "bv2.h"),
            os.path.join(ROOT, "include", "bv2_testing.h"), os.path.join(ROOT, "include", "bv2_bert.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
 
@@ -78,7 +79,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(f"[bv2 build] {rel}:\n{out}\n")
     if failed:
         raise RuntimeError("hipcc failed; see messages above")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={os.path.join(CSRC, EXPORTS)}", "-o", LIB] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)

@@ -245,7 +245,16 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       // the flow: this LayerNorm, the coupling's post and the next coupling's pre in one launch (flow_boundary.hip)
       fb->a = l.a; fb->nslab = l.nslab; fb->slab_stride = l.slab_stride; fb->gamma = l.gamma; fb->beta = l.beta; fb->eps = l.eps;
       fb->mask = mask; fb->B = B; fb->C = H; fb->T = T;
-      if (!c.rc) { if (int r = launch_flow_boundary(c.s, *fb)) c.fail("flow.boundary", r); }
+      fb->launched = flow_boundary_supported(*fb) ? 1 : 0;
+    }
+    if (fb && i + 1 == e.n_layers && fb->launched) {
+      if (!c.rc) {
+        const int pi = c.prof_begin("flow.boundary");
+        const int r = launch_flow_boundary(c.s, *fb);
+        c.prof_end(pi, "flow_boundary", 2.0 * B * T * (double)H * fb->C1 * (fb->pre_w ? 2 : 1),
+                   4.0 * B * T * ((double)H * (l.nslab + (fb->pre_w ? 1 : 0)) + 2.0 * fb->C1));
+        if (r) c.fail("flow.boundary", r);
+      }
     } else
     c.ln(l, "enc.ln2");
     if (tapname) {
@@ -689,7 +698,7 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
     // small-N fp32 regime: LayerNorm-2 of the last Encoder layer + post + the NEXT coupling's pre run as one launch (flow_boundary.hip);
     // the next coupling's x0 is this coupling's x1 (the Flip is folded into the weights), so its `h` is ready when its turn comes
     bool fuse_b = cf.use_transformer_flow && c.h->flow_dtype != BV2_F16 && !c.h->no_fused_boundary && c.h->taps.empty() &&
-                  n_slabs(B, Ty) > 1 && H == 192 && half * 2 == C && K.post.cin == H && K.post.cout == half && K.post.k == 1 &&
+                  n_slabs(B, Ty) > 1 && H == 192 && half * 2 == C && half * 2 == H && K.post.cin == H && K.post.cout == half && K.post.k == 1 &&
                   K.pre.cin == half && K.pre.cout == H && K.pre.k == 1 && K.post.cin_pad == H && K.pre.cin_pad == half;
     const CouplingW* Kn = a + 1 < m.n_coupling ? &m.coupling[a + 1] : nullptr;
     if (fuse_b && Kn) {
@@ -709,13 +718,14 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
       FbArgs F;
       std::memset(&F, 0, sizeof(F));
       if (fuse_b) {
-        F.x1 = x1; F.x1_out = x1; F.z_bstride = (int64_t)C * Ty;
+        F.x1 = x1; F.x1_out = x1; F.z_bstride = (int64_t)C * Ty; F.C1 = half;
         F.post_w = c.W(K.post.w_off); F.post_b = c.W(K.post.b_off);
         if (Kn) { F.pre_w = c.W(Kn->pre.w_off); F.pre_b = c.W(Kn->pre.b_off); F.pre_out = P.h; pre_done = true; }
       }
       run_encoder(c, K.enc, P.enc, ymask, gv_flow + a * H, P.gv_stride, B, Ty, nullptr, c.h->flow_dtype == BV2_F16, nullptr, nullptr, 0,
                   fuse_b ? &F : nullptr);
-      if (fuse_b) continue;                                      // post (and the next pre) are done
+      if (fuse_b && F.launched) continue;                        // post (and the next pre) are done
+      pre_done = false;                                          // the boundary kernel declined these arguments: LayerNorm ran, post follows
     } else if (c.h->flow_dtype == BV2_F16) {
       // WN.forward on the fp16 matrix core (bv2_set_flow_dtype(BV2_F16)): in_layer reads the fp32 x (rounded while staged), adds
       // bias + g_l and gates in fp32, writes the gate output as fp16 channels-last — it is only ever res_skip's input; res_skip
@@ -1010,6 +1020,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     // runs its six GEMM / epilogue / barrier phases in lock-step: 1.58 -> 1.36 ms per step at B = 32.  (C = 16 through the same kernel
     // on a half-empty MFMA block: 1.49 -> 1.72 ms, not kept.)
     if (whole && U.cout == 32 && !c.h->no_respair_c32 && !c.h->no_fused_respair) whole = false;
+    const bool narrow_layerwise = c.h->no_fused_resblock && U.cout <= 32;    // "fused_resblock" = 0: one conv per launch on the narrow stages
     if (whole) {
       // narrow stages: every branch's whole ResBlock (all dilation pairs) in ONE launch, intermediates in LDS
       RbClLaunch F;
@@ -1035,7 +1046,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     }
     // wide stages: one (dilated conv, conv) pair per launch, the intermediate in LDS (respair_cl_bf16.hip).  A tile's halo rows are
     // another tile's outputs, so a pair never runs in place: branch j ping-pongs between S[1 + j] and S[1 + nb + j] and ends in S[1 + j]
-    bool pairs = !whole && nb <= 3 && !c.h->no_fused_respair;
+    bool pairs = !whole && nb <= 3 && !c.h->no_fused_respair && !narrow_layerwise;
     for (int j = 0; j < nb && pairs; ++j)
       for (int d = 0; d < m.n_rbd && pairs; ++d)
         pairs = respair_cl_bf16_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]) &&

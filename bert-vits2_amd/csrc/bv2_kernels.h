@@ -3,8 +3,24 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace bv2 {
+
+// Raise a kernel's dynamic-LDS limit ONCE per (device, kernel) instead of on every launch: the attribute call is a driver round trip
+// on the batch-1 latency path (~20 launchers x several launches per step).  Remembers the largest size granted so far.
+inline void ensure_dyn_lds(const void* kern, size_t lds) {
+  if (lds <= 64 * 1024) return;
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& g = granted[{dev, kern}];
+  if (lds > g && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) g = lds;
+}
 
 // --------------------------------------------------------------------------------------------------------------
 // conv1d as implicit GEMM on fp32 MFMA (kernels/conv_mfma.hip)
@@ -327,6 +343,8 @@ struct FbArgs {
   const float* pre_w; const float* pre_b; float* pre_out;   // pre_out [B][C][T]
   float* h_out;
   int B, C, T;
+  int launched;                                        // set by the executor: the fused launch was taken (else LayerNorm + post + pre)
+  int C1;                                              // rows of x1 (= post's outputs = pre's inputs); the kernel is built for C1 == C/2
 };
 bool flow_boundary_supported(const FbArgs& a);
 int launch_flow_boundary(hipStream_t stream, const FbArgs& a);

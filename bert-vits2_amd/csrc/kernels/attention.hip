@@ -489,7 +489,7 @@ template <int DT, int NW, bool F16, bool ONE>
 static int launch_attn_variant2(hipStream_t stream, const AttnArgs& a, dim3 grid) {
   const size_t lds = attn_lds_bytes(32 * DT, NW);
   auto kern = attention_kernel<DT, NW, F16, ONE>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   AttnArgs at = a;
   at.dbg = timeline_slice(grid.x, grid.y, grid.z, 77000 + 10 * DT + NW, 0, a.D, a.T);    // tile id 77xxx: attention
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, at);

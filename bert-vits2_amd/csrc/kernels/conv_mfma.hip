@@ -741,7 +741,7 @@ static int launch_variant(hipStream_t stream, const ConvLaunch& L0, int ck, int 
   if (ck == 32) {
     const size_t lds = sizeof(float) * (size_t)(nxbuf * 32 * XS * 64);
     auto kern = conv1d_mfma_kernel<WM, WN, MI, NI, 32, XS>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, per_xcd, snake_n);
   } else {
     const size_t lds = sizeof(float) * (size_t)(nxbuf * 16 * XS * 64);
@@ -793,15 +793,15 @@ static void launch_splitk_nw(hipStream_t stream, const ConvLaunch& L, int nw, di
   (void)stage_rows;
   if (nw == 16) {
     auto kern = conv1d_splitk_kernel<MASK, 16, LDSX>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(1024), lds, stream, L, mtiles, ntiles, per_xcd, total);
   } else if (nw == 8) {
     auto kern = conv1d_splitk_kernel<MASK, 8, LDSX>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, L, mtiles, ntiles, per_xcd, total);
   } else {
     auto kern = conv1d_splitk_kernel<MASK, 4, LDSX>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, L, mtiles, ntiles, per_xcd, total);
   }
 }

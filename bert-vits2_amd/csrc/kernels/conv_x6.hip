@@ -477,7 +477,7 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
   }
   const size_t lds = (size_t)(NLD > 0 ? 2 : 1) * 3 * XR * (CK + 8) * 2;
   auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR, NLD>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + NLD)), lds, stream, Ls, mtiles, per_xcd, snake_n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -489,7 +489,7 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
 void conv_x6_occupancy(int out[4]) {
   auto q = [](auto kern, int threads, size_t lds) {
     int n = -1;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)kern, lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, lds) != hipSuccess) n = -1;
     return n;
   };

@@ -248,7 +248,7 @@ int launch_deberta_attn(hipStream_t stream, const DebertaAttnArgs& a) {
   if (lds > 160 * 1024) return -2;
   dim3 grid((a.T + DQ - 1) / DQ, a.H, a.B);
   auto go = [&](auto kern) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(64 * DNW), lds, stream, a);
   };
   switch (a.D) {

@@ -404,7 +404,7 @@ static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   const int ngrp = (nt + WN - 1) / WN;
   dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
   auto kern = conv_f16_kernel<WN, NI, IN_CT, OUT_CT, G>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   HcLaunch Lt = L;
   Lt.dbg = L.nprob > 1 ? nullptr : timeline_slice(grid.x, grid.y, 1, 99000 + WN * 100 + NI * 10 + (IN_CT ? 2 : 0) + (OUT_CT ? 1 : 0), p.k, p.cin, L.L);   // 99xxx: fp16 conv
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN), lds, stream, Lt, ngrp);

@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) flow_boundary_kernel(const FbArgs A) {
 }
 
 bool flow_boundary_supported(const FbArgs& a) {
-  if (a.C != 192 || a.T < 1 || a.B < 1 || !a.a || !a.mask || !a.gamma || !a.beta || !a.x1 || !a.x1_out || !a.post_w || !a.post_b) return false;
+  if (a.C != 192 || a.C1 * 2 != a.C || a.T < 1 || a.B < 1 || !a.a || !a.mask || !a.gamma || !a.beta || !a.x1 || !a.x1_out || !a.post_w || !a.post_b) return false;
   if (a.nslab != 1 && a.nslab != 2 && a.nslab != 4 && a.nslab != 8) return false;
   if ((int64_t)a.C * a.T >= (1ll << 31)) return false;
   if (a.pre_w && (!a.pre_b || !a.pre_out)) return false;
@@ -188,7 +188,7 @@ int launch_flow_boundary(hipStream_t stream, const FbArgs& a) {
 #define FB_LAUNCH(NS)                                                                                              \
   {                                                                                                                \
     auto kern = flow_boundary_kernel<6, NS>;                                                                       \
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+    ensure_dyn_lds((const void*)kern, lds);                                                                        \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);                                                     \
   }
   switch (a.nslab) {

@@ -232,7 +232,7 @@ static int launch_cl_variant(hipStream_t stream, const ClLaunch& L, int nt, size
   const int ngrp = (nt + WN * MI - 1) / (WN * MI);
   dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
   auto kern = conv_cl_bf16_kernel<WN, WM, MI, NI, G>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   ClLaunch Lt = L;
   {
     int ks = 0;

@@ -290,7 +290,7 @@ static int launch_rb(hipStream_t stream, const RbClLaunch& L, int max_tiles) {
   constexpr int R = 32 * NW * NI;
   const size_t lds = (size_t)2 * (R + 2 * RB_G) * (C + 8) * 2;
   auto kern = resblock_cl_bf16_kernel<C, NW, NI>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(max_tiles, L.B, L.nprob), dim3(64 * NW), lds, stream, L);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -354,7 +354,7 @@ int launch_resblock_fused(hipStream_t stream, const FusedLaunch& F) {
   dim3 grid((F.L + RF_BN - 1) / RF_BN, F.B, F.nprob);
   const size_t lds = sizeof(float) * (size_t)(32 * RF_XP + 32 * RF_TP);
   auto kern = F.C == 16 ? resblock_fused_kernel<true> : resblock_fused_kernel<false>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   FusedLaunch Ft = F;
   {
     int ks = 0;

@@ -579,7 +579,7 @@ static int launch_rp(hipStream_t stream, const RpClLaunch& L0) {
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, L0.B, L0.nprob);
   if (mix) grid = dim3(per_xcd * 8 * L0.nprob, L0.B, 1);
   auto kern = respair_cl_bf16_kernel<WN, WM, NI, G>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   RpClLaunch Lt = L0;
   if (Lt.dbg == nullptr) {
     int ks = 0;
@@ -607,7 +607,7 @@ static int launch_rp2(hipStream_t stream, const RpClLaunch& L0) {
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, L0.B, L0.nprob);
   if (mix) grid = dim3(per_xcd * 8 * L0.nprob, L0.B, 1);
   auto kern = respair2_cl_bf16_kernel<WN, WM, G>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  ensure_dyn_lds((const void*)kern, lds);
   RpClLaunch Lt = L0;
   if (Lt.dbg == nullptr) {
     int ks = 0;

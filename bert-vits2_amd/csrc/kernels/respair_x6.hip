@@ -332,16 +332,16 @@ int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
   const size_t lds = (size_t)3 * (HT + 64) * (F.C + 8) * 2;
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, F.B, F.nprob);
   if (F.C == 16) {
-    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)respair_x6_kernel<16, 4>, lds);
     hipLaunchKernelGGL((respair_x6_kernel<16, 4>), grid, dim3(256), lds, stream, F, per_xcd);
   } else if (F.C == 32) {
-    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)respair_x6_kernel<32, 4>, lds);
     hipLaunchKernelGGL((respair_x6_kernel<32, 4>), grid, dim3(256), lds, stream, F, per_xcd);
   } else if (F.C == 64) {
-    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)respair_x6_kernel<64, 4>, lds);
     hipLaunchKernelGGL((respair_x6_kernel<64, 4>), grid, dim3(512), lds, stream, F, per_xcd);
   } else {
-    (void)hipFuncSetAttribute((const void*)respair_x6_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_dyn_lds((const void*)respair_x6_kernel<128, 2>, lds);
     hipLaunchKernelGGL((respair_x6_kernel<128, 2>), grid, dim3(512), lds, stream, F, per_xcd);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -247,12 +247,14 @@ void bv2_graph_destroy(bv2_graph* graph);
 
 /* ---- debugging / measurement ------------------------------------------------------------------------------ */
 /* Kernel-selection switches, for tests that hold the fused kernels to the layer-wise ones (default 1 = fused):
- *   "fused_resblock"  the narrow Generator stages as whole-ResBlock / fused-pair kernels (0: one conv per launch)
+ *   "fused_resblock"  the narrow Generator stages as whole-ResBlock / fused-pair kernels (0: one conv per launch; in bf16 mode this
+ *                     also takes the C = 32 stage off the pair kernel, i.e. 0 = every narrow stage layer-wise)
  *   "conv_x6"         the ResBlock convs of the fp32 Generator stages with C >= 32 on the bf16 matrix core: operands split exactly
  *                     into three bf16 planes, six cross products accumulated in fp32 — fp32 accuracy (dropped terms < 2^-23 of a
  *                     product) at 6/16 of the fp32-MFMA time (kernels/conv_x6.hip).  0: v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
  *   "conv_x6_c32"     also the C = 32 stage layer-wise on conv_x6.hip (two launches per ResBlock pair, 44.6 us each at batch 1) instead
- *                     of the fused fp32-MFMA pair kernel (one launch, 110 us); 0: resblock_fused.hip
+ *                     of the fused fp32-MFMA pair kernel (one launch, 110 us); 0: resblock_fused.hip.  Only consulted when the C = 32
+ *                     stage is NOT on the split-bf16 pair kernel, i.e. together with "x6_pair" = 0 (the default runs respair_x6.hip there)
  *   "fused_respair"   the wide bf16 Generator stages (C = 64 / 128 / 256) one (dilated conv, conv) ResBlock pair per launch, the
  *                     intermediate in LDS (kernels/respair_cl_bf16.hip; bit-identical to the layer-wise path); 0: one conv per launch
  *   "respair_c32"     1 (default): also the C = 32 stage pair by pair (one wave owns all channels); 0: whole-ResBlock launches

@@ -29,6 +29,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.bv2_abi_version() == 3
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """A drop-in C-ABI library exports `bv2_*` and nothing else: the linker version script csrc/libbv2.map keeps every C++ symbol of
+    the executor / launchers (namespace bv2) local."""
+    import subprocess
+    lib = L.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", lib._name], check=True, capture_output=True, text=True).stdout
+    exported = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert len(exported) >= 50
+    stray = [n for n in exported if not n.startswith("bv2_")]
+    assert not stray, stray[:10]
+    declared = set(_declared("bv2.h") + _declared("bv2_testing.h") + _declared("bv2_bert.h"))
+    undeclared = [n for n in exported if n not in declared]
+    assert not undeclared, f"exported but declared in no header: {undeclared}"
+
+
 def test_create_rejects_bad_config_with_message():
     lib = L.load()
     cfg = L.make_config(H.default_v23())

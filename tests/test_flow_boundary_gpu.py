@@ -51,3 +51,30 @@ def test_flow_with_fused_boundary_vs_oracle(name):
     z = m.stage_flow(ref["z_p"], ref["y_lengths"], ref["g"])
     ym = ref["y_mask"]
     assert rms((z.cpu() - ref["z"]) * ym) <= 2e-5 * max(rms(ref["z"] * ym), 1e-3)
+
+
+def test_inter_channels_not_equal_hidden_takes_the_three_launch_form():
+    """the fused kernel is built for x1 rows = hidden/2 = 96.  A config with hidden_channels = 192 and inter_channels = 256
+    (legal in the reference: TransformerCouplingLayer.pre is half -> hidden, models.py:95-132) must NOT take it: the executor's gate
+    (half * 2 == H) and flow_boundary_supported (C1 * 2 == C) both decline, and the flow agrees with the oracle."""
+    from bert_vits2_amd import hparams as H, synth
+    hp = H.default_v23(inter_channels=256)
+    sd = synth.synthetic_state_dict(hp, seed=5)
+    from bert_vits2_amd import models
+    m = models.from_hparams(hp)
+    m.load_state_dict(sd, strict=False)
+    m = m.to("cuda").eval()
+    B, Ty = 2, 77
+    gen = torch.Generator().manual_seed(3)
+    yl = torch.tensor([77, 41], dtype=torch.int64)
+    ym = (torch.arange(Ty)[None, :] < yl[:, None])[:, None, :].float()
+    z_p = torch.randn(B, hp.inter_channels, Ty, generator=gen) * ym
+    g = torch.randn(B, hp.gin_channels, 1, generator=gen)
+    m.set_option("fused_boundary", 0)
+    z0 = m.stage_flow(z_p.cuda(), yl.cuda(), g.cuda())
+    m.set_option("fused_boundary", 1)
+    z1 = m.stage_flow(z_p.cuda(), yl.cuda(), g.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)                       # same launches either way: the fused kernel was declined
+    ref = O.flow_reverse(sd, hp, z_p, ym, g)
+    assert rms((z1.cpu() - ref) * ym) <= 2e-5 * max(rms(ref * ym), 1e-3)

@@ -158,7 +158,7 @@ def test_conv1d_x6_resblock_shape_with_residual_in_place_like_the_generator():
 
 def test_generator_on_conv_x6_matches_the_fp32_mfma_generator():
     """The whole Generator (models.py:538-557) three ways on one ragged batch: split-bf16 convs on every stage with C >= 32 (default),
-    C = 32 back on the fused fp32 pair kernel (conv_x6_c32 = 0), everything on the fp32 matrix core (conv_x6 = 0).  The waveforms
+    C = 32 back on the fused fp32 pair kernel (x6_pair = 0 and conv_x6_c32 = 0), everything on the fp32 matrix core (conv_x6 = 0).  The waveforms
     agree to fp32 round-off — the switch changes which matrix core forms the products, not the arithmetic."""
     from bert_vits2_amd import hparams as H, models, synth
     hp = H.default_v23()
@@ -171,7 +171,7 @@ def test_generator_on_conv_x6_matches_the_fp32_mfma_generator():
     yl = torch.tensor([97, 60, 33], dtype=torch.int64).cuda()
     gv = torch.randn(B, hp.gin_channels, generator=g).cuda()
     outs = {}
-    for name, opts in (("x6", {}), ("x6_c64", {"conv_x6_c32": 0}), ("mfma32", {"conv_x6": 0})):
+    for name, opts in (("x6", {}), ("x6_c64", {"x6_pair": 0, "conv_x6_c32": 0}), ("mfma32", {"conv_x6": 0})):
         for k, v in opts.items():
             m.set_option(k, v)
         outs[name] = m.stage_generator(z, yl, gv).cpu()
