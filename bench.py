@@ -526,19 +526,18 @@ def run_two_streams(model, hp, dev, steps, nstreams=2):
 
 
 def build_bert(dev):
+    from bert_vits2_amd import bert_synth as BS
     from bert_vits2_amd.bert_encoder import BertEncoder
-    from oracle import bert_oracle as BO
-    sd = BO.synthetic_state_dict(BO.LARGE, 0, layers=22)
-    return BertEncoder(**BO.LARGE).load_state_dict(sd, device=dev), sd
+    sd = BS.bert_state_dict(BS.LARGE, 0, layers=22)
+    return BertEncoder(**BS.LARGE).load_state_dict(sd, device=dev), sd
 
 
 def run_text_to_audio(model, hp, dev, steps, nstreams, enc0):
     """SURVEY 8f-2 + the hot path as ONE device-resident request: BertModel forward for the sentence (53 tokens, hidden_states[-3]) ->
     word-level features handed to infer() through bert_index (no host copy, no repeated matrix) -> config 2's 128-symbol utterance,
     with `nstreams` requests in flight (a handle + HIP stream each for both models, one copy of each weight blob)."""
-    from bert_vits2_amd import bert_features as BF
-    from oracle import bert_oracle as BO
-    cfg = BO.LARGE
+    from bert_vits2_amd import bert_features as BF, bert_synth as BS
+    cfg = BS.LARGE
     encs = [enc0] + [enc0.replica() for _ in range(nstreams - 1)]
     ms = [model]
     for _ in range(nstreams - 1):
@@ -552,7 +551,7 @@ def run_text_to_audio(model, hp, dev, steps, nstreams, enc0):
     streams = [torch.cuda.Stream(dev) for _ in ms]
     batch, _ = make_batch(CONFIGS[2], 1, 128, 0)
     b = {k: v.to(dev) for k, v in batch.items()}
-    ids, _ = BO.synthetic_inputs(cfg, [53], 0)
+    ids, _ = BS.synthetic_inputs(cfg, [53], 0)
     ids = ids.to(dev)
     word2ph = [1] + [2, 3] * 24 + [2, 2, 2] + [1]                   # 53 words -> 128 symbols (blanks interspersed)
     assert len(word2ph) == 53 and sum(word2ph) == 128
@@ -597,11 +596,11 @@ def bench_bert(dev, with_cpu, enc=None, sd=None):
     """SURVEY 8f-2 leg (secondary, N=1 only): hidden_states[-3] of a chinese-roberta-wwm-ext-large-shaped BertModel for ONE sentence
     of config 2's size (128 symbols with blanks interspersed = ~51 characters + [CLS]/[SEP] = 53 tokens) through bv2_bert_forward,
     seeded synthetic weights.  HBM-side roofline: every forward streams the 22 layers' fp32 weights once (algorithmic bytes)."""
-    from oracle import bert_oracle as BO
-    cfg, S, layers = BO.LARGE, 53, 22
+    from bert_vits2_amd import bert_synth as BS
+    cfg, S, layers = BS.LARGE, 53, 22
     if enc is None:
         enc, sd = build_bert(dev)
-    ids, _ = BO.synthetic_inputs(cfg, [S], 0)
+    ids, _ = BS.synthetic_inputs(cfg, [S], 0)
     ids = ids.to(dev)
     for _ in range(3):
         enc(ids)
@@ -625,7 +624,7 @@ def bench_bert(dev, with_cpu, enc=None, sd=None):
                              note="latency-bound at batch 1: 156 dependent launches of ~10 us; the weights (1.1 GB fp32) are the algorithmic bytes"))
     # the same model over a padded batch of 8 sentences (a request split into sentences, infer.py:268-332): the weights are
     # streamed once per batch instead of once per sentence
-    ids8, ln8 = BO.synthetic_inputs(cfg, [53, 41, 37, 53, 29, 48, 33, 53], 1)
+    ids8, ln8 = BS.synthetic_inputs(cfg, [53, 41, 37, 53, 29, 48, 33, 53], 1)
     ids8, ln8 = ids8.to(dev), ln8.to(dev)
     for _ in range(2):
         enc(ids8, lengths=ln8)
@@ -641,10 +640,9 @@ def bench_bert(dev, with_cpu, enc=None, sd=None):
     # size: disentangled attention (kernels/deberta_attn.hip), the Japanese model's ConvLayer
     try:
         from bert_vits2_amd.bert_encoder import BertEncoder
-        from oracle import deberta_oracle as DO
-        for nm, dcfg in (("deberta_v2_large_japanese", DO.LARGE_JA), ("deberta_v3_large", DO.LARGE_V3)):
+        for nm, dcfg in (("deberta_v2_large_japanese", BS.LARGE_JA), ("deberta_v3_large", BS.LARGE_V3)):
             dcfg = dict(dcfg, vocab_size=min(dcfg["vocab_size"], 32000))        # the embedding table is read one row per token
-            dsd = DO.synthetic_state_dict(dcfg, 0, layers=layers)
+            dsd = BS.deberta_state_dict(dcfg, 0, layers=layers)
             denc = BertEncoder(**dcfg, model_type="deberta-v2").load_state_dict(dsd, device=dev)
             dids = torch.randint(1, dcfg["vocab_size"], (1, S), generator=torch.Generator().manual_seed(1)).to(dev)
             for _ in range(3):
@@ -657,6 +655,7 @@ def bench_bert(dev, with_cpu, enc=None, sd=None):
             dms = (time.perf_counter() - t0) / 20 * 1e3
             res[nm] = dict(ms_per_sentence=round(dms, 4), sentences_per_sec=round(1e3 / dms, 2), tokens=S)
             if with_cpu and nm == "deberta_v2_large_japanese":
+                from oracle import deberta_oracle as DO                      # the checker, cpu leg only
                 dref = DO.hidden_state(dsd, dcfg, dids.cpu(), layers)
                 res[nm]["max_abs_err_vs_oracle"] = float((dout.cpu().transpose(1, 2) - dref).abs().max())
             del denc, dsd
@@ -665,6 +664,7 @@ def bench_bert(dev, with_cpu, enc=None, sd=None):
     if with_cpu:
         nthreads = min(usable_cores(), 64)           # torch's default team is the HOST's core count even inside a CPU quota
         torch.set_num_threads(nthreads)
+        from oracle import bert_oracle as BO                                    # the checker, cpu leg only
         ref = BO.hidden_state(sd, cfg, ids.cpu(), layers)                       # warm-up
         ts = []
         for _ in range(3):

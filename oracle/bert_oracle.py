@@ -25,46 +25,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-TINY = dict(vocab_size=97, hidden_size=128, num_hidden_layers=5, num_attention_heads=2, intermediate_size=384,
-            max_position_embeddings=48, type_vocab_size=2, layer_norm_eps=1e-12)
-MID = dict(vocab_size=211, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024,
-           max_position_embeddings=80, type_vocab_size=2, layer_norm_eps=1e-12)
-LARGE = dict(vocab_size=21128, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
-             max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12)     # chinese-roberta-wwm-ext-large's config.json
-
-
-def synthetic_state_dict(cfg: Dict, seed: int = 0, layers: Optional[int] = None) -> Dict[str, torch.Tensor]:
-    """Seeded synthetic ``BertModel.state_dict()`` (no pooler): there is no network for the real checkpoint.  Scales are chosen so
-    that attention is far from uniform and LayerNorm inputs have O(1) spread (the pretrained model's regime)."""
-    g = torch.Generator().manual_seed(1000 + seed)
-    C, I = cfg["hidden_size"], cfg["intermediate_size"]
-    n = cfg["num_hidden_layers"] if layers is None else layers
-    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
-    sd = {"embeddings.word_embeddings.weight": r(cfg["vocab_size"], C, sc=0.6),
-          "embeddings.position_embeddings.weight": r(cfg["max_position_embeddings"], C, sc=0.3),
-          "embeddings.token_type_embeddings.weight": r(cfg["type_vocab_size"], C, sc=0.2),
-          "embeddings.LayerNorm.weight": 1 + r(C, sc=0.1), "embeddings.LayerNorm.bias": r(C, sc=0.1)}
-    for i in range(n):
-        p = f"encoder.layer.{i}."
-        for name, (o, c_in, sc) in {"attention.self.query": (C, C, 2.0), "attention.self.key": (C, C, 2.0),
-                                    "attention.self.value": (C, C, 1.0), "attention.output.dense": (C, C, 1.0),
-                                    "intermediate.dense": (I, C, 1.0), "output.dense": (C, I, 1.0)}.items():
-            sd[p + name + ".weight"] = r(o, c_in, sc=sc / math.sqrt(c_in))
-            sd[p + name + ".bias"] = r(o, sc=0.05)
-        for name in ("attention.output.LayerNorm", "output.LayerNorm"):
-            sd[p + name + ".weight"] = 1 + r(C, sc=0.1)
-            sd[p + name + ".bias"] = r(C, sc=0.1)
-    return sd
-
-
-def synthetic_inputs(cfg: Dict, lengths, seed: int = 0):
-    g = torch.Generator().manual_seed(77 + seed)
-    S = max(lengths)
-    ids = torch.randint(0, cfg["vocab_size"], (len(lengths), S), generator=g)
-    for b, n in enumerate(lengths):
-        ids[b, n:] = 0                                    # [PAD]
-    return ids, torch.tensor(lengths, dtype=torch.int64)
-
+from bert_vits2_amd.bert_synth import LARGE, MID, TINY, bert_state_dict as synthetic_state_dict, synthetic_inputs  # noqa: F401  (shared with the product-side legs)
 
 def _ln(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)

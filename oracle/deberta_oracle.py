@@ -30,54 +30,8 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-TINY_V3 = dict(vocab_size=131, hidden_size=128, num_hidden_layers=5, num_attention_heads=2, intermediate_size=384,
-               max_position_embeddings=64, relative_attention=True, position_buckets=16, norm_rel_ebd="layer_norm", share_att_key=True,
-               pos_att_type="p2c|c2p", layer_norm_eps=1e-7, max_relative_positions=-1, position_biased_input=False, type_vocab_size=0)
-TINY_JA = dict(TINY_V3, vocab_size=97, conv_kernel_size=3, conv_act="gelu", pos_att_type=["p2c", "c2p"], attention_head_size=64)
-MID_V3 = dict(TINY_V3, vocab_size=211, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024,
-              max_position_embeddings=160, position_buckets=32)
-# /root/reference/bert/deberta-v3-large/config.json and deberta-v2-large-japanese-char-wwm/config.json
-LARGE_V3 = dict(vocab_size=128100, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
-                max_position_embeddings=512, relative_attention=True, position_buckets=256, norm_rel_ebd="layer_norm", share_att_key=True,
-                pos_att_type="p2c|c2p", layer_norm_eps=1e-7, max_relative_positions=-1, position_biased_input=False, type_vocab_size=0)
-LARGE_JA = dict(LARGE_V3, vocab_size=22012, conv_kernel_size=3, conv_act="gelu", pos_att_type=["p2c", "c2p"], attention_head_size=64)
-
-
-def att_span(cfg: Dict) -> int:
-    mr = cfg.get("max_relative_positions", -1)
-    mr = cfg["max_position_embeddings"] if mr < 1 else mr
-    pb = cfg.get("position_buckets", -1)
-    return pb if pb > 0 else mr
-
-
-def synthetic_state_dict(cfg: Dict, seed: int = 0, layers: Optional[int] = None) -> Dict[str, torch.Tensor]:
-    """Seeded synthetic ``DebertaV2Model.state_dict()``; same scale choices as the BERT one (oracle/bert_oracle.py)."""
-    g = torch.Generator().manual_seed(2000 + seed)
-    C, I = cfg["hidden_size"], cfg["intermediate_size"]
-    n = cfg["num_hidden_layers"] if layers is None else layers
-    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
-    sd = {"embeddings.word_embeddings.weight": r(cfg["vocab_size"], C, sc=0.8),
-          "embeddings.LayerNorm.weight": 1 + r(C, sc=0.1), "embeddings.LayerNorm.bias": r(C, sc=0.1),
-          "encoder.rel_embeddings.weight": r(2 * att_span(cfg), C, sc=0.8),
-          "encoder.LayerNorm.weight": 1 + r(C, sc=0.1), "encoder.LayerNorm.bias": r(C, sc=0.1)}
-    k = cfg.get("conv_kernel_size", 0)
-    if k > 0:
-        sd["encoder.conv.conv.weight"] = r(C, C, k, sc=1.0 / math.sqrt(C * k))
-        sd["encoder.conv.conv.bias"] = r(C, sc=0.05)
-        sd["encoder.conv.LayerNorm.weight"] = 1 + r(C, sc=0.1)
-        sd["encoder.conv.LayerNorm.bias"] = r(C, sc=0.1)
-    for i in range(n):
-        p = f"encoder.layer.{i}."
-        for name, (o, c_in, sc) in {"attention.self.query_proj": (C, C, 2.0), "attention.self.key_proj": (C, C, 2.0),
-                                    "attention.self.value_proj": (C, C, 1.0), "attention.output.dense": (C, C, 1.0),
-                                    "intermediate.dense": (I, C, 1.0), "output.dense": (C, I, 1.0)}.items():
-            sd[p + name + ".weight"] = r(o, c_in, sc=sc / math.sqrt(c_in))
-            sd[p + name + ".bias"] = r(o, sc=0.05)
-        for name in ("attention.output.LayerNorm", "output.LayerNorm"):
-            sd[p + name + ".weight"] = 1 + r(C, sc=0.1)
-            sd[p + name + ".bias"] = r(C, sc=0.1)
-    return sd
-
+from bert_vits2_amd.bert_synth import (LARGE_JA, LARGE_V3, MID_V3, TINY_JA, TINY_V3, att_span,  # noqa: F401
+                                       deberta_state_dict as synthetic_state_dict)
 
 def log_bucket_position(rel: torch.Tensor, bucket_size: int, max_position: int) -> torch.Tensor:
     """``make_log_bucket_position``: float32 arithmetic exactly as transformers does it (the ceil() makes it rounding-sensitive)."""
