@@ -76,6 +76,10 @@ def parse(argv=None):
                     help="bv2_test_set_variants(spec, cl_generic, hc_generic) before the run (tuning A/B only)")
     ap.add_argument("--streams", type=int, default=2, help="requests in flight for the secondary two-stream leg of config 2")
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path at whatever world size there is — at --gpus 1: a world-size-1 RCCL process group on the "
+                         "device, the blob broadcast, both barriers, all_reduce(MAX), all_gather_object and the N>1 line builder — so "
+                         "that the multi-GPU path executes on the one GPU a builder has")
     ap.add_argument("--master-port", type=int, default=0, help="self-launched N>1 runs: rendezvous port on 127.0.0.1 (0 = pick a free one)")
     ap.add_argument("--library", default=None, metavar="PATH",
                     help="same-box A/B of two BUILDS (tools/ab_build.py): load this libbv2 (same C ABI) instead of the in-tree build")
@@ -328,8 +332,10 @@ def upsampling_block(ups, psteps, config):
                 launches=rows)
 
 
-def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False):
-    """Time `steps` steps of BASELINE config `num` on this rank; returns the result dict (rank-local times; the caller reduces)."""
+def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False, solo=False, collective=False):
+    """Time `steps` steps of BASELINE config `num` on this rank; returns the result dict (rank-local times; the caller reduces).
+    ``collective``: a process group exists and every rank is in this call — the timed region is bracketed by its barriers (always at
+    world > 1).  ``solo``: this rank runs alone while the others wait (the N=1 anchor of the N>1 line): no barriers, no extra legs."""
     cfg = dict(CONFIGS[num])
     B = overrides.get("batch") or cfg["batch"]
     T = overrides.get("symbols") or cfg["symbols"]
@@ -347,7 +353,7 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     audio_per_step = frames_per_step * hp.total_upsample / hp.sampling_rate
 
     def barrier():
-        if world > 1:
+        if (world > 1 or collective) and not solo:
             import torch.distributed as dist
             dist.barrier()
 
@@ -369,6 +375,9 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     Ty = y_mask.shape[2]
     res = dict(config=num, B=B, T=T, Ty=Ty, gen_dtype=gen_dtype, flow_dtype=flow_dtype, graph=use_graph, dt=dt, steps=steps,
                audio_per_step=audio_per_step, lengths=lengths)
+    if solo:
+        model.enable_graphs(False)
+        return res
     if rank == 0:
         # ---- PCIe-inclusive variant: inputs start in pinned HOST memory, the audio ends in pinned HOST memory.  The
         # uploads land in the PERSISTENT device tensors the (static_io) graph reads in place, so a captured graph is replayed, not
@@ -805,6 +814,11 @@ def headline(line, details_path=None):
                          for r in line["per_rank"]]
         h["weight_broadcast_ms"] = line.get("weight_broadcast_ms")
         h["collectives_in_timed_region"] = "none"
+        if isinstance(line.get("n1_same_workload"), dict):
+            h["n1_same_workload"] = _pick(line["n1_same_workload"], ("value", "ms_per_step"))
+            h["scaling_efficiency"] = line.get("scaling_efficiency")
+        if line.get("forced_dist"):
+            h["forced_dist"] = str(line["forced_dist"])[:160]
     if details_path:
         h["details"] = details_path
     txt = json.dumps(h, allow_nan=False, separators=(",", ":"))
@@ -924,13 +938,17 @@ def rank_main(args):
         seam = importlib.import_module(args.seam).seam
     dev = seam.device(local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                    # --force-dist without a launcher: a world-size-1 group on this device
+            os.environ.setdefault("MASTER_PORT", str(args.master_port or _free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         seam.init_pg(dev, rank, world)
 
     hp = H.default_v23(use_transformer_flow=not args.residual_flow)
-    primary = args.config if args.config is not None else (2 if world == 1 else 4)
+    primary = args.config if args.config is not None else (4 if use_dist else 2)
     overrides = dict(batch=args.batch, symbols=args.symbols, dtype=args.dtype, flow=args.flow_dtype, graph=args.graph)
     if args.residual_flow and overrides["flow"] is None:
         overrides["flow"] = "f32"                     # --flow-dtype f16 selects the fp16 WN convolutions
@@ -951,11 +969,23 @@ def rank_main(args):
         model.set_option(key, int(val))
         log(f"option {key} = {val}")
 
-    res = seam.run_config(primary, model, hp, dev, rank, world, args.steps, args.warmup, overrides, args.full_profile)
+    res = seam.run_config(primary, model, hp, dev, rank, world, args.steps, args.warmup, overrides, args.full_profile,
+                          collective=use_dist)
     log(f"rank {rank}: config {primary}: timed region {res['dt']:.3f}s for {args.steps} steps")
     dt, audio = res["dt"], res["audio_per_step"] * args.steps
     per_rank = None
-    if world > 1:
+    n1_same = None
+    if use_dist:
+        # the same-workload single-GPU anchor of this line: rank 0 runs ITS shard once more, alone, while every other rank waits at the
+        # barrier below (outside the timed region) — so that value / (N x n1) is a scaling efficiency on ONE workload, whatever the
+        # N = 1 line of the driver measured (that one is BASELINE config 2, batch 1)
+        if rank == 0:
+            r1 = seam.run_config(primary, model, hp, dev, 0, 1, args.steps, min(args.warmup, 2), overrides, solo=True)
+            n1_same = dict(value=round(r1["audio_per_step"] * args.steps / r1["dt"], 2), ms_per_step=round(r1["dt"] / args.steps * 1e3, 4),
+                           utterances=r1["B"], steps=args.steps)
+            log(f"rank 0 alone, same workload: {n1_same['value']} audio-s/s ({n1_same['ms_per_step']} ms/step)")
+        dist.barrier()
+    if use_dist:
         # value = audio of ALL ranks / the slowest rank's time (max over ranks); each rank also reports its own line
         mine = dict(rank=rank, local_rank=local, device=seam.device_name(dev), ms_per_step=round(res["dt"] / args.steps * 1e3, 4),
                     audio_s_per_step=round(res["audio_per_step"], 4), utterances=res["B"], symbols_total=sum(res["lengths"]),
@@ -973,7 +1003,7 @@ def rank_main(args):
         dt = float(tmax.item())
 
     secondary = {}
-    if world == 1 and rank == 0 and not args.no_secondary and args.config is None and not args.residual_flow:
+    if world == 1 and not use_dist and rank == 0 and not args.no_secondary and args.config is None and not args.residual_flow:
         for num in (3, 4, 5):
             try:
                 r = run_config(num, model, hp, dev, 0, 1, max(5, min(args.steps, 10)), 3, {})
@@ -1048,7 +1078,7 @@ def rank_main(args):
 
     if rank == 0:
         cpu, parity = None, None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle port)")
             cpu, par = cpu_baseline(hp, sd, args.cpu_iters)
             if primary == 2 and not any(v is not None for v in overrides.values()):
@@ -1066,8 +1096,9 @@ def rank_main(args):
                         parallelism=f"utterance-sharded x{world}", rtf=s["rtf"], x_realtime_per_gpu=round(s["value"] / world, 2),
                         hipgraph=res["graph"], weight_broadcast_ms=round(t_bcast * 1e3, 3),
                         pcie_inclusive=s.get("pcie_inclusive"),
-                        note=("N=1 measures BASELINE config 2 (the metric's config); N>1 measures config 4 per GPU — the N=1 figure of "
-                              "that same workload is secondary.config4 of the N=1 line" if args.config is None else None)),
+                        note=("N=1 measures BASELINE config 2 (the metric's config); N>1 measures config 4 per GPU — the single-GPU figure of "
+                              "that same workload is n1_same_workload of the N>1 line itself (and secondary.config4 of the N=1 line)"
+                              if args.config is None else None)),
             roofline=s.get("roofline"), cpu_baseline=cpu, parity=parity)
         if s.get("upsampling_roofline") is not None:
             line["upsampling_roofline"] = s["upsampling_roofline"]
@@ -1077,12 +1108,17 @@ def rank_main(args):
             line["per_rank"] = per_rank
             line["weight_broadcast_ms"] = round(max(r["weight_broadcast_ms"] for r in per_rank), 3)
             line["collectives_in_timed_region"] = "none on the data path (two barriers bracket it); the weight blob is broadcast once, before"
+            if n1_same is not None:
+                line["n1_same_workload"] = n1_same
+                line["scaling_efficiency"] = round(s["value"] / (world * n1_same["value"]), 4) if n1_same["value"] else None
+            if args.force_dist:
+                line["forced_dist"] = f"world size {world}: backend {seam.backend}, process group + blob broadcast + barriers + all_reduce(MAX) + all_gather_object executed"
         if secondary:
             line["secondary"] = secondary
         if res.get("full"):
             line["kernel_families_untimed_pass"] = res["full"]
         emit(line, args.details_out)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

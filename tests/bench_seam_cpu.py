@@ -27,14 +27,14 @@ class CpuSeam(bench.Seam):
         assert model._host_blob is not None and model._host_blob.numel() > 1 << 20
         return model, sd, t
 
-    def run_config(self, num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False):
+    def run_config(self, num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False, solo=False, collective=False):
         cfg = bench.CONFIGS[num]
         B, T = overrides.get("batch") or cfg["batch"], overrides.get("symbols") or cfg["symbols"]
         _, lengths = bench.make_batch(cfg, B, T, rank)               # the real per-rank shard of the workload
         frames = 3 * sum(lengths)
         digest = float(model._host_blob[256:4096].double().sum())    # every rank must hold rank 0's blob
         return dict(config=num, B=B, T=T, Ty=3 * T, gen_dtype=cfg["dtype"], flow_dtype=cfg["flow"], graph=bool(cfg["graph"]),
-                    dt=0.010 * steps * (1 + rank), steps=steps, audio_per_step=frames * hp.total_upsample / hp.sampling_rate,
+                    dt=(0.008 if solo else 0.010) * steps * (1 + rank), steps=steps, audio_per_step=frames * hp.total_upsample / hp.sampling_rate,
                     lengths=lengths,
                     roofline=dict(bound="mfma", kernel="fake", achieved=1.0 + rank, peak=10.0, unit="TFLOP/s", frac=(1.0 + rank) / 10,
                                   avg_launch_us=1.0, traffic=None, blob_digest=digest))

@@ -77,6 +77,8 @@ def _full_record(n_gpus):
                               roofline=dict(bound="mfma", kernel="conv_cl_bf16<4x1>", achieved=832.123, peak=2500.0, unit="TFLOP/s",
                                             frac=0.3328, avg_launch_us=575.12)) for r in range(n_gpus)]
         d["ranks_seen"], d["launcher"], d["weight_broadcast_ms"] = n_gpus, "torch.distributed.run", 123.456
+        d["n1_same_workload"] = dict(value=7890.12, ms_per_step=16.1234, utterances=32, steps=20)
+        d["scaling_efficiency"] = 0.9876
     return d
 
 
@@ -113,6 +115,7 @@ def test_headline_is_compact_strict_json_for_1_and_8_gpus(tmp_path, capsys):
         assert h["parity"].get("wave_max_abs") is None and "NaN" not in last
         if n == 8:
             assert len(h["per_rank"]) == 8 and h["ranks_seen"] == 8 and all(r["roofline"]["frac"] > 0 for r in h["per_rank"])
+            assert h["n1_same_workload"]["value"] == 7890.12 and h["scaling_efficiency"] == 0.9876      # the same-workload anchor survives
         else:
             assert h["secondary"]["config3"]["value"] > 0 and "frac" in h["secondary"]["config3"]
             assert abs(h["control_ratio_vs_fp32_mfma"] - rec["value"] / rec["secondary"]["config2_fp32_mfma"]["value"]) < 1e-3

@@ -34,6 +34,10 @@ def _check(d, launcher):
     assert "config 4" in d["config"]["workload"] and d["config"]["parallelism"] == "utterance-sharded x2"
     assert all(r["roofline"]["frac"] > 0 for r in ranks)                                           # per-GPU roofline
     assert d["weight_broadcast_ms"] >= 0 and d["cpu_baseline"] is None
+    # the same-workload single-GPU anchor: rank 0 alone (the fake seam: 8 ms per step) -> efficiency = value / (2 x n1)
+    n1 = d["n1_same_workload"]
+    assert abs(n1["ms_per_step"] - 8.0) < 1e-6 and abs(n1["value"] - ranks[0]["audio_s_per_step"] / 0.008) < 0.01 * n1["value"]
+    assert abs(d["scaling_efficiency"] - d["value"] / (2 * n1["value"])) < 1e-3
 
 
 def test_self_launched_two_ranks_gloo():
@@ -46,3 +50,13 @@ def test_torchrun_launched_two_ranks_gloo():
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--seam", "tests.bench_seam_cpu"])
     _check(d, "torch.distributed.run")
+
+
+def test_forced_dist_at_world_size_one_gloo():
+    """--gpus 1 --force-dist: the N>1 code path (process group, blob broadcast, barriers, all_reduce(MAX), all_gather_object, the N>1
+    line builder) at world size 1 — what tests/test_dist_w1_gpu.py runs against RCCL on the one GPU of the test box."""
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--steps", "4", "--warmup", "1", "--seam", "tests.bench_seam_cpu"])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and "config 4" in d["config"]["workload"]
+    assert "world size 1" in d["forced_dist"] and d["per_rank"][0]["rank"] == 0
+    assert abs(d["ms_per_step"] - 10.0) < 1e-6 and abs(d["n1_same_workload"]["ms_per_step"] - 8.0) < 1e-6
+    assert abs(d["scaling_efficiency"] - 0.8) < 1e-3
