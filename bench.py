@@ -76,6 +76,9 @@ def parse(argv=None):
                     help="bv2_test_set_variants(spec, cl_generic, hc_generic) before the run (tuning A/B only)")
     ap.add_argument("--streams", type=int, default=2, help="requests in flight for the secondary two-stream leg of config 2")
     ap.add_argument("--full-profile", action="store_true", help="extra untimed pass timing every MFMA kernel launch site")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the primary timed region is run this many times back to back; `value` is the FIRST (the contract's K steps after W "
+                         "warm-ups), the others are reported as its spread")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path at whatever world size there is — at --gpus 1: a world-size-1 RCCL process group on the "
                          "device, the blob broadcast, both barriers, all_reduce(MAX), all_gather_object and the N>1 line builder — so "
@@ -121,8 +124,12 @@ def reference_container():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*reference_container*.json")), reverse=True):
         try:
             d = json.load(open(path))
+            rng = list(d.get("reference_over_port_range") or [d["reference_over_port"]] * 2)
+            hist = [v for v in (d.get("history") or {}).values() if isinstance(v, (int, float))]
             return dict(ms=d["reference"]["ms"], audio_s_per_s=d["reference"]["audio_s_per_s"], threads=d["threads"], cores=d["cores_usable"],
                         torch=d["torch"], port_ms_same_box=d["port"]["ms"], reference_over_port=d["reference_over_port"],
+                        reference_over_port_range=rng, sessions=d.get("sessions", 1),
+                        reference_over_port_all_measurements=[min(rng + hist), max(rng + hist)],
                         waveform_rms_reference_vs_port=d["waveform_rms_reference_vs_port"], source=os.path.relpath(path, ROOT),
                         note="the reference's own SynthesizerTrn.infer (models.py:1026-1074, unmodified) on the BUILD CONTAINER's host cores, "
                              "same utterance / checkpoint / noise as the port figure beside it; measured by oracle/time_reference.py")
@@ -169,6 +176,8 @@ def cpu_baseline(hp, sd, iters, budget_s=40.0):
     torch.set_num_threads(nthreads)
     rc = reference_container()
     est = None if rc is None else round(v2 / rc["reference_over_port"], 3)
+    est_rng = None if rc is None else [round(v2 / rc["reference_over_port_all_measurements"][1], 3),
+                                       round(v2 / rc["reference_over_port_all_measurements"][0], 3)]
     return dict(value=round(v2, 3), unit="audio-seconds/sec", cores=nthreads, kind="port",
                 sample=f"median of {n2} timed runs of config 2's utterance (B=1, T=128, T_y={ty2}, {audio2:.3f} s audio) after 2 warm-ups, "
                        f"torch CPU fp32, oracle restatement",
@@ -177,9 +186,11 @@ def cpu_baseline(hp, sd, iters, budget_s=40.0):
                 single_thread=None if vs is None else dict(value=round(vs, 3), ms_per_step=round(meds * 1e3, 2), cores=1, runs=ns),
                 reference_container=rc,
                 reference_estimate_this_box=None if est is None else dict(
-                    value=est, unit="audio-seconds/sec",
+                    value=est, range=est_rng, unit="audio-seconds/sec",
                     note="this box's port figure / reference_container.reference_over_port: what the reference's own infer() would "
-                         "reach on these host cores if the container's reference/port ratio carries over")), par
+                         "reach on these host cores if the container's reference/port ratio carries over.  `range` spans every ratio "
+                         "measured so far (interleaved sessions of the current file and the sequential figures of rounds 3-4): the ratio "
+                         "moves with host load, so the estimate is an interval, not a number")), par
 
 
 def parity_block(model, hp, dev, par):
@@ -332,10 +343,14 @@ def upsampling_block(ups, psteps, config):
                 launches=rows)
 
 
-def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False, solo=False, collective=False):
+def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False, solo=False, collective=False,
+               repeats=1, contract=True):
     """Time `steps` steps of BASELINE config `num` on this rank; returns the result dict (rank-local times; the caller reduces).
     ``collective``: a process group exists and every rank is in this call — the timed region is bracketed by its barriers (always at
-    world > 1).  ``solo``: this rank runs alone while the others wait (the N=1 anchor of the N>1 line): no barriers, no extra legs."""
+    world > 1).  ``solo``: this rank runs alone while the others wait (the N=1 anchor of the N>1 line): no barriers, no extra legs.
+    ``repeats``: the timed region (exactly `steps` steps between two syncs) is run this many times back to back.  ``contract`` = True
+    (the primary line): `dt` is the FIRST region — the K steps after the W warm-ups the driver's contract names — and the others are
+    reported as its spread; False (secondary legs): `dt` is the median region, so one bad draw cannot set a leg's figure."""
     cfg = dict(CONFIGS[num])
     B = overrides.get("batch") or cfg["batch"]
     T = overrides.get("symbols") or cfg["symbols"]
@@ -363,18 +378,27 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
         out = call()
     torch.cuda.synchronize()
     assert int(out[2].sum().item()) == frames_per_step, (int(out[2].sum().item()), frames_per_step)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        o, attn, y_mask, _rest = call()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _rep in range(max(1, repeats)):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            o, attn, y_mask, _rest = call()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = dts[0] if contract else sorted(dts)[len(dts) // 2]
     Ty = y_mask.shape[2]
     res = dict(config=num, B=B, T=T, Ty=Ty, gen_dtype=gen_dtype, flow_dtype=flow_dtype, graph=use_graph, dt=dt, steps=steps,
                audio_per_step=audio_per_step, lengths=lengths)
+    if len(dts) > 1:
+        ms = [d / steps * 1e3 for d in dts]
+        spread = (max(ms) - min(ms)) / min(ms)
+        res["repeats"] = dict(ms_per_step=[round(m, 4) for m in ms], min=round(min(ms), 4), max=round(max(ms), 4),
+                              median=round(sorted(ms)[len(ms) // 2], 4), spread=round(spread, 4), unstable=bool(spread > 0.05),
+                              reported="first region (the contract's K steps)" if contract else "median region")
     if solo:
         model.enable_graphs(False)
         return res
@@ -709,6 +733,8 @@ def summary(res, hp, world, dt=None, audio=None):
                ms_per_step=round(dt / res["steps"] * 1e3, 4), steps=res["steps"],
                dtype=dtype_label(res), utterances_per_gpu=res["B"], symbols=res["T"], frames=res["Ty"], hipgraph=res["graph"],
                rtf=round(dt / audio, 6))
+    if res.get("repeats"):
+        out["repeats"] = res["repeats"]
     if "io_ms_per_step" in res:
         out["pcie_inclusive"] = dict(value=round(res["audio_per_step"] / (res["io_ms_per_step"] * 1e-3), 2),
                                      ms_per_step=round(res["io_ms_per_step"], 4), bytes_per_step=res["io_bytes_per_step"],
@@ -745,6 +771,11 @@ def _leg(v):
     if "error" in v:
         return dict(error=str(v["error"])[:80])
     out = _pick(v, ("value", "ms_per_step", "ms_per_request", "ms_per_sentence", "sentences_per_sec", "launches"))
+    rp = v.get("repeats")
+    if isinstance(rp, dict):
+        out["min_max"] = [rp.get("min"), rp.get("max")]
+        if rp.get("unstable"):
+            out["unstable"] = True
     r = v.get("roofline")
     if isinstance(r, dict) and "frac" in r:
         out["frac"], out["bound"] = r["frac"], r.get("bound")
@@ -769,6 +800,8 @@ def headline(line, details_path=None):
         h["config"]["workload"] = h["config"]["workload"][:260]
     if isinstance(cfg.get("pcie_inclusive"), dict):
         h["config"]["pcie_inclusive"] = _pick(cfg["pcie_inclusive"], ("value", "ms_per_step"))
+    if isinstance(line.get("repeats"), dict):
+        h["repeats"] = _pick(line["repeats"], ("ms_per_step", "spread", "unstable"))
     r = line.get("roofline")
     if isinstance(r, dict):
         h["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac")) if "error" not in r else dict(error=str(r["error"])[:120])
@@ -784,9 +817,12 @@ def headline(line, details_path=None):
         h["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:170]
         if isinstance(c.get("reference_container"), dict):
             h["cpu_baseline"]["reference_container"] = _pick(c["reference_container"], ("ms", "audio_s_per_s", "threads", "port_ms_same_box",
-                                                                                         "reference_over_port"))
+                                                                                         "reference_over_port", "reference_over_port_range"))
         if isinstance(c.get("reference_estimate_this_box"), dict):
             h["cpu_baseline"]["reference_estimate_this_box"] = c["reference_estimate_this_box"].get("value")
+            h["cpu_baseline"]["reference_estimate_range"] = c["reference_estimate_this_box"].get("range")
+        if isinstance(c.get("single_thread"), dict):
+            h["cpu_baseline"]["single_thread"] = _pick(c["single_thread"], ("value", "ms_per_step"))
     else:
         h["cpu_baseline"] = None
     if isinstance(line.get("parity"), dict):
@@ -970,7 +1006,7 @@ def rank_main(args):
         log(f"option {key} = {val}")
 
     res = seam.run_config(primary, model, hp, dev, rank, world, args.steps, args.warmup, overrides, args.full_profile,
-                          collective=use_dist)
+                          collective=use_dist, repeats=args.repeats, contract=True)
     log(f"rank {rank}: config {primary}: timed region {res['dt']:.3f}s for {args.steps} steps")
     dt, audio = res["dt"], res["audio_per_step"] * args.steps
     per_rank = None
@@ -1006,7 +1042,7 @@ def rank_main(args):
     if world == 1 and not use_dist and rank == 0 and not args.no_secondary and args.config is None and not args.residual_flow:
         for num in (3, 4, 5):
             try:
-                r = run_config(num, model, hp, dev, 0, 1, max(5, min(args.steps, 10)), 3, {})
+                r = run_config(num, model, hp, dev, 0, 1, max(10, min(args.steps, 10)), 3, {}, repeats=3, contract=False)
                 secondary[f"config{num}"] = summary(r, hp, 1)
                 log(f"secondary config {num}: {secondary[f'config{num}']['value']} audio-s/s ({secondary[f'config{num}']['ms_per_step']} ms/step)")
             except Exception as e:          # a secondary workload must never take the primary line down
@@ -1016,7 +1052,7 @@ def rank_main(args):
         # of the split-bf16 form (conv_x6.hip): the same fp32 numerics at the fp32 MFMA rate — the kernel of rounds 1-2
         try:
             model.set_option("conv_x6", 0)
-            r = run_config(2, model, hp, dev, 0, 1, max(5, min(args.steps, 20)), 3, {})
+            r = run_config(2, model, hp, dev, 0, 1, max(10, min(args.steps, 20)), 3, {}, repeats=3, contract=False)
             secondary["config2_fp32_mfma"] = summary(r, hp, 1)
             rf = secondary["config2_fp32_mfma"].get("roofline")
             if isinstance(rf, dict) and rf.get("traffic") is not None:
@@ -1038,7 +1074,7 @@ def rank_main(args):
             m_wn.load_state_dict(synth.synthetic_state_dict(hp_wn, seed=0, pin_durations=2.5), strict=False)
             sharding.distribute_weights(m_wn, dev, src=0)
             for num, key, ov in ((2, "config2_residual_flow", dict(flow="f32")), (3, "config3_residual_flow", dict(flow=WN_FLOW_B32))):
-                r = run_config(num, m_wn, hp_wn, dev, 0, 1, max(5, min(args.steps, 20 if num == 2 else 10)), 3, ov)
+                r = run_config(num, m_wn, hp_wn, dev, 0, 1, max(10, min(args.steps, 20 if num == 2 else 10)), 3, ov, repeats=3, contract=False)
                 secondary[key] = summary(r, hp_wn, 1)
                 log(f"secondary {key}: {secondary[key]['value']} audio-s/s ({secondary[key]['ms_per_step']} ms/step)")
             del m_wn
@@ -1100,6 +1136,8 @@ def rank_main(args):
                               "that same workload is n1_same_workload of the N>1 line itself (and secondary.config4 of the N=1 line)"
                               if args.config is None else None)),
             roofline=s.get("roofline"), cpu_baseline=cpu, parity=parity)
+        if s.get("repeats"):
+            line["repeats"] = s["repeats"]
         if s.get("upsampling_roofline") is not None:
             line["upsampling_roofline"] = s["upsampling_roofline"]
         if per_rank is not None:

@@ -27,7 +27,7 @@ class CpuSeam(bench.Seam):
         assert model._host_blob is not None and model._host_blob.numel() > 1 << 20
         return model, sd, t
 
-    def run_config(self, num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False, solo=False, collective=False):
+    def run_config(self, num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False, solo=False, collective=False, **kw):
         cfg = bench.CONFIGS[num]
         B, T = overrides.get("batch") or cfg["batch"], overrides.get("symbols") or cfg["symbols"]
         _, lengths = bench.make_batch(cfg, B, T, rank)               # the real per-rank shard of the workload
