@@ -1142,7 +1142,9 @@ def rank_main(args):
             line["upsampling_roofline"] = s["upsampling_roofline"]
         if per_rank is not None:
             line["ranks_seen"] = len([r for r in per_rank if r is not None])
-            line["launcher"] = "self (torch.multiprocessing.spawn)" if os.environ.get("BV2_BENCH_SELF_LAUNCHED") else "torch.distributed.run"
+            line["launcher"] = ("self (torch.multiprocessing.spawn)" if os.environ.get("BV2_BENCH_SELF_LAUNCHED") else
+                                "none (--force-dist: this process is the whole world-size-1 group)" if (args.force_dist and world == 1 and "TORCHELASTIC_RUN_ID" not in os.environ)
+                                else "torch.distributed.run")
             line["per_rank"] = per_rank
             line["weight_broadcast_ms"] = round(max(r["weight_broadcast_ms"] for r in per_rank), 3)
             line["collectives_in_timed_region"] = "none on the data path (two barriers bracket it); the weight blob is broadcast once, before"
