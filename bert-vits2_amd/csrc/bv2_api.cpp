@@ -407,6 +407,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "respair_mix") h->respair_problem_major = value == 0;
   else if (k == "respair_form") h->respair_form = value;
   else if (k == "respair_c32") h->no_respair_c32 = value == 0;
+  else if (k == "resblock_c16") h->no_resblock_c16 = value == 0;
   else if (k == "conv_x6") h->no_conv_x6 = value == 0;
   else if (k == "conv_x6_c32") h->x6_narrow = value != 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;
@@ -594,6 +595,54 @@ static inline uint16_t t_f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
+int64_t bv2_test_resblock_cl_pack_bytes(int C, int k, int nd) {
+  const int64_t units = (int64_t)2 * nd * resblock_cl_bf16_units(C, k) + RBCL_PD;      // the larger of the two stream formats
+  return units * 1024 + (int64_t)2 * nd * 32 * 4 + 256;
+}
+
+int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                         int C, int k, const int* dil, int nd, int L, float slope, int variant, const int64_t* lens) {
+  try {
+    if (nd < 1 || nd > BV2_RBCL_MAX_D) return -2;
+    if (variant == 1 ? !resblock_c16_bf16_supported(C, k, dil, nd) : !resblock_cl_bf16_supported(C, k, dil, nd)) return -2;
+    const int Upad = resblock_cl_bf16_units(C, k), KU = rb16_units(k), G = C / 16;
+    const int64_t wunits = variant == 1 ? (int64_t)2 * nd * KU : (int64_t)2 * nd * Upad + RBCL_PD;
+    const int brow = variant == 1 ? 16 : 32;
+    std::vector<uint16_t> pk((size_t)wunits * 512, 0);
+    std::vector<float> pb((size_t)2 * nd * brow, 0.f);
+    for (int d = 0; d < nd; ++d)
+      for (int e = 0; e < 2; ++e) {
+        const float* w = w_host + (size_t)(2 * d + e) * C * C * k;
+        for (int co = 0; co < C; ++co) {
+          pb[(size_t)(2 * d + e) * brow + co] = bias_host[(size_t)(2 * d + e) * C + co];
+          for (int ci = 0; ci < C; ++ci)
+            for (int j = 0; j < k; ++j) {
+              const uint16_t v = t_f2bf(w[((size_t)co * C + ci) * k + j]);
+              if (variant == 1) {
+                pk[(size_t)(2 * d + e) * KU * 512 + (size_t)rb16_w_index(j, ci, co)] = v;
+              } else {                                  // tap-major units of m-tile 0 (bv2_model.cpp): unit = tap * G + group
+                const int64_t in_unit = cl_w_index(j, ci, co, C, k) % 512;
+                pk[((size_t)(2 * d + e) * Upad + (size_t)j * G + ci / 16) * 512 + (size_t)in_unit] = v;
+              }
+            }
+        }
+      }
+    char* base = static_cast<char*>(wpack_dev);
+    const size_t wbytes = pk.size() * 2, boff = (wbytes + 255) / 256 * 256;
+    if (hipMemcpy(base, pk.data(), wbytes, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    if (hipMemcpy(base + boff, pb.data(), pb.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    RbClLaunch F;
+    std::memset(&F, 0, sizeof(F));
+    F.nprob = 1; F.B = B; F.C = C; F.L = L; F.nd = nd; F.slope = slope; F.lens = lens; F.len_mul = 1;
+    F.p[0].x = static_cast<const uint16_t*>(x); F.p[0].out = static_cast<uint16_t*>(out);
+    F.p[0].w = reinterpret_cast<const uint16_t*>(base); F.p[0].bias = reinterpret_cast<const float*>(base + boff);
+    F.p[0].k = k;
+    for (int d = 0; d < nd; ++d) F.p[0].dil[d] = dil[d];
+    return variant == 1 ? launch_resblock_c16_bf16(static_cast<hipStream_t>(stream), F)
+                        : launch_resblock_cl_bf16(static_cast<hipStream_t>(stream), F);
+  } catch (...) { return -100; }
+}
+
 int64_t bv2_test_conv_cl_pack_bytes(int cin, int cout, int k) {
   return cl_w_elems(cin, t_round_up(cout, 32), k) * 2 + (int64_t)t_round_up(cout, 32) * 4;
 }
@@ -689,7 +738,7 @@ int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i,
     // kind 3: fp16 stream of a transformer-flow Encoder conv — coupling i (application order), layer j, d = 0 qkv / 1 o /
     //         2 ffn conv_1 / 3 ffn conv_2.   kind 4: resblock conv rb[i][j][d][e] read back from the TAP-MAJOR whole-ResBlock
     //         stream (must equal kind 2).
-    bool half = false, tapmajor = false;
+    bool half = false, tapmajor = false, tappair = false;
     if (kind == 3 && i >= 0 && i < m.n_coupling && m.cfg.use_transformer_flow && j >= 0 && j < m.coupling[i].enc.n_layers &&
         d >= 0 && d < 4) {
       const EncLayerW& L = m.coupling[i].enc.layer[j];
@@ -703,17 +752,26 @@ int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i,
       tapmajor = true;
       if (m.rbcl_w_off[i][j] < 0) return -2;
     }
+    else if (kind == 5 && i >= 0 && i < m.n_ups && j >= 0 && j < m.n_rbk && d >= 0 && d < m.n_rbd && (e == 0 || e == 1)) {
+      // kind 5: rb[i][j][d][e] read back from the tap-PAIR stream of kernels/resblock_c16_bf16.hip (must equal kind 2)
+      w = &m.rb[i][j][d][e];
+      pad_left = ((w->k - 1) / 2) * (e == 0 ? m.cfg.resblock_dilation_sizes[j][d] : 1);
+      tappair = true;
+      if (m.rb16_w_off[i][j] < 0) return -2;
+    }
     if (!w || (!half && w->wb_off < 0)) return -2;
     dims[0] = w->cin; dims[1] = w->cout; dims[2] = w->k; dims[3] = pad_left;
     const float* blob = static_cast<const float*>(host_blob);
     const uint16_t* wb = reinterpret_cast<const uint16_t*>(blob + (half ? w->wh_off : w->wb_off));
     if (tapmajor) wb = reinterpret_cast<const uint16_t*>(blob + m.rbcl_w_off[i][j]) +
                        (int64_t)(2 * d + e) * resblock_cl_bf16_units(w->cin, w->k) * 512;
+    if (tappair) wb = reinterpret_cast<const uint16_t*>(blob + m.rb16_w_off[i][j]) + (int64_t)(2 * d + e) * rb16_units(w->k) * 512;
     if (w_out)
       for (int co = 0; co < w->cout; ++co)
         for (int ci = 0; ci < w->cin; ++ci)
           for (int jj = 0; jj < w->k; ++jj) {
             int64_t idx = cl_w_index(jj, ci, co, w->cin, w->k);
+            if (tappair) idx = rb16_w_index(jj, ci, co);
             if (tapmajor) {                           // unit (group s, tap jj) sits at jj*G + s instead of s*k + jj
               const int G = w->cin / 16, sg = ci / 16;
               idx = ((int64_t)jj * G + sg) * 512 + idx % 512;
@@ -730,7 +788,8 @@ int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i,
             w_out[((size_t)co * w->cin + ci) * w->k + jj] = f;
           }
     if (bias_out)
-      for (int co = 0; co < w->cout; ++co) bias_out[co] = w->b_off >= 0 ? blob[w->b_off + co] : 0.f;
+      for (int co = 0; co < w->cout; ++co)
+        bias_out[co] = tappair ? blob[m.rb16_b_off[i][j] + (2 * d + e) * 16 + co] : (w->b_off >= 0 ? blob[w->b_off + co] : 0.f);
     return 0;
   } catch (...) { return -100; }
 }

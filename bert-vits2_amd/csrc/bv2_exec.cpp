@@ -1034,13 +1034,21 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
         p.k = cf.resblock_kernel_sizes[j];
         for (int d = 0; d < m.n_rbd; ++d) p.dil[d] = cf.resblock_dilation_sizes[j][d];
       }
+      // C = 16: the tap-pair form on v_mfma_f32_16x16x32_bf16 (resblock_c16_bf16.hip) when every branch has its stream
+      bool c16 = U.cout == 16 && !c.h->no_resblock_c16;
+      for (int j = 0; j < nb && c16; ++j) c16 = m.rb16_w_off[i][j] >= 0;
+      if (c16)
+        for (int jj = 0; jj < nb; ++jj) {
+          const int j = nb - 1 - jj;
+          F.p[jj].w = reinterpret_cast<const uint16_t*>(c.W(m.rb16_w_off[i][j])); F.p[jj].bias = c.W(m.rb16_b_off[i][j]);
+        }
       if (!c.rc) {
         const int pi = c.prof_begin("dec.resblock.whole");
         if (pi >= 0 && c.h->prof_mode >= 3)
           c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
                         std::to_string(Lo) + " B" + std::to_string(B);
-        const int r = launch_resblock_cl_bf16(c.s, F);
-        c.prof_end(pi, "resblock_cl_bf16", resblock_cl_bf16_flops(F), resblock_cl_bf16_bytes(F));
+        const int r = c16 ? launch_resblock_c16_bf16(c.s, F) : launch_resblock_cl_bf16(c.s, F);
+        c.prof_end(pi, c16 ? "resblock_c16_bf16" : "resblock_cl_bf16", resblock_cl_bf16_flops(F), resblock_cl_bf16_bytes(F));
         if (r) c.fail("dec.resblock.whole", r);
       }
     }

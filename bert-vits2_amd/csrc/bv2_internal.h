@@ -99,6 +99,9 @@ struct Model {
   // whole-ResBlock bf16 streams of the narrow stages (kernels/resblock_cl_bf16.hip); -1 where the stage is too wide
   int64_t rbcl_w_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
   int64_t rbcl_b_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
+  // the C = 16 stage once more in the tap-pair layout of kernels/resblock_c16_bf16.hip (rb16_w_index); -1 elsewhere
+  int64_t rb16_w_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
+  int64_t rb16_b_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
   VecW conv_post;
   int post_c = 0, post_k = 7;
   int total_up = 1;
@@ -126,6 +129,7 @@ struct bv2_handle {
   bool no_conv_x6 = false;           // "conv_x6" = 0: wide Generator convs on the fp32 matrix core (conv_mfma.hip) instead of the bf16x6 form
   bool x6_narrow = true;             // "conv_x6_c32" = 0: the C = 32 stage on the fused fp32 pair kernel instead of layer-wise on conv_x6.hip
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
+  bool no_resblock_c16 = false;      // "resblock_c16" = 0: the C = 16 bf16 stage on the 32x32x16 whole-ResBlock kernel (resblock_cl_bf16.hip) instead of resblock_c16_bf16.hip
   bool no_respair_c32 = false;       // "respair_c32" = 0: the C = 32 bf16 stage as whole-ResBlock launches (resblock_cl_bf16.hip) instead of pair by pair
   int respair_form = 1;              // "respair_form": 1 = 64 x 128 wave tiles (respair2_cl_bf16_kernel), 0 = 32-channel waves
   bool respair_problem_major = false; // "respair_mix" = 0: the pair kernel's branches dispatched one after the other (A/B only)

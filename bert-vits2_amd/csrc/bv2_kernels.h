@@ -228,6 +228,18 @@ int launch_resblock_cl_bf16(hipStream_t stream, const RbClLaunch& L);
 double resblock_cl_bf16_flops(const RbClLaunch& L);
 double resblock_cl_bf16_bytes(const RbClLaunch& L);
 
+// the same whole-ResBlock launch for C = 16 on v_mfma_f32_16x16x32_bf16 (kernels/resblock_c16_bf16.hip, round 5): one MFMA = 16 output
+// channels x 16 time steps x (2 taps x 16 input channels), unpadded 32-byte LDS rows, two workgroups per CU.  Same RbClLaunch, but
+//   w    : [d][conv e][unit u < rb16_units(k)][lane 64][8 bf16], element index inside a conv = rb16_w_index (zero where tap >= k)
+//   bias : fp32 [2*nd][16]
+inline int rb16_units(int k) { return (k + 1) / 2; }
+inline int64_t rb16_w_index(int j, int ci, int co) {            // tap j, input channel ci, output channel co (all < 16 / k)
+  const int q = 2 * (j & 1) + (ci >> 3);
+  return ((int64_t)(j >> 1) * 64 + co + 16 * q) * 8 + (ci & 7);
+}
+bool resblock_c16_bf16_supported(int C, int k, const int* dil, int nd);
+int launch_resblock_c16_bf16(hipStream_t stream, const RbClLaunch& L);
+
 // one (dilated conv, conv) pair of ResBlock1 with its residual at C = 64 / 128 / 256 in one launch, bf16 channels-last, the
 // intermediate in LDS (kernels/respair_cl_bf16.hip).  x / out: [B][L][C], out != x; w1 / w2: the convs' ordinary fragment streams
 // (cl_w_index), b1 / b2 fp32 [C]; conv1 has dilation dil, conv2 dilation 1, both k taps.

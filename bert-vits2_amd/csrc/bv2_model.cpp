@@ -463,6 +463,27 @@ int pack_all(Model& m, Packer& P) {
             }
         }
       }
+      // C = 16: the tap-pair stream of resblock_c16_bf16.hip, rearranged from the per-conv bf16 stream just written (same bf16 values)
+      m.rb16_w_off[i][j] = m.rb16_b_off[i][j] = -1;
+      if (m.n_rbd <= BV2_RBCL_MAX_D && resblock_c16_bf16_supported(ch, k, c.resblock_dilation_sizes[j], m.n_rbd)) {
+        const int KU = rb16_units(k);
+        m.rb16_w_off[i][j] = P.alloc(((int64_t)2 * m.n_rbd * KU * 512 + 1) / 2);
+        m.rb16_b_off[i][j] = P.alloc((int64_t)2 * m.n_rbd * 16);
+        if (P.fill()) {
+          uint16_t* dst = reinterpret_cast<uint16_t*>(P.blob + m.rb16_w_off[i][j]);
+          std::memset(dst, 0, sizeof(uint16_t) * (size_t)2 * m.n_rbd * KU * 512);
+          for (int d = 0; d < m.n_rbd; ++d)
+            for (int e = 0; e < 2; ++e) {
+              const ConvW& cw = m.rb[i][j][d][e];
+              const uint16_t* src = reinterpret_cast<const uint16_t*>(P.blob + cw.wb_off);
+              uint16_t* cd = dst + (int64_t)(2 * d + e) * KU * 512;
+              for (int co = 0; co < 16; ++co)
+                for (int ci = 0; ci < 16; ++ci)
+                  for (int j2 = 0; j2 < k; ++j2) cd[rb16_w_index(j2, ci, co)] = src[cl_w_index(j2, ci, co, 16, k)];
+              std::memcpy(P.blob + m.rb16_b_off[i][j] + (2 * d + e) * 16, P.blob + cw.b_off, sizeof(float) * 16);
+            }
+        }
+      }
     }
   }
   P.emit_bf16 = false;

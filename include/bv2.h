@@ -30,7 +30,7 @@ extern "C" {
 
 #define BV2_ABI_VERSION 3   /* 3: bv2_decode_in.nz_tstride, the six ONNX-seam stage calls, bv2_detach_weights,
                                pack-layout version in the blob header */
-#define BV2_PACK_LAYOUT 11   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
+#define BV2_PACK_LAYOUT 12   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
                                a blob cached on disk by an older packer is rejected by bv2_attach_weights */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
@@ -258,6 +258,9 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "fused_respair"   the wide bf16 Generator stages (C = 64 / 128 / 256) one (dilated conv, conv) ResBlock pair per launch, the
  *                     intermediate in LDS (kernels/respair_cl_bf16.hip; bit-identical to the layer-wise path); 0: one conv per launch
  *   "respair_c32"     1 (default): also the C = 32 stage pair by pair (one wave owns all channels); 0: whole-ResBlock launches
+ *   "resblock_c16"    1 (default): the C = 16 bf16 stage's whole-ResBlock launch on v_mfma_f32_16x16x32_bf16 (two taps x 16 channels per
+ *                     instruction, unpadded 32-byte LDS rows, two workgroups per CU: kernels/resblock_c16_bf16.hip); 0: the 32x32x16
+ *                     whole-ResBlock kernel (resblock_cl_bf16.hip), whose MFMA block is half zero padding at this width
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)

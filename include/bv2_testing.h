@@ -47,6 +47,15 @@ int bv2_test_conv_cl_bf16(void* stream, const void* x0, const void* x1, const vo
                           const float* bias_host, void* wpack_dev, void* out, const void* res, const float* bias2, int B, int cin,
                           int cout, int k, int dil, int pad_left, int L, int pre_lrelu, float slope);
 
+/* a WHOLE ResBlock1 (nd (dilated conv, conv) pairs with their residuals, reference modules.py:296-309) of a narrow Generator stage in one
+ * launch, bf16 channels-last: x / out DEVICE bf16 [B][L][C] (out != x), w_host [nd][2][C][C][k] and bias_host [nd][2][C] HOST fp32 (index
+ * [d][0] = convs1[d] with dilation dil[d], [d][1] = convs2[d]); variant 0 = kernels/resblock_cl_bf16.hip (v_mfma_f32_32x32x16_bf16, C = 16 /
+ * 32), 1 = kernels/resblock_c16_bf16.hip (v_mfma_f32_16x16x32_bf16, C = 16); lens: optional DEVICE int64 [B] valid rows per item;
+ * wpack_dev needs bv2_test_resblock_cl_pack_bytes(C, k, nd) bytes.  Returns -2 for an unsupported shape. */
+int64_t bv2_test_resblock_cl_pack_bytes(int C, int k, int nd);
+int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                         int C, int k, const int* dil, int nd, int L, float slope, int variant, const int64_t* lens);
+
 /* fp16 Encoder conv (kernels/enc_f16.hip).  in_ct: x is DEVICE fp32 [B][cin][L] (in_mask [B][L] optional) else fp16 [B][L][cin];
  * out_ct: out is DEVICE fp32 [B][cout][out_rstride] (res like out, res_mode 0/1/2 = none/add/rsub) else fp16 [B][L][cout];
  * w_host [cout][cin][k], bias_host [cout] HOST fp32; wpack_dev needs bv2_test_conv_cl_pack_bytes(cin, cout, k) bytes;
@@ -59,7 +68,8 @@ int bv2_test_conv_f16(void* stream, const void* x, int in_ct, const float* in_ma
  * kind 0 = dec.conv_pre, 1 = dec.ups[i] in its channels-last single-conv form (C_out' = u*C_out), 2 = resblock conv
  * rb[i][j][d][e], 3 = fp16 stream of a transformer-flow Encoder conv (coupling i in application order, layer j, d = 0 fused
  * q/k/v(+relative-key rows) / 1 conv_o / 2 FFN conv_1 / 3 FFN conv_2), 4 = rb[i][j][d][e] read back from the tap-major
- * whole-ResBlock stream (must equal kind 2).  dims = {cin, cout, k, pad_left}; w_out [cout][cin][k] (bf16 values widened to fp32) and bias_out [cout]
+ * whole-ResBlock stream (must equal kind 2), 5 = rb[i][j][d][e] (C = 16 stage) read back from the tap-pair stream of
+ * kernels/resblock_c16_bf16.hip, bias from its own bias block (must equal kind 2).  dims = {cin, cout, k, pad_left}; w_out [cout][cin][k] (bf16 values widened to fp32) and bias_out [cout]
  * may be NULL to query dims only.  Returns 0, or a negative status. */
 int bv2_test_dump_cl_conv(bv2_handle* h, const void* host_blob, int kind, int i, int j, int d, int e, int32_t* dims,
                           float* w_out, float* bias_out);

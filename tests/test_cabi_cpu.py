@@ -271,8 +271,12 @@ def test_fp16_flow_streams_and_tap_major_resblock_streams():
                     w2, b2, pl2 = _dump_cl(lib, h, blob, 2, i, j, d, e)
                     w4, b4, pl4 = _dump_cl(lib, h, blob, 4, i, j, d, e)
                     assert pl2 == pl4 and torch.equal(w2, w4) and torch.equal(b2, b4)
+                    if i == 4:                                   # C = 16: the tap-pair stream of resblock_c16_bf16.hip holds the same values
+                        w5, b5, pl5 = _dump_cl(lib, h, blob, 5, i, j, d, e)
+                        assert pl2 == pl5 and torch.equal(w2, w5) and torch.equal(b2, b5)
     dims = (C.c_int32 * 4)()
     assert lib.bv2_test_dump_cl_conv(h, C.c_void_p(blob.data_ptr()), 4, 0, 0, 0, 0, dims, None, None) == -2   # wide stage: none
+    assert lib.bv2_test_dump_cl_conv(h, C.c_void_p(blob.data_ptr()), 5, 3, 0, 0, 0, dims, None, None) == -2   # C = 32: no tap-pair stream
 
 
 def test_no_kernel_on_the_default_path_has_a_scratch_segment():
