@@ -408,6 +408,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "respair_form") h->respair_form = value;
   else if (k == "respair_c32") h->no_respair_c32 = value == 0;
   else if (k == "resblock_c16") h->no_resblock_c16 = value == 0;
+  else if (k == "xcd_affine") h->no_xcd_affine = value == 0;
   else if (k == "conv_x6") h->no_conv_x6 = value == 0;
   else if (k == "conv_x6_c32") h->x6_narrow = value != 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;
@@ -498,15 +499,15 @@ int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_flo
   if (!h || !off_floats || !n_floats) return -1;
   const Model& m = h->model;
   int n = 0;
+  auto add = [&](const ConvW& w) {
+    if (w.wx_off < 0) return;
+    if (n < max_regions) { off_floats[n] = w.wx_off; n_floats[n] = (x6_w_elems(w.cin, w.cout_pad, w.k) + 1) / 2; }
+    ++n;
+  };
   for (int i = 0; i < m.n_ups; ++i)
     for (int j = 0; j < m.n_rbk; ++j)
       for (int d = 0; d < m.n_rbd; ++d)
-        for (int e = 0; e < 2; ++e) {
-          const ConvW& w = m.rb[i][j][d][e];
-          if (w.wx_off < 0) continue;
-          if (n < max_regions) { off_floats[n] = w.wx_off; n_floats[n] = (x6_w_elems(w.cin, w.cout_pad, w.k) + 1) / 2; }
-          ++n;
-        }
+        for (int e = 0; e < 2; ++e) add(m.rb[i][j][d][e]);
   return n;
 }
 static int64_t t_x6_off(int cin, int cout, int k) {

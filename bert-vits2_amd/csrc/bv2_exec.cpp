@@ -120,10 +120,13 @@ struct Ctx {
     p.cin = w.cin; p.cout = w.cout; p.cout_pad = w.cout_pad; p.k = w.k; p.dil = 1; p.pad_left = (w.k - 1) / 2;
     return p;
   }
-  void conv_h(const HcProb& p, int B, int L, const char* tag, const HcProb* p2 = nullptr) {
+  // batch item -> XCD affinity for the fp16 Encoder stacks (HcLaunch::xcd_b): every kernel of a layer keeps item b on XCD b % 8.  Only when
+  // the batch fills the eight XCDs about evenly
+  bool xcd_affine(int B) const { return !h->no_xcd_affine && B >= 8 && (B % 8 == 0 || B >= 32); }
+  void conv_h(const HcProb& p, int B, int L, const char* tag, const HcProb* p2 = nullptr, bool xcd = false) {
     if (rc) return;
     HcLaunch hl;
-    hl.p[0] = p; hl.nprob = 1; hl.B = B; hl.L = L;
+    hl.p[0] = p; hl.nprob = 1; hl.B = B; hl.L = L; hl.xcd_b = xcd ? 1 : 0;
     if (p2) { hl.p[1] = *p2; hl.nprob = 2; }
     const char* vn = "conv_f16";
     const int pi = prof_begin(tag);
@@ -161,6 +164,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
                  int B, int T, const char* tapname, bool f16 = false, float* out2 = nullptr, const float* vec2 = nullptr,
                  int vec2_bstride = 0, FbArgs* fb = nullptr) {
   const int H = e.hidden, ld = attn_ld(T), R = qkv_rows(e);
+  const bool xcd = f16 && c.xcd_affine(B);
   // cond_layer_idx == 2 > 0: the speaker add always rides on the previous layer's LN2 epilogue
   for (int i = 0; i < e.n_layers; ++i) {
     const EncLayerW& L = e.layer[i];
@@ -169,13 +173,13 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     if (f16) {
       HcProb q = c.hprob(L.qkv, b.x, true, b.qkv, true, T);
       q.out_rstride = ld; q.out_bstride = (int64_t)R * ld;
-      c.conv_h(q, B, T, "enc.qkv");
+      c.conv_h(q, B, T, "enc.qkv", nullptr, xcd);
     } else {
       c.conv1(p, B, T, "enc.qkv");
     }
     AttnArgs a;
     a.qkv = b.qkv; a.ld = ld; a.mask = mask; a.erv = c.W(L.erv.off); a.out = b.att;
-    a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow; a.f16 = f16 ? 1 : 0;
+    a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow; a.f16 = f16 ? 1 : 0; a.xcd_b = xcd ? 1 : 0;
     // small-N regime (the one where `s` holds partial slabs): conv_o runs inside the attention kernel, head h -> slab h
     const bool fuse_o = !f16 && !c.h->no_fused_attn_o && n_slabs(B, T) >= e.heads && L.o.k == 1 && L.o.cin == H;
     // key split (batch 1, long sequences): the key tiles of a (head, query tile) go to `ks` workgroups, each writing its own partial
@@ -205,7 +209,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     } else if (f16) {
       HcProb q = c.hprob(L.o, b.att, true, b.s, true, T);
       q.res = b.x; q.res_mode = RES_ADD;
-      c.conv_h(q, B, T, "enc.o");
+      c.conv_h(q, B, T, "enc.o", nullptr, xcd);
     } else {
       p = c.prob(L.o, b.att, b.s, T);
       p.res = b.x; p.res_mode = RES_ADD;
@@ -214,7 +218,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     LnArgs l;
     std::memset(&l, 0, sizeof(l));
     l.a = b.s; l.nslab = ns; l.slab_stride = b.slab;
-    l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T;
+    l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T; l.xcd_b = xcd ? 1 : 0;
     if (ks > 1) { l.ml = b.ml; l.ml_H = e.heads; l.ml_ks = ks; l.bias = c.W(L.o.b_off); l.add = b.x; }
     c.ln(l, "enc.ln1");
     l.ml = nullptr; l.bias = nullptr; l.add = nullptr; l.ml_H = l.ml_ks = 0;
@@ -222,10 +226,10 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       // FFN (attentions.py:438-446): hidden activation relu(conv_1(x*mask))*mask kept as fp16 channels-last in b.f1
       HcProb q = c.hprob(L.ffn1, b.x, true, b.f1, false, T);
       q.in_mask = mask; q.act = ACT_RELU; q.out_mask = mask; q.mask_post = 1;
-      c.conv_h(q, B, T, "enc.ffn1");
+      c.conv_h(q, B, T, "enc.ffn1", nullptr, xcd);
       q = c.hprob(L.ffn2, b.f1, false, b.s, true, T);
       q.out_mask = mask; q.mask_pre = 1; q.res = b.x; q.res_mode = RES_ADD;
-      c.conv_h(q, B, T, "enc.ffn2");
+      c.conv_h(q, B, T, "enc.ffn2", nullptr, xcd);
       ns = 1;
     } else {
       p = c.prob(L.ffn1, b.x, b.f1, T);
@@ -902,12 +906,12 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
           const bool x6 = !c.h->no_conv_x6;                       // the split-bf16 planes ride along: launch_conv1d picks conv_x6.hip
           ConvProb p = c.prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
           p.pre_act = PRE_LRELU; p.slope = 0.1f;
-          if (x6 && m.rb[i][j][d][0].wx_off >= 0) p.w6 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off));
+          p.w6 = (x6 && m.rb[i][j][d][0].wx_off >= 0) ? reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off)) : nullptr;
           c1.p[jj] = p;
           p = c.prob(m.rb[i][j][d][1], tmp, cur, Lo, 1);
           p.pre_act = PRE_LRELU; p.slope = 0.1f;
           p.res = xin; p.res_mode = RES_ADD;
-          if (x6 && m.rb[i][j][d][1].wx_off >= 0) p.w6 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][1].wx_off));
+          p.w6 = (x6 && m.rb[i][j][d][1].wx_off >= 0) ? reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][1].wx_off)) : nullptr;
           c2.p[jj] = p;
         }
         c.conv(c1, "dec.resblock.convs1");

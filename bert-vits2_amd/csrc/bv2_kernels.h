@@ -11,6 +11,19 @@ namespace bv2 {
 
 // Raise a kernel's dynamic-LDS limit ONCE per (device, kernel) instead of on every launch: the attribute call is a driver round trip
 // on the batch-1 latency path (~20 launchers x several launches per step).  Remembers the largest size granted so far.
+// Batch-item -> XCD affinity: workgroup `id` of a 1-D launch runs on XCD id & 7; it takes item b = 8 * (slot / per) + (id & 7) and the
+// r-th workgroup of that item, slot = id >> 3, r = slot % per.  Returns false for the padding workgroups of a batch that is not a
+// multiple of 8 (uniform per workgroup: safe to exit on).
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool xcd_decode(unsigned id, int per, int B, int& b, int& r) {
+  const unsigned slot = id >> 3;
+  b = (int)(slot / (unsigned)per) * 8 + (int)(id & 7u);
+  r = (int)(slot % (unsigned)per);
+  return b < B;
+}
+#endif
+inline int xcd_grid(int B, int per) { return 8 * ((B + 7) / 8) * per; }
+
 inline void ensure_dyn_lds(const void* kern, size_t lds) {
   if (lds <= 64 * 1024) return;
   static std::mutex mu;
@@ -298,7 +311,11 @@ struct HcProb {
 // out[b][t][16*mt + j] = fp16( tanh(v[j]) * sigmoid(v[j+16]) ), `out` has cout/2 channels (out_bstride = cout/2 * L).
 // A launch carries 1 or 2 problems (blockIdx.z) with the same cin / k / dil / cout_pad and input form: the two row halves of
 // res_skip_layers (x update in place, skip sum), reference modules.py:203-210.
-struct HcLaunch { HcProb p[2]; int nprob = 1; int B, L; unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
+// xcd_b = 1: batch item b runs on XCD b % 8 (a 1-D launch of 8 * ceil(B / 8) * workgroups-per-item, workgroup id -> XCD id & 7 is the
+// hardware's round-robin): the kernels of an Encoder layer then hand a batch item's tensors on inside ONE XCD's L2 (the eight L2s are not
+// coherent: a tile produced on another XCD comes back through the fabric).  Same switch in LnArgs / AttnArgs; see xcd_decode.
+struct HcLaunch { HcProb p[2]; int nprob = 1; int B, L; unsigned long long* dbg = nullptr;   // dbg: tools/timeline.py only
+                  int xcd_b = 0; int xcd_gx = 0, xcd_per = 0; };    // xcd_gx / xcd_per: filled by the launcher
 int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name);
 void conv_f16_set_tuning(int generic);                       // tests / tuning only (bv2_test_set_variants)
 bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl);
@@ -339,6 +356,7 @@ struct LnArgs {
   // range r) behind conv_o; ml [B][ml_H][ml_ks][2][T] holds the range's softmax (max, sum) per query.  v = sum_{h,r} w_{h,r} slab
   // + bias[c] (conv_o's bias) + add (the residual), w_{h,r} = l_r e^{m_r - M_h} / sum_r' l_r' e^{m_r' - M_h}  (AttnArgs::ksplit)
   const float* ml; int ml_H, ml_ks; const float* bias;
+  int xcd_b; int xcd_per;             // batch item -> XCD affinity (HcLaunch::xcd_b); xcd_per: filled by the launcher
 };
 int launch_layernorm(hipStream_t stream, const LnArgs& a);
 
@@ -416,6 +434,7 @@ struct AttnArgs {
   // ml_out [B][H][ksplit][2][T]; the consumer (LnArgs::ml) merges the slabs with the flash-decoding weights
   int ksplit = 1; float* ml_out = nullptr;
   unsigned long long* dbg = nullptr;   // tools/timeline.py only
+  int xcd_b = 0; int xcd_gx = 0, xcd_per = 0;   // batch item -> XCD affinity (HcLaunch::xcd_b); xcd_gx / xcd_per: filled by the launcher
 };
 int attention_pick_ksplit(int B, int H, int T, int max_slabs);   // key ranges per (head, query tile) that fill the chip at small batch
 int launch_attention(hipStream_t stream, const AttnArgs& a);

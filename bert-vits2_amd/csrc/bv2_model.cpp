@@ -303,6 +303,9 @@ int pack_all(Model& m, Packer& P) {
   m.tone_emb = P.vec("enc_p.tone_emb.weight", {c.n_tones, hid});
   m.lang_emb = P.vec("enc_p.language_emb.weight", {c.n_languages, hid});
   const char* bn[3] = {"enc_p.bert_proj", "enc_p.ja_bert_proj", "enc_p.en_bert_proj"};
+  // (Round 5, measured and not kept: these convs also as split-bf16 planes so that at batch >= 16, where they leave the split-K regime,
+  // they take conv_x6.hip — config 3 15.12 / 15.08 -> 15.06 / 15.08 ms, nothing, for +42 MB of blob: N = 128 columns per batch item gives
+  // the 64x128 / 128x64 tiles one or two column tiles per item; profiles/r05_ab_x6_enc_not_kept.txt.)
   for (int i = 0; i < 3; ++i) m.bert[i] = P.conv1d(bn[i], hid, c.bert_dim, 1);
   m.enc = pack_encoder(P, "enc_p.encoder", hid, filt, c.n_heads, c.n_layers, c.kernel_size, gin);
   m.proj_m = P.conv1d("enc_p.proj", 2 * inter, hid, 1, true, false, 0, inter);

@@ -68,8 +68,14 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps everything derived from it in SGPRs
   const int l31 = lane & 31, lh = lane >> 5;
   const int KS = A.ksplit > 1 ? A.ksplit : 1;
-  const int kr = KS > 1 ? (int)blockIdx.x % KS : 0;          // this workgroup's key range
-  const int b = blockIdx.z, h = blockIdx.y, i0 = (KS > 1 ? (int)blockIdx.x / KS : (int)blockIdx.x) * AQ;
+  int b = blockIdx.z, h = blockIdx.y, bx = blockIdx.x;
+  if (A.xcd_b) {                                             // batch item -> XCD affinity (bv2_kernels.h xcd_decode)
+    int r;
+    if (!xcd_decode(blockIdx.x, A.xcd_per, A.B, b, r)) return;
+    bx = r % A.xcd_gx; h = r / A.xcd_gx;
+  }
+  const int kr = KS > 1 ? bx % KS : 0;                       // this workgroup's key range
+  const int i0 = (KS > 1 ? bx / KS : bx) * AQ;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;  // timeline stamps (tools/timeline.py; A.dbg is null in the product)
   if (A.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int T = A.T, W = A.W, NR = 2 * W + 1, ld = A.ld;
@@ -491,6 +497,10 @@ static int launch_attn_variant2(hipStream_t stream, const AttnArgs& a, dim3 grid
   auto kern = attention_kernel<DT, NW, F16, ONE>;
   ensure_dyn_lds((const void*)kern, lds);
   AttnArgs at = a;
+  if (a.xcd_b) {
+    at.xcd_gx = (int)grid.x; at.xcd_per = (int)(grid.x * grid.y);
+    grid = dim3(xcd_grid(a.B, at.xcd_per), 1, 1);
+  }
   at.dbg = timeline_slice(grid.x, grid.y, grid.z, 77000 + 10 * DT + NW, 0, a.D, a.T);    // tile id 77xxx: attention
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, at);
   return hipGetLastError() == hipSuccess ? 0 : -1;

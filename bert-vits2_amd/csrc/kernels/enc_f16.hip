@@ -128,23 +128,28 @@ __device__ __forceinline__ void hc_gemm_tm(f32x16 (&acc)[NI], const uint16_t* wb
   }
 }
 
-// fp32 [C][T] rows -> fp16 channels-last LDS tile (rows tb .. tb+rows-1, channels c0 .. c0+ck-1), x mask, zero padding
+// fp32 [C][T] rows -> fp16 channels-last LDS tile (rows tb .. tb+rows-1, channels c0 .. c0+ck-1), x mask, zero padding.
+// Round 5: a lane loads FOUR consecutive time steps of its two channels as one 16-byte load each (a wave instruction = 4 time quads x 16
+// channel pairs = 16 time steps x 32 channels; a channel row is read in 64-byte segments as before, with a quarter of the load
+// instructions), rounds, and writes four (channel pair) words to rows 4 tq .. 4 tq + 3.  Rows of x are only 4-byte aligned in general
+// (T_y is arbitrary): the vector type says so, and the hardware's unaligned-access mode serves a dwordx4 at any dword address.  The
+// scalar form (one 4-byte load per element, 54 load instructions per lane for a 132-row x 192-channel tile) was 16-26k cycles of a
+// 39-57k-cycle workgroup at B = 32 (tools/timeline.py, profiles/r05_timeline_c3_f16_convs.txt).
+typedef float hc_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 template <int NT>
 __device__ __forceinline__ void hc_stage_ct(unsigned short* xs, int pitch, const float* x, int x_rstride, const float* mask,
                                             int tb, int rows, int c0, int ck, int Lin, int tid) {
   const int lane = tid & 63, wid = tid >> 6;
-  const int tl = lane & 15, cq = lane >> 4;       // 16 time steps x 4 channel pairs per wave instruction
-  const int tblocks = (rows + 15) >> 4, cblocks = ck >> 3;
+  const int tq = lane & 3, cp = lane >> 2;        // 4 time quads x 16 channel pairs per wave instruction
+  const int tblocks = (rows + 15) >> 4, cblocks = (ck + 31) >> 5;
   const int units = tblocks * cblocks;
   constexpr int NWV = NT / 64;
   unsigned* xs32 = reinterpret_cast<unsigned*>(xs);
   const int p32 = pitch >> 1;
-  // HQ units per thread in flight per batch: with batches of 4 a 192-channel x 132-row tile took 7 SERIAL global round trips
-  // (~4.6k cycles each under load, tools/timeline.py) — four times the MFMA time of the FFN conv it feeds
-  constexpr int HQ = 14;
+  constexpr int HQ = 7;                           // units per thread in flight per batch: a 132-row x 192-channel tile in ONE round trip with 8 waves
   for (int u0 = wid; u0 < units; u0 += HQ * NWV) {
-    float a[HQ], b[HQ], m[HQ];
-    int dst[HQ];
+    float a[HQ][4], b[HQ][4], m[HQ][4];
+    int dst[HQ], r0[HQ];
     bool wr[HQ];
 #pragma unroll
     for (int q = 0; q < HQ; ++q) {
@@ -152,21 +157,41 @@ __device__ __forceinline__ void hc_stage_ct(unsigned short* xs, int pitch, const
       const bool inb = u < units;
       u = inb ? u : units - 1;
       const int cbk = u / tblocks, tbk = u - cbk * tblocks;
-      const int r = tbk * 16 + tl;
+      const int r = tbk * 16 + tq * 4;
       const int t = tb + r;
-      const bool ok = t >= 0 && t < Lin;
-      const int tc = t < 0 ? 0 : (t >= Lin ? Lin - 1 : t);           // clamped: the loads are unconditional
-      const int c = c0 + cbk * 8 + cq * 2;
-      const float* src = x + (int64_t)c * x_rstride + tc;
-      a[q] = src[0];
-      b[q] = src[x_rstride];
-      m[q] = ok ? (mask ? mask[tc] : 1.f) : 0.f;
-      wr[q] = inb && r < rows;
-      dst[q] = r * p32 + cbk * 4 + cq;
+      int cl = cbk * 32 + cp * 2;                  // channel inside the chunk (ck is a multiple of 16: a pair never straddles its end)
+      const bool cok = cl < ck;
+      cl = cok ? cl : 0;
+      const float* src = x + (int64_t)(c0 + cl) * x_rstride;
+      if (t >= 0 && t + 4 <= Lin) {
+        const hc_f32x4u va = *reinterpret_cast<const hc_f32x4u*>(src + t);
+        const hc_f32x4u vb = *reinterpret_cast<const hc_f32x4u*>(src + x_rstride + t);
+        hc_f32x4u vm = hc_f32x4u{1.f, 1.f, 1.f, 1.f};
+        if (mask) vm = *reinterpret_cast<const hc_f32x4u*>(mask + t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[q][i] = va[i]; b[q][i] = vb[i]; m[q][i] = vm[i]; }
+      } else {                                     // a quad that straddles [0, Lin): element by element, clamped
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ti = t + i;
+          const bool ok = ti >= 0 && ti < Lin;
+          const int tc = ti < 0 ? 0 : (ti >= Lin ? Lin - 1 : ti);
+          a[q][i] = src[tc];
+          b[q][i] = src[x_rstride + tc];
+          m[q][i] = ok ? (mask ? mask[tc] : 1.f) : 0.f;
+        }
+      }
+      wr[q] = inb && cok;
+      r0[q] = r;
+      dst[q] = r * p32 + (cl >> 1);
     }
 #pragma unroll
     for (int q = 0; q < HQ; ++q)
-      if (wr[q]) xs32[dst[q]] = h_pack(a[q] * m[q], b[q] * m[q]);
+      if (wr[q]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (r0[q] + i < rows) xs32[dst[q] + i * p32] = h_pack(a[q][i] * m[q][i], b[q][i] * m[q][i]);
+      }
   }
 }
 
@@ -203,16 +228,25 @@ template <int WN, int NI, bool IN_CT, bool OUT_CT, int G>   // G > 0: every chun
 __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, const int ngrp) {
   constexpr int NT = 64 * WN, BT = 32 * NI;
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
-  const HcProb& P = L.p[blockIdx.z];
+  int b, cg, tile, pz = blockIdx.z;
+  if (L.xcd_b) {                                                    // batch item -> XCD affinity (bv2_kernels.h xcd_decode)
+    int r;
+    if (!xcd_decode(blockIdx.x, L.xcd_per, L.B, b, r)) return;
+    tile = r % L.xcd_gx; r /= L.xcd_gx;
+    cg = r % ngrp; pz = r / ngrp;
+  } else {
+    b = blockIdx.y / ngrp;
+    cg = blockIdx.y - b * ngrp;
+    tile = blockIdx.x;
+  }
+  const HcProb& P = L.p[pz];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
   if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
-  const int b = blockIdx.y / ngrp;
-  const int cg = blockIdx.y - b * ngrp;
   const int mt = cg * WN + wid;
-  const int t0 = blockIdx.x * BT;
+  const int t0 = tile * BT;
   const int cin = P.cin, k = P.k, dil = P.dil;
   const int rows = BT + (k - 1) * dil;
   const bool active = mt * 32 < P.cout_pad;
@@ -406,6 +440,10 @@ static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   auto kern = conv_f16_kernel<WN, NI, IN_CT, OUT_CT, G>;
   ensure_dyn_lds((const void*)kern, lds);
   HcLaunch Lt = L;
+  if (L.xcd_b) {
+    Lt.xcd_gx = (int)grid.x; Lt.xcd_per = (int)grid.x * ngrp * L.nprob;
+    grid = dim3(xcd_grid(L.B, Lt.xcd_per), 1, 1);
+  }
   Lt.dbg = L.nprob > 1 ? nullptr : timeline_slice(grid.x, grid.y, 1, 99000 + WN * 100 + NI * 10 + (IN_CT ? 2 : 0) + (OUT_CT ? 1 : 0), p.k, p.cin, L.L);   // 99xxx: fp16 conv
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN), lds, stream, Lt, ngrp);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -24,8 +24,9 @@ template <int CPT, int NSLAB, int MODE, bool GUARD, int KS = 0>   // CPT channel
 __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
   __shared__ float red[2][4][LN_TT];               // [pass][wave][time step]
   const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 3;
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * LN_TT + tx;
+  int b = blockIdx.y, tile = blockIdx.x;
+  if (A.xcd_b && !xcd_decode(blockIdx.x, A.xcd_per, A.B, b, tile)) return;   // batch item -> XCD affinity (bv2_kernels.h)
+  const int t = tile * LN_TT + tx;
   const bool tok = t < A.T;
   const int tcl = tok ? t : A.T - 1;
   const int C = A.C, T = A.T;
@@ -205,9 +206,14 @@ int launch_layernorm(hipStream_t stream, const LnArgs& a) {
   if (a.mode == 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8) return -1;
   if (a.ml && (a.mode != 0 || (ns != 4 && ns != 8) || (a.ml_ks != 2 && a.ml_ks != 4) || a.ml_H * a.ml_ks != ns)) return -1;
   dim3 grid((a.T + LN_TT - 1) / LN_TT, a.B);
-  if (a.C == 6 * LN_G) launch_ln_cfg<6, false>(stream, a, grid);          // hidden_channels 192
-  else if (a.C == 8 * LN_G) launch_ln_cfg<8, false>(stream, a, grid);     // DurationPredictor filter 256
-  else launch_ln_cfg<8, true>(stream, a, grid);
+  LnArgs ax = a;
+  if (a.xcd_b) {
+    ax.xcd_per = (int)grid.x;
+    grid = dim3(xcd_grid(a.B, ax.xcd_per), 1, 1);
+  }
+  if (a.C == 6 * LN_G) launch_ln_cfg<6, false>(stream, ax, grid);         // hidden_channels 192
+  else if (a.C == 8 * LN_G) launch_ln_cfg<8, false>(stream, ax, grid);    // DurationPredictor filter 256
+  else launch_ln_cfg<8, true>(stream, ax, grid);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

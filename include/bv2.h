@@ -30,7 +30,7 @@ extern "C" {
 
 #define BV2_ABI_VERSION 3   /* 3: bv2_decode_in.nz_tstride, the six ONNX-seam stage calls, bv2_detach_weights,
                                pack-layout version in the blob header */
-#define BV2_PACK_LAYOUT 12   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
+#define BV2_PACK_LAYOUT 13   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
                                a blob cached on disk by an older packer is rejected by bv2_attach_weights */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
@@ -261,6 +261,9 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "resblock_c16"    1 (default): the C = 16 bf16 stage's whole-ResBlock launch on v_mfma_f32_16x16x32_bf16 (two taps x 16 channels per
  *                     instruction, unpadded 32-byte LDS rows, two workgroups per CU: kernels/resblock_c16_bf16.hip); 0: the 32x32x16
  *                     whole-ResBlock kernel (resblock_cl_bf16.hip), whose MFMA block is half zero padding at this width
+ *   "xcd_affine"      1 (default): in the fp16 Encoder stacks at batch >= 16, batch item b runs on XCD b % 8 in EVERY kernel of a layer (q/k/v,
+ *                     attention, conv_o, LayerNorms, FFN convs), so a layer's tensors are handed on inside one XCD's L2 (the eight L2s are
+ *                     not coherent with each other); 0: plain grids
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)

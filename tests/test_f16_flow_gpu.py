@@ -198,3 +198,28 @@ def test_wn_flow_f16_sits_at_the_reference_autocast_level():
     m.set_flow_dtype(torch.float32)
     o32 = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), w_ceil=gold["w_ceil"], **kw)[0]
     assert rms((o32.cpu() - gold["o"])[vm]) < 5e-5                      # the fp32 path is untouched by the switch
+
+
+@pytest.mark.parametrize("B,Ty", [(16, 77), (35, 40), (32, 384)])
+def test_xcd_affine_placement_changes_nothing_but_the_placement(B, Ty):
+    """Round 5: at batch >= 16 the fp16 Encoder stacks run batch item b on XCD b % 8 in every kernel of a layer (1-D launches decoded by
+    xcd_decode, bv2_kernels.h).  Only WHERE a workgroup runs changes: the flow output is bit-identical to the plain grids', for a batch
+    that is a multiple of 8 and for one that is not (padding workgroups exit), ragged lengths included."""
+    hp, seed, *_ = cases.build_case("zh_b1_t24")
+    m = _gpu_model(hp, seed)
+    m.set_flow_dtype(torch.float16)
+    g = torch.Generator().manual_seed(B * 1000 + Ty)
+    lens = torch.randint(1, Ty + 1, (B,), generator=g)
+    lens[0] = Ty
+    ym = (torch.arange(Ty)[None, :] < lens[:, None])[:, None, :].float()
+    z_p = (torch.randn(B, hp.inter_channels, Ty, generator=g) * ym).cuda()
+    gv = torch.randn(B, hp.gin_channels, 1, generator=g).cuda()
+    outs = []
+    for v in (0, 1):
+        m.set_option("xcd_affine", v)
+        outs.append(m.stage_flow(z_p, lens.cuda(), gv))
+    torch.cuda.synchronize()
+    m.set_option("xcd_affine", 1)
+    m.set_flow_dtype(torch.float32)
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1])
