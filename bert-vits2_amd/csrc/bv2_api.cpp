@@ -644,6 +644,104 @@ int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_
   } catch (...) { return -100; }
 }
 
+// ---- direct kernel-level entries for the round-4 fused kernels (they were only held to the layer-wise kernels)
+int bv2_test_respair_cl(void* stream, const void* x, void* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                        int C, int k, int dil, int L, float slope, int form, const int64_t* lens) {
+  try {
+    if (!respair_cl_bf16_supported(C, k, dil)) return -2;
+    const int64_t ne = cl_w_elems(C, C, k);
+    std::vector<uint16_t> pk((size_t)2 * ne, 0);
+    for (int e = 0; e < 2; ++e)
+      for (int co = 0; co < C; ++co)
+        for (int ci = 0; ci < C; ++ci)
+          for (int j = 0; j < k; ++j)
+            pk[(size_t)e * ne + (size_t)cl_w_index(j, ci, co, C, k)] = t_f2bf(w_host[(((size_t)e * C + co) * C + ci) * k + j]);
+    char* base = static_cast<char*>(wpack_dev);
+    const size_t wbytes = pk.size() * 2 + 8192, boff = (wbytes + 255) / 256 * 256;     // + slack: the rings run a few units past a stream's end
+    if (hipMemset(base, 0, boff + (size_t)2 * C * 4) != hipSuccess) return -6;
+    if (hipMemcpy(base, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    if (hipMemcpy(base + boff, bias_host, (size_t)2 * C * 4, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    RpClLaunch F;
+    std::memset(&F, 0, sizeof(F));
+    F.nprob = 1; F.B = B; F.C = C; F.L = L; F.slope = slope; F.lens = lens; F.len_mul = 1; F.form = form; F.mix = 1;
+    RpClProb& q = F.p[0];
+    q.x = static_cast<const uint16_t*>(x); q.out = static_cast<uint16_t*>(out);
+    q.w1 = reinterpret_cast<const uint16_t*>(base); q.w2 = q.w1 + ne;
+    q.b1 = reinterpret_cast<const float*>(base + boff); q.b2 = q.b1 + C;
+    q.k = k; q.dil = dil;
+    return launch_respair_cl_bf16(static_cast<hipStream_t>(stream), F, nullptr);
+  } catch (...) { return -100; }
+}
+int64_t bv2_test_respair_cl_pack_bytes(int C, int k) { return cl_w_elems(C, C, k) * 4 + 8192 + 256 + (int64_t)2 * C * 4; }
+
+int64_t bv2_test_respair_x6_pack_bytes(int C, int k) { return x6_w_elems(C, (C + 31) / 32 * 32, k) * 4 + 16384 + 256 + (int64_t)2 * 32 * 4 + (int64_t)2 * C * 4; }
+int bv2_test_respair_x6(void* stream, const float* x, float* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                        int C, int k, int dil, int L, float slope, const int64_t* lens) {
+  try {
+    if (!respair_x6_supported(C, k, dil)) return -2;
+    const int cout_pad = t_round_up(C, 32);
+    const int64_t ne = x6_w_elems(C, cout_pad, k);
+    std::vector<uint16_t> pk((size_t)2 * ne, 0);
+    for (int e = 0; e < 2; ++e)
+      for (int co = 0; co < C; ++co)
+        for (int ci = 0; ci < C; ++ci)
+          for (int j = 0; j < k; ++j) {
+            uint16_t h3[3];
+            x6_split(w_host[(((size_t)e * C + co) * C + ci) * k + j], h3);
+            for (int pl = 0; pl < 3; ++pl) pk[(size_t)e * ne + (size_t)x6_w_index(j, ci, co, C, k, pl)] = h3[pl];
+          }
+    std::vector<float> pb((size_t)2 * cout_pad, 0.f);
+    for (int e = 0; e < 2; ++e)
+      for (int co = 0; co < C; ++co) pb[(size_t)e * cout_pad + co] = bias_host[(size_t)e * C + co];
+    char* base = static_cast<char*>(wpack_dev);
+    const size_t wbytes = pk.size() * 2 + 16384, boff = (wbytes + 255) / 256 * 256;
+    if (hipMemset(base, 0, boff + pb.size() * 4) != hipSuccess) return -6;
+    if (hipMemcpy(base, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    if (hipMemcpy(base + boff, pb.data(), pb.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    FusedLaunch F;
+    std::memset(&F, 0, sizeof(F));
+    F.nprob = 1; F.B = B; F.C = C; F.L = L; F.slope = slope; F.lens = lens; F.len_mul = 1;
+    FusedProb& q = F.p[0];
+    q.x = x; q.out = out; q.k = k; q.dil = dil;
+    q.w61 = reinterpret_cast<const uint16_t*>(base); q.w62 = q.w61 + ne;
+    q.b1 = reinterpret_cast<const float*>(base + boff); q.b2 = q.b1 + cout_pad;
+    q.w1 = q.b1; q.w2 = q.b1;                        // the fp32 streams are not read by this kernel
+    return launch_respair_x6(static_cast<hipStream_t>(stream), F);
+  } catch (...) { return -100; }
+}
+
+int bv2_test_flow_boundary(void* stream, const float* a, int nslab, int64_t slab_stride, const float* gamma, const float* beta,
+                           const float* mask, float* x1, int64_t z_bstride, const float* post_w_host, const float* post_b_host,
+                           const float* pre_w_host, const float* pre_b_host, float* pre_out, float* wpack_dev, int B, int C, int T) {
+  try {
+    const int C1 = C / 2;
+    // two 1x1 convs in the packed conv layout (conv_w_index, k = 1): post C -> C1, pre C1 -> C
+    const size_t npost = (size_t)t_round_up(C, 16) * t_round_up(C1, 128), npre = (size_t)t_round_up(C1, 16) * t_round_up(C, 128);
+    std::vector<float> pk(npost + npre + (size_t)C1 + (size_t)C + 64, 0.f);
+    for (int co = 0; co < C1; ++co)
+      for (int ci = 0; ci < C; ++ci) pk[(size_t)conv_w_index(0, ci, co, t_round_up(C, 16), 1)] = post_w_host[(size_t)co * C + ci];
+    if (pre_w_host)
+      for (int co = 0; co < C; ++co)
+        for (int ci = 0; ci < C1; ++ci) pk[npost + (size_t)conv_w_index(0, ci, co, t_round_up(C1, 16), 1)] = pre_w_host[(size_t)co * C1 + ci];
+    for (int co = 0; co < C1; ++co) pk[npost + npre + co] = post_b_host[co];
+    if (pre_b_host)
+      for (int co = 0; co < C; ++co) pk[npost + npre + C1 + co] = pre_b_host[co];
+    if (hipMemcpy(wpack_dev, pk.data(), pk.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    FbArgs F;
+    std::memset(&F, 0, sizeof(F));
+    F.a = a; F.nslab = nslab; F.slab_stride = slab_stride; F.gamma = gamma; F.beta = beta; F.eps = 1e-5f; F.mask = mask;
+    F.x1 = x1; F.x1_out = x1; F.z_bstride = z_bstride; F.post_w = wpack_dev; F.post_b = wpack_dev + npost + npre;
+    if (pre_w_host) { F.pre_w = wpack_dev + npost; F.pre_b = wpack_dev + npost + npre + C1; F.pre_out = pre_out; }
+    F.B = B; F.C = C; F.T = T; F.C1 = C1;
+    if (!flow_boundary_supported(F)) return -2;
+    return launch_flow_boundary(static_cast<hipStream_t>(stream), F);
+  } catch (...) { return -100; }
+}
+int64_t bv2_test_flow_boundary_pack_floats(int C) {
+  const int C1 = C / 2;
+  return (int64_t)t_round_up(C, 16) * t_round_up(C1, 128) + (int64_t)t_round_up(C1, 16) * t_round_up(C, 128) + C1 + C + 64;
+}
+
 int64_t bv2_test_conv_cl_pack_bytes(int cin, int cout, int k) {
   return cl_w_elems(cin, t_round_up(cout, 32), k) * 2 + (int64_t)t_round_up(cout, 32) * 4;
 }

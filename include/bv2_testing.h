@@ -56,6 +56,27 @@ int64_t bv2_test_resblock_cl_pack_bytes(int C, int k, int nd);
 int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
                          int C, int k, const int* dil, int nd, int L, float slope, int variant, const int64_t* lens);
 
+/* ONE (dilated conv, conv) pair of ResBlock1 with its residual in one launch, bf16 channels-last (kernels/respair_cl_bf16.hip): x / out
+ * DEVICE bf16 [B][L][C] (out != x), C = 32 / 64 / 128 / 256; w_host [2][C][C][k] (index 0 = the dilated conv), bias_host [2][C] HOST fp32;
+ * form 1 = 64-channel x 128-row wave tiles on the swizzled tile (C >= 64), 0 = 32-channel waves on the padded tile; lens optional DEVICE
+ * int64 [B]; wpack_dev needs bv2_test_respair_cl_pack_bytes(C, k) bytes */
+int64_t bv2_test_respair_cl_pack_bytes(int C, int k);
+int bv2_test_respair_cl(void* stream, const void* x, void* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                        int C, int k, int dil, int L, float slope, int form, const int64_t* lens);
+/* the same pair in fp32 with both convs on the bf16 matrix core from exact three-way splits (kernels/respair_x6.hip): x / out DEVICE fp32
+ * [B][C][L], C = 16 / 32 / 64 / 128; the packer splits w_host into its three bf16 planes (x6_split) */
+int64_t bv2_test_respair_x6_pack_bytes(int C, int k);
+int bv2_test_respair_x6(void* stream, const float* x, float* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                        int C, int k, int dil, int L, float slope, const int64_t* lens);
+/* the flow's coupling boundary in one launch (kernels/flow_boundary.hip): h = LayerNorm_C(sum of nslab slabs a [B][C][T]) * mask;
+ * x1 [C/2 rows][T] (inside z, z_bstride floats per item) = (x1 - post(h) - post_b) * mask in place; pre_out [B][C][T] = (pre(x1) + pre_b) *
+ * mask unless pre_w_host is NULL.  post_w_host [C/2][C], pre_w_host [C][C/2] HOST fp32; every other pointer DEVICE; wpack_dev needs
+ * bv2_test_flow_boundary_pack_floats(C) floats.  C = 192 only (-2 otherwise). */
+int64_t bv2_test_flow_boundary_pack_floats(int C);
+int bv2_test_flow_boundary(void* stream, const float* a, int nslab, int64_t slab_stride, const float* gamma, const float* beta,
+                           const float* mask, float* x1, int64_t z_bstride, const float* post_w_host, const float* post_b_host,
+                           const float* pre_w_host, const float* pre_b_host, float* pre_out, float* wpack_dev, int B, int C, int T);
+
 /* fp16 Encoder conv (kernels/enc_f16.hip).  in_ct: x is DEVICE fp32 [B][cin][L] (in_mask [B][L] optional) else fp16 [B][L][cin];
  * out_ct: out is DEVICE fp32 [B][cout][out_rstride] (res like out, res_mode 0/1/2 = none/add/rsub) else fp16 [B][L][cout];
  * w_host [cout][cin][k], bias_host [cout] HOST fp32; wpack_dev needs bv2_test_conv_cl_pack_bytes(cin, cout, k) bytes;
