@@ -154,6 +154,11 @@ class BertEncoder:
         out["encoder.relative_index"] = _relative_index_table(self._buckets, self._max_rel, self._span, self._max_pos)
         return out
 
+    def set_option(self, key: str, value: int) -> None:
+        """``bv2_bert_set_option`` (include/bv2_bert.h): kernel-selection switches for A/B measurements, e.g. ``"prefetch"``."""
+        if self._lib.bv2_bert_set_option(self._h, key.encode(), int(value)) != 0:
+            raise ValueError(self._err())
+
     def replica(self) -> "BertEncoder":
         """A second handle (own workspace, usable on another HIP stream) on the SAME packed weights: request-level concurrency
         (``serving.replicas`` does this for the synthesizer)."""

@@ -57,6 +57,7 @@ struct bv2_bert {
   int64_t tab = -1, conv_g = -1, conv_b = -1;           // DeBERTa-v2: relative index table, ConvLayer LayerNorm
   Lin conv;                                             // DeBERTa-v2 ConvLayer (k = conv_kernel_size)
   std::vector<LayerW> layer;
+  int prefetch = 3;                                     // bv2_bert_set_option("prefetch"): bit 0 LayerNorm / embedding launches, bit 1 GEMM launches carry the next GEMM's weights
   bool deberta() const { return cfg.arch == BV2_BERT_ARCH_DEBERTA_V2; }
   std::set<std::string> packed, wanted;
   int D() const { return cfg.hidden_size / cfg.num_heads; }
@@ -303,6 +304,13 @@ static BertPlan plan(const bv2_bert* h, Carve& A, int B, int S) {
   return p;
 }
 
+int bv2_bert_set_option(bv2_bert* h, const char* key, int value) {
+  if (!h || !key) return -1;
+  if (std::string(key) == "prefetch") { h->prefetch = value & 3; return 0; }
+  h->err = std::string("bv2_bert_set_option: unknown key ") + key;
+  return -1;
+}
+
 int64_t bv2_bert_workspace_bytes(const bv2_bert* h, int B, int S) {
   if (!h || B < 1 || S < 1) return -1;
   Carve A(nullptr, 0);
@@ -328,6 +336,11 @@ int bv2_bert_forward(bv2_bert* h, void* stream, int B, int S, const int64_t* inp
 
     const bool deb = h->deberta();
     if (deb && S > c.max_position) { h->err = "bv2_bert_forward: S exceeds the relative-position table (max_position)"; return -1; }
+    // the packed stream of a GEMM's weights as a prefetch target (bv2_kernels.h Prefetch): batch 1 only
+    auto pf_of = [&](const Lin* l, int bit) -> Prefetch {
+      if (!l || B != 1 || !(h->prefetch & bit) || l->w_off < 0) return Prefetch{nullptr, 0};
+      return Prefetch{W + l->w_off, (unsigned)((int64_t)(l->cout_pad / 32) * (l->cin_pad / 8) * l->k * 1024)};
+    };
     float* x_in = P.emb ? P.emb : P.x;               // layer 0 reads the embeddings from here (kept for the DeBERTa ConvLayer)
     BertEmbedArgs e;
     e.input_ids = input_ids; e.token_type_ids = token_type_ids;
@@ -335,12 +348,13 @@ int bv2_bert_forward(bv2_bert* h, void* stream, int B, int S, const int64_t* inp
     e.lengths = deb ? lengths : nullptr;             // DebertaV2Embeddings multiplies by the mask, BertEmbeddings does not
     e.gamma = W + h->emb_g; e.beta = W + h->emb_b; e.eps = c.layer_norm_eps;
     e.out = x_in; e.B = B; e.S = S; e.C = C; e.vocab = c.vocab_size; e.max_pos = c.max_position; e.type_vocab = c.type_vocab_size;
+    if (c.num_layers_run > 0) e.pf = pf_of(&h->layer[0].qkv, 1);
     chk(launch_bert_embed_ln(s, e), "bert.embeddings");
     chk(launch_seq_mask(s, lengths, P.mask, B, S), "bert.mask");
 
     // y = W x + b as a k = 1 conv on [B][cin][S]; slabs > 1: K split across workgroups, the LayerNorm sums the partial slabs
     auto gemm = [&](const Lin& l, const float* x, float* y, int act, const float* res, bool slabs, int out_rs, int64_t out_bs,
-                    const char* what, const float* out_mask = nullptr) -> int {
+                    const char* what, const float* out_mask = nullptr, const Lin* next = nullptr) -> int {
       ConvLaunch cl;
       std::memset(&cl, 0, sizeof(cl));
       ConvProb& p = cl.p[0];
@@ -354,12 +368,15 @@ int bv2_bert_forward(bv2_bert* h, void* stream, int B, int S, const int64_t* inp
       p.k = l.k; p.dil = 1; p.pad_left = (l.k - 1) / 2; p.slope = 0.1f; p.act = act;
       p.out_mask = out_mask; p.mask_pre = out_mask ? 1 : 0;          // (act(Wx + b)) * mask, then + residual
       cl.nprob = 1; cl.B = B; cl.L = S; cl.ksplit = 1; cl.slab_stride = P.slab;
+      cl.pf = pf_of(next, 2);
       if (slabs && conv_use_splitk(cl)) cl.ksplit = conv_pick_ksplit(cl, 4);   // 4 slabs: measured 1.77 ms per forward against 1.91 (8) and 1.85 (2) at B = 1, S = 53
       chk(launch_conv1d(s, cl, TILE_AUTO, nullptr), what);
       return cl.ksplit;
     };
-    auto ln = [&](const float* a, int nslab, int64_t g, int64_t b, float* y, const char* what, const float* mask = nullptr) {
+    auto ln = [&](const float* a, int nslab, int64_t g, int64_t b, float* y, const char* what, const float* mask = nullptr,
+                  const Lin* next = nullptr) {
       BertLnArgs l;
+      l.pf = pf_of(next, 1);
       l.a = a; l.nslab = nslab; l.slab_stride = P.slab; l.gamma = W + g; l.beta = W + b; l.eps = c.layer_norm_eps; l.mask = mask;
       l.out = y; l.B = B; l.C = C; l.T = S;
       chk(launch_bert_ln(s, l), what);
@@ -371,7 +388,8 @@ int bv2_bert_forward(bv2_bert* h, void* stream, int B, int S, const int64_t* inp
       const float* xin = i == 0 ? x_in : P.x;
       const bool last = i + 1 == c.num_layers_run;
       const bool conv_here = deb && i == 0 && c.conv_kernel_size > 0;
-      gemm(L.qkv, xin, P.qkv, ACT_NONE, nullptr, false, P.ld, (int64_t)R * P.ld, "bert.qkv");
+      const Lin* next_qkv = (!last && !conv_here) ? &h->layer[i + 1].qkv : nullptr;
+      gemm(L.qkv, xin, P.qkv, ACT_NONE, nullptr, false, P.ld, (int64_t)R * P.ld, "bert.qkv", nullptr, &L.o);
       if (deb) {
         DebertaAttnArgs a;
         a.qkv = P.qkv; a.ld = P.ld; a.mask = P.mask; a.pk = W + L.pk; a.pq = W + L.pq; a.tab = W + h->tab; a.out = P.att;
@@ -384,10 +402,10 @@ int bv2_bert_forward(bv2_bert* h, void* stream, int B, int S, const int64_t* inp
         chk(launch_attention(s, a), "bert.attention");
       }
       int ns = gemm(L.o, P.att, P.s, ACT_NONE, xin, true, S, (int64_t)C * S, "bert.attention.output");
-      ln(P.s, ns, L.g1, L.b1, P.x1, "bert.attention.output.LayerNorm");
-      gemm(L.ffn1, P.x1, P.f1, ACT_GELU, nullptr, false, S, (int64_t)I * S, "bert.intermediate");
+      ln(P.s, ns, L.g1, L.b1, P.x1, "bert.attention.output.LayerNorm", nullptr, &L.ffn1);
+      gemm(L.ffn1, P.x1, P.f1, ACT_GELU, nullptr, false, S, (int64_t)I * S, "bert.intermediate", nullptr, &L.ffn2);
       ns = gemm(L.ffn2, P.f1, P.s, ACT_NONE, P.x1, true, S, (int64_t)C * S, "bert.output");
-      ln(P.s, ns, L.g2, L.b2, (last && !conv_here) ? out : P.x, "bert.output.LayerNorm");
+      ln(P.s, ns, L.g2, L.b2, (last && !conv_here) ? out : P.x, "bert.output.LayerNorm", nullptr, next_qkv);
       if (conv_here) {
         // DebertaV2Encoder.forward: after layer 0, output = ConvLayer(embeddings, layer-0 output, mask)
         //   = LayerNorm(layer0 + gelu(conv1d_k(embeddings)) [masked]) * mask     (conv_act = gelu; masked BEFORE the activation in HF:

@@ -103,10 +103,16 @@ struct Ctx {
     return L.ksplit;
   }
   int conv1(const ConvProb& p, int B, int L, const char* tag, int max_split = 1, int64_t slab_stride = 0,
-            const int64_t* lens = nullptr, int len_mul = 1) {
+            const int64_t* lens = nullptr, int len_mul = 1, Prefetch pf = Prefetch{nullptr, 0}) {
     ConvLaunch cl;
-    cl.p[0] = p; cl.nprob = 1; cl.B = B; cl.L = L; cl.lens = lens; cl.len_mul = len_mul;
+    cl.p[0] = p; cl.nprob = 1; cl.B = B; cl.L = L; cl.lens = lens; cl.len_mul = len_mul; cl.pf = pf;
     return conv(cl, tag, max_split, slab_stride);
+  }
+  // the packed fp32 stream of a conv (m-tile-major: what the split-K kernel's XCDs read in contiguous eighths) as a prefetch target;
+  // bit 0 of the "prefetch" option: LayerNorm launches carry one, bit 1: split-K launches do.  Batch 1 only.
+  Prefetch pf_of(const ConvW& w, int B, int bit) const {
+    if (B != 1 || !(h->prefetch & bit) || w.w_off < 0) return Prefetch{nullptr, 0};
+    return Prefetch{W(w.w_off), (unsigned)((int64_t)(w.cout_pad / 32) * (w.cin_pad / 8) * w.k * 1024)};
   }
   // fp16 Encoder conv (kernels/enc_f16.hip) on dense tensors: in_ct/out_ct select fp32 [B][C][T] vs fp16 [B][T][C]
   HcProb hprob(const ConvW& w, const void* x, bool in_ct, void* out, bool out_ct, int L) const {
@@ -220,8 +226,9 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     l.a = b.s; l.nslab = ns; l.slab_stride = b.slab;
     l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T; l.xcd_b = xcd ? 1 : 0;
     if (ks > 1) { l.ml = b.ml; l.ml_H = e.heads; l.ml_ks = ks; l.bias = c.W(L.o.b_off); l.add = b.x; }
+    if (!f16) l.pf = c.pf_of(L.ffn1, B, 1);                       // the FFN's first weight set lands in L2 under this LayerNorm
     c.ln(l, "enc.ln1");
-    l.ml = nullptr; l.bias = nullptr; l.add = nullptr; l.ml_H = l.ml_ks = 0;
+    l.ml = nullptr; l.bias = nullptr; l.add = nullptr; l.ml_H = l.ml_ks = 0; l.pf = Prefetch{nullptr, 0};
     if (f16) {
       // FFN (attentions.py:438-446): hidden activation relu(conv_1(x*mask))*mask kept as fp16 channels-last in b.f1
       HcProb q = c.hprob(L.ffn1, b.x, true, b.f1, false, T);
@@ -234,12 +241,13 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     } else {
       p = c.prob(L.ffn1, b.x, b.f1, T);
       p.in_mask = mask; p.act = ACT_RELU;
-      c.conv1(p, B, T, "enc.ffn1");
+      c.conv1(p, B, T, "enc.ffn1", 1, 0, nullptr, 1, c.pf_of(L.ffn2, B, 2));   // conv_2's weights under conv_1 (whose own are in L2 by now)
       p = c.prob(L.ffn2, b.f1, b.s, T);
       p.in_mask = mask; p.out_mask = mask; p.mask_pre = 1; p.res = b.x; p.res_mode = RES_ADD;
       ns = c.conv1(p, B, T, "enc.ffn2", kSlabs, b.slab);
     }
     l.a = b.s; l.nslab = ns; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off);
+    if (!f16 && i + 1 < e.n_layers) l.pf = c.pf_of(e.layer[i + 1].qkv, B, 1);   // the next layer's q/k/v projection
     if (i + 1 == kCondLayer && i + 1 < e.n_layers) { l.vec = spk; l.vec_bstride = spk_bstride; l.mask = mask; }
     if (i + 1 == e.n_layers) {
       l.mask = mask;

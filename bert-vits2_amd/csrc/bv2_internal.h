@@ -129,6 +129,7 @@ struct bv2_handle {
   bool no_conv_x6 = false;           // "conv_x6" = 0: wide Generator convs on the fp32 matrix core (conv_mfma.hip) instead of the bf16x6 form
   bool x6_narrow = true;             // "conv_x6_c32" = 0: the C = 32 stage on the fused fp32 pair kernel instead of layer-wise on conv_x6.hip
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
+  int prefetch = 0;                  // "prefetch": bit 0 LayerNorm launches, bit 1 split-K launches carry the next launch's weight stream (batch 1); measured: nothing at config 2 (profiles/r05_ab_prefetch_c2.txt), off
   bool no_xcd_affine = false;        // "xcd_affine" = 0: plain grids for the fp16 Encoder stacks (default: batch item b on XCD b % 8 at B >= 16)
   bool no_resblock_c16 = false;      // "resblock_c16" = 0: the C = 16 bf16 stage on the 32x32x16 whole-ResBlock kernel (resblock_cl_bf16.hip) instead of resblock_c16_bf16.hip
   bool no_respair_c32 = false;       // "respair_c32" = 0: the C = 32 bf16 stage as whole-ResBlock launches (resblock_cl_bf16.hip) instead of pair by pair

@@ -24,6 +24,34 @@ __device__ __forceinline__ bool xcd_decode(unsigned id, int per, int B, int& b, 
 #endif
 inline int xcd_grid(int B, int per) { return 8 * ((B + 7) / 8) * per; }
 
+// Weight prefetch tail (round 5).  In the small-N regime (batch 1, one BERT sentence) every launch is a dependent ~10 us kernel whose
+// first act is to pull its weights (0.5-17 MB) from HBM / the Infinity Cache, while the launch in front of it (a LayerNorm on 7-48
+// workgroups, or a GEMM whose own weights are already on chip) leaves HBM idle.  A launch can therefore carry `pf`: the NEXT launch's
+// weight stream, which PF_BLOCKS spare workgroups of THIS launch touch line by line (one dword per 128-byte line) so that it sits in L2
+// when the consumer starts.  XCD-local: the split-K kernel gives XCD x the x-th eighth of the m-tiles (its virtual ids are contiguous per
+// XCD and the packed stream is m-tile-major), so the prefetch workgroup with hardware id l (XCD l & 7) touches the same eighth.
+struct Prefetch { const void* ptr; unsigned bytes; };
+constexpr int PF_BLOCKS = 128;                       // 16 per XCD
+#if defined(__HIPCC__)
+// l: the workgroup's linear hardware id, j: its index among the PF_BLOCKS prefetch workgroups (both wave-uniform)
+__device__ __forceinline__ void prefetch_tail(const Prefetch pf, unsigned l, unsigned j, unsigned tid, unsigned nthreads) {
+  const unsigned lines = (pf.bytes + 127u) >> 7;
+  const unsigned lx = (lines + 7u) >> 3;                          // lines per XCD region
+  const unsigned per = PF_BLOCKS / 8, lc = (lx + per - 1u) / per; // lines per workgroup
+  const unsigned xcd = l & 7u, c = j >> 3;
+  const unsigned l0 = xcd * lx + c * lc;
+  unsigned l1 = l0 + lc;
+  if (l1 > (xcd + 1u) * lx) l1 = (xcd + 1u) * lx;
+  if (l1 > lines) l1 = lines;
+  const char* base = static_cast<const char*>(pf.ptr);
+  for (unsigned i = l0 + tid; i < l1; i += nthreads) {
+    unsigned sink;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(base + (size_t)i * 128u) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#endif
+
 inline void ensure_dyn_lds(const void* kern, size_t lds) {
   if (lds <= 64 * 1024) return;
   static std::mutex mu;
@@ -102,6 +130,7 @@ struct ConvLaunch {
   int ksplit;               // split-K kernel only: K split across workgroups into `ksplit` partial slabs (1 = none)
   int64_t slab_stride;      // floats between the partial slabs of one output (slab z is written at out + z*slab_stride)
   unsigned long long* dbg = nullptr;   // tools/timeline.py only: 8 u64 per workgroup (s_memtime stamps + HW ids); null in the product
+  Prefetch pf = {nullptr, 0};          // split-K kernel only: the NEXT launch's weight stream, touched by PF_BLOCKS spare workgroups
 };
 // tools/timeline.py: while a device buffer is set, every conv launch records per-workgroup timestamps into its own slice of it
 void conv_set_timeline(unsigned long long* dev_buf, long long capacity_u64);
@@ -357,6 +386,7 @@ struct LnArgs {
   // + bias[c] (conv_o's bias) + add (the residual), w_{h,r} = l_r e^{m_r - M_h} / sum_r' l_r' e^{m_r' - M_h}  (AttnArgs::ksplit)
   const float* ml; int ml_H, ml_ks; const float* bias;
   int xcd_b; int xcd_per;             // batch item -> XCD affinity (HcLaunch::xcd_b); xcd_per: filled by the launcher
+  Prefetch pf;                        // B == 1 only: the next launch's weight stream (Prefetch above); ptr null = none
 };
 int launch_layernorm(hipStream_t stream, const LnArgs& a);
 
@@ -388,6 +418,7 @@ struct BertEmbedArgs {
   const float* gamma; const float* beta; float eps;
   float* out;                                                  // [B][C][S]
   int B, S, C, vocab, max_pos, type_vocab;
+  Prefetch pf = {nullptr, 0};                                  // B == 1: the first q/k/v projection's weights
 };
 int launch_bert_embed_ln(hipStream_t stream, const BertEmbedArgs& a);
 struct BertLnArgs {
@@ -396,6 +427,7 @@ struct BertLnArgs {
   const float* mask;                                           // null, or [B][T] multiplied into the output (DeBERTa-v2 ConvLayer)
   float* out;
   int B, C, T;
+  Prefetch pf = {nullptr, 0};                                  // B == 1: the next GEMM's weights
 };
 int launch_bert_ln(hipStream_t stream, const BertLnArgs& a);
 // DeBERTa-v2 disentangled attention (kernels/deberta_attn.hip)

@@ -17,6 +17,11 @@ __global__ void __launch_bounds__(256) bert_embed_ln_kernel(const BertEmbedArgs 
   __shared__ float red[2][4];
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int C = A.C, S = A.S;
+  if (A.pf.ptr) {                                   // B == 1: tokens padded to a multiple of 8, then PF_BLOCKS spare workgroups (Prefetch)
+    const unsigned n8 = ((unsigned)S + 7u) & ~7u;
+    if (blockIdx.x >= n8) { prefetch_tail(A.pf, blockIdx.x, blockIdx.x - n8, threadIdx.x, 256); return; }
+    if (s >= S) return;
+  }
   int64_t id = A.input_ids[(int64_t)b * S + s];
   id = id < 0 ? 0 : (id >= A.vocab ? A.vocab - 1 : id);             // clamped like every gather in libbv2 (a bad id must not fault)
   int64_t tt = A.token_type_ids ? A.token_type_ids[(int64_t)b * S + s] : 0;
@@ -64,7 +69,13 @@ __global__ void __launch_bounds__(256) bert_embed_ln_kernel(const BertEmbedArgs 
 
 int launch_bert_embed_ln(hipStream_t stream, const BertEmbedArgs& a) {
   if (a.C < 1 || a.C > 2048 || a.S < 1 || a.B < 1) return -1;
-  hipLaunchKernelGGL(bert_embed_ln_kernel, dim3(a.S, a.B), dim3(256), 0, stream, a);
+  if (a.pf.ptr && a.pf.bytes && a.B == 1) {
+    hipLaunchKernelGGL(bert_embed_ln_kernel, dim3(((a.S + 7) & ~7) + PF_BLOCKS, 1), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  BertEmbedArgs a2 = a;
+  a2.pf = Prefetch{nullptr, 0};
+  hipLaunchKernelGGL(bert_embed_ln_kernel, dim3(a.S, a.B), dim3(256), 0, stream, a2);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -83,8 +94,13 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   __shared__ float red[2][16][TT];
   const int tx = threadIdx.x & (TT - 1), ty = threadIdx.x / TT;
   const int b = blockIdx.y;
-  const int t = blockIdx.x * TT + tx;
   const int C = A.C, T = A.T;
+  if (A.pf.ptr) {                                   // B == 1: token tiles padded to a multiple of 8, then PF_BLOCKS spare workgroups (Prefetch)
+    const unsigned nt8 = ((unsigned)(T + TT - 1) / TT + 7u) & ~7u;
+    if (blockIdx.x >= nt8) { prefetch_tail(A.pf, blockIdx.x, blockIdx.x - nt8, threadIdx.x, 1024); return; }
+    if ((int)blockIdx.x * TT >= T) return;
+  }
+  const int t = blockIdx.x * TT + tx;
   const bool tok = t < T;
   const int tcl = tok ? t : T - 1;
   const int64_t base = (int64_t)b * C * T;
@@ -144,14 +160,18 @@ __global__ void __launch_bounds__(1024) bert_ln_kernel(const BertLnArgs A) {
   }
 }
 
-int launch_bert_ln(hipStream_t stream, const BertLnArgs& a) {
+int launch_bert_ln(hipStream_t stream, const BertLnArgs& a0) {
   constexpr int BLN_G = 128;                        // channel groups of the 8-token form
-  if (a.C < BLN_G || a.C % BLN_G || a.C > 8 * BLN_G || a.T < 1 || a.B < 1 || a.nslab < 1) return -1;
-  if ((int64_t)a.C * a.T >= (1ll << 31)) return -1;
+  if (a0.C < BLN_G || a0.C % BLN_G || a0.C > 8 * BLN_G || a0.T < 1 || a0.B < 1 || a0.nslab < 1) return -1;
+  if ((int64_t)a0.C * a0.T >= (1ll << 31)) return -1;
   // few tokens (one short sentence): 2-token workgroups, 4x the CUs (measured: profiles/r03_*bert*)
-  const bool narrow = (int64_t)a.B * a.T <= 128 && a.C % 512 == 0 && a.C <= 1024 && (a.nslab == 1 || a.nslab == 2 || a.nslab == 4);
+  const bool narrow = (int64_t)a0.B * a0.T <= 128 && a0.C % 512 == 0 && a0.C <= 1024 && (a0.nslab == 1 || a0.nslab == 2 || a0.nslab == 4);
+  BertLnArgs a = a0;
+  const bool pf = a.pf.ptr && a.pf.bytes && a.B == 1;
+  if (!pf) a.pf = Prefetch{nullptr, 0};
   if (narrow) {
     dim3 grid((a.T + 1) / 2, a.B);
+    if (pf) grid = dim3(((grid.x + 7) & ~7u) + PF_BLOCKS, 1);
 #define BLN2(CPT_, NS_) hipLaunchKernelGGL((bert_ln_kernel<CPT_, NS_, 2>), grid, dim3(1024), 0, stream, a)
     if (a.C == 512) { if (a.nslab == 1) BLN2(1, 1); else if (a.nslab == 2) BLN2(1, 2); else BLN2(1, 4); }
     else { if (a.nslab == 1) BLN2(2, 1); else if (a.nslab == 2) BLN2(2, 2); else BLN2(2, 4); }
@@ -159,6 +179,7 @@ int launch_bert_ln(hipStream_t stream, const BertLnArgs& a) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   dim3 grid((a.T + 7) / 8, a.B);
+  if (pf) grid = dim3(((grid.x + 7) & ~7u) + PF_BLOCKS, 1);
   const int cpt = a.C / BLN_G;
 #define BLN_LAUNCH(CPT_, NS_) hipLaunchKernelGGL((bert_ln_kernel<CPT_, NS_, 8>), grid, dim3(1024), 0, stream, a)
 #define BLN_CPT(CPT_)                                                                                  \

@@ -392,6 +392,10 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(red_raw);   // [NWV][32][33]; LDSX: aliases the X tile (barrier between)
   // XCD-aware placement: consecutive virtual ids (which share a weight slice) land on the same XCD
   const int bid = blockIdx.x;
+  if (bid >= per_xcd * 8) {                                         // spare workgroups: the next launch's weights into this XCD's L2
+    prefetch_tail(L.pf, (unsigned)bid, (unsigned)(bid - per_xcd * 8), threadIdx.x, 64 * NWV);
+    return;
+  }
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
   if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
   const int v = (bid & 7) * per_xcd + (bid >> 3);
@@ -821,7 +825,7 @@ static int launch_splitk(hipStream_t stream, const ConvLaunch& L0, int max_cout_
   for (int i = 0; i < L.nprob; ++i)
     if (L.p[i].act == ACT_GATE && nw == 16) nw = 8;   // the gate pairs rows inside one thread: at most 16 rows per pass
   if (variant_name) *variant_name = nw == 16 ? "conv1d_splitk<32x32,16w>" : (nw == 8 ? "conv1d_splitk<32x32,8w>" : "conv1d_splitk<32x32,4w>");
-  const dim3 grid(per_xcd * 8);
+  const dim3 grid(per_xcd * 8 + (L.pf.ptr && L.pf.bytes ? PF_BLOCKS : 0));
   // LDSX form: every problem has taps to re-use (k > 1), the staged tile fits (32 + (k-1)*dil <= SK_XP columns, <= SK_RPW rows
   // per wave) and a lane's 32-bit byte offsets reach every element
   bool ldsx = !g_tune_no_ldsx;

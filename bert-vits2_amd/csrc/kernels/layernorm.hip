@@ -26,6 +26,11 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const LnArgs A) {
   const int tx = threadIdx.x & (LN_TT - 1), ty = threadIdx.x >> 3;
   int b = blockIdx.y, tile = blockIdx.x;
   if (A.xcd_b && !xcd_decode(blockIdx.x, A.xcd_per, A.B, b, tile)) return;   // batch item -> XCD affinity (bv2_kernels.h)
+  if (!A.xcd_b && A.pf.ptr) {                                                // B == 1: tiles padded to a multiple of 8, then PF_BLOCKS spare workgroups
+    const unsigned nt8 = ((unsigned)(A.T + LN_TT - 1) / LN_TT + 7u) & ~7u;
+    if (blockIdx.x >= nt8) { prefetch_tail(A.pf, blockIdx.x, blockIdx.x - nt8, threadIdx.x, 256); return; }
+    if (tile * LN_TT >= A.T) return;
+  }
   const int t = tile * LN_TT + tx;
   const bool tok = t < A.T;
   const int tcl = tok ? t : A.T - 1;
@@ -210,6 +215,11 @@ int launch_layernorm(hipStream_t stream, const LnArgs& a) {
   if (a.xcd_b) {
     ax.xcd_per = (int)grid.x;
     grid = dim3(xcd_grid(a.B, ax.xcd_per), 1, 1);
+    ax.pf = Prefetch{nullptr, 0};
+  } else if (a.pf.ptr && a.pf.bytes && a.B == 1) {
+    grid = dim3(((grid.x + 7) & ~7u) + PF_BLOCKS, 1);
+  } else {
+    ax.pf = Prefetch{nullptr, 0};
   }
   if (a.C == 6 * LN_G) launch_ln_cfg<6, false>(stream, ax, grid);         // hidden_channels 192
   else if (a.C == 8 * LN_G) launch_ln_cfg<8, false>(stream, ax, grid);    // DurationPredictor filter 256

@@ -124,6 +124,7 @@ SYMBOLS = [
     ("bv2_bert_pack_tensor", C.c_int, [_P, _P, C.c_int64, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
     ("bv2_bert_missing", C.c_int, [_P]),
     ("bv2_bert_attach_weights", C.c_int, [_P, _P, C.c_int64]),
+    ("bv2_bert_set_option", C.c_int, [_P, C.c_char_p, C.c_int]),
     ("bv2_bert_workspace_bytes", C.c_int64, [_P, C.c_int, C.c_int]),
     ("bv2_bert_forward", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64]),
 ]

@@ -261,6 +261,11 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "resblock_c16"    1 (default): the C = 16 bf16 stage's whole-ResBlock launch on v_mfma_f32_16x16x32_bf16 (two taps x 16 channels per
  *                     instruction, unpadded 32-byte LDS rows, two workgroups per CU: kernels/resblock_c16_bf16.hip); 0: the 32x32x16
  *                     whole-ResBlock kernel (resblock_cl_bf16.hip), whose MFMA block is half zero padding at this width
+ *   "prefetch"        default 0 (measured: within noise at config 2 — the batch-1 launches do not wait for their weights; the BERT extractor,
+ *                     where it is worth 0.6 %, has it on: bv2_bert_set_option).  Batch 1 (small-N regime): bit 0 — a LayerNorm launch carries the NEXT launch's weight stream (FFN conv_1 behind
+ *                     LayerNorm-1, the next layer's q/k/v projection behind LayerNorm-2), bit 1 — a split-K conv launch does (conv_2 behind
+ *                     conv_1): 128 spare workgroups touch it line by line into the L2 of the XCD whose workgroups will read it
+ *                     (bv2_kernels.h Prefetch).  0: every launch fetches its own weights from HBM / the Infinity Cache when it starts
  *   "xcd_affine"      1 (default): in the fp16 Encoder stacks at batch >= 16, batch item b runs on XCD b % 8 in EVERY kernel of a layer (q/k/v,
  *                     attention, conv_o, LayerNorms, FFN convs), so a layer's tensors are handed on inside one XCD's L2 (the eight L2s are
  *                     not coherent with each other); 0: plain grids

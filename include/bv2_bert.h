@@ -75,6 +75,11 @@ int bv2_bert_pack_tensor(bv2_bert* h, void* host_blob, int64_t blob_bytes, const
 /* Number of tensors the blob still misses (0 = complete); names via bv2_bert_last_error when > 0. */
 int bv2_bert_missing(bv2_bert* h);
 
+/* Kernel-selection switches for A/B measurements.  "prefetch" (default 3; batch 1 only): bit 0 — the embedding / LayerNorm launches, bit 1 —
+ * the GEMM launches carry the NEXT GEMM's packed weight stream, which spare workgroups touch into the L2 of the XCD that will read it, so
+ * a 12-17 MB weight set is on chip when its GEMM starts (bv2_kernels.h Prefetch).  0: every GEMM fetches its weights when it starts. */
+int bv2_bert_set_option(bv2_bert* h, const char* key, int value);
+
 /* Attach the blob after the caller copied it to DEVICE memory (the library never allocates). */
 int bv2_bert_attach_weights(bv2_bert* h, const void* dev_blob, int64_t bytes);
 
