@@ -102,6 +102,9 @@ struct Model {
   // the C = 16 stage once more in the tap-pair layout of kernels/resblock_c16_bf16.hip (rb16_w_index); -1 elsewhere
   int64_t rb16_w_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
   int64_t rb16_b_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
+  // the C = 64 / C = 32 stages as whole-ResBlock streams of kernels/resblock_sw_bf16.hip (rbsw_w_index); -1 elsewhere
+  int64_t rbsw_w_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
+  int64_t rbsw_b_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
   VecW conv_post;
   int post_c = 0, post_k = 7;
   int total_up = 1;
@@ -131,6 +134,7 @@ struct bv2_handle {
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
   int prefetch = 0;                  // "prefetch": bit 0 LayerNorm launches, bit 1 split-K launches carry the next launch's weight stream (batch 1); measured: nothing at config 2 (profiles/r05_ab_prefetch_c2.txt), off
   bool no_xcd_affine = false;        // "xcd_affine" = 0: plain grids for the fp16 Encoder stacks (default: batch item b on XCD b % 8 at B >= 16)
+  int resblock_sw = 0;               // "resblock_sw": bit 0 the C = 64, bit 1 the C = 32 bf16 stage as whole-ResBlock launches (resblock_sw_bf16.hip) instead of pair by pair; measured slower (profiles/r05_ab_resblock_sw_not_kept.txt): off
   bool no_resblock_c16 = false;      // "resblock_c16" = 0: the C = 16 bf16 stage on the 32x32x16 whole-ResBlock kernel (resblock_cl_bf16.hip) instead of resblock_c16_bf16.hip
   bool no_respair_c32 = false;       // "respair_c32" = 0: the C = 32 bf16 stage as whole-ResBlock launches (resblock_cl_bf16.hip) instead of pair by pair
   int respair_form = 1;              // "respair_form": 1 = 64 x 128 wave tiles (respair2_cl_bf16_kernel), 0 = 32-channel waves

@@ -282,6 +282,19 @@ inline int64_t rb16_w_index(int j, int ci, int co) {            // tap j, input 
 bool resblock_c16_bf16_supported(int C, int k, const int* dil, int nd);
 int launch_resblock_c16_bf16(hipStream_t stream, const RbClLaunch& L);
 
+// ... and for C = 64 / C = 32 on v_mfma_f32_32x32x16_bf16 with unpadded XOR-swizzled LDS rows (kernels/resblock_sw_bf16.hip, round 5): a wave
+// owns NB 32-row blocks x all C output channels.  Same RbClLaunch, but
+//   w    : [conv c = 2 d + e][tap j][16-channel group g][32-row tile mt][lane 64][8 bf16] (rbsw_w_index; a tap's fragments contiguous)
+//   bias : fp32 [2*nd][C]
+inline int64_t rbsw_w_index(int c, int j, int ci, int co, int C, int k) {
+  const int G = C / 16, MT = C / 32;
+  const int lane = (co & 31) + 32 * ((ci % 16) / 8);
+  return (((((int64_t)c * k + j) * G + ci / 16) * MT + co / 32) * 64 + lane) * 8 + (ci % 8);
+}
+bool resblock_sw_bf16_supported(int C, int k, const int* dil, int nd);
+int64_t resblock_sw_bf16_w_elems(int C, int k, int nd);
+int launch_resblock_sw_bf16(hipStream_t stream, const RbClLaunch& L);
+
 // one (dilated conv, conv) pair of ResBlock1 with its residual at C = 64 / 128 / 256 in one launch, bf16 channels-last, the
 // intermediate in LDS (kernels/respair_cl_bf16.hip).  x / out: [B][L][C], out != x; w1 / w2: the convs' ordinary fragment streams
 // (cl_w_index), b1 / b2 fp32 [C]; conv1 has dilation dil, conv2 dilation 1, both k taps.

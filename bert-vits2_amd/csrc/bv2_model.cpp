@@ -466,6 +466,25 @@ int pack_all(Model& m, Packer& P) {
             }
         }
       }
+      // C = 64 / 32: the whole-ResBlock stream of resblock_sw_bf16.hip ([conv][tap][group][m-tile] fragments), same bf16 values
+      m.rbsw_w_off[i][j] = m.rbsw_b_off[i][j] = -1;
+      if (m.n_rbd <= BV2_RBCL_MAX_D && resblock_sw_bf16_supported(ch, k, c.resblock_dilation_sizes[j], m.n_rbd)) {
+        const int64_t ne = resblock_sw_bf16_w_elems(ch, k, m.n_rbd);
+        m.rbsw_w_off[i][j] = P.alloc((ne + 1) / 2 + 2048);          // + slack: nothing reads past the stream, kept for symmetry with the rings
+        m.rbsw_b_off[i][j] = P.alloc((int64_t)2 * m.n_rbd * ch);
+        if (P.fill()) {
+          uint16_t* dst = reinterpret_cast<uint16_t*>(P.blob + m.rbsw_w_off[i][j]);
+          for (int d = 0; d < m.n_rbd; ++d)
+            for (int e = 0; e < 2; ++e) {
+              const ConvW& cw = m.rb[i][j][d][e];
+              const uint16_t* src = reinterpret_cast<const uint16_t*>(P.blob + cw.wb_off);
+              for (int co = 0; co < ch; ++co)
+                for (int ci = 0; ci < ch; ++ci)
+                  for (int j2 = 0; j2 < k; ++j2) dst[rbsw_w_index(2 * d + e, j2, ci, co, ch, k)] = src[cl_w_index(j2, ci, co, ch, k)];
+              std::memcpy(P.blob + m.rbsw_b_off[i][j] + (2 * d + e) * ch, P.blob + cw.b_off, sizeof(float) * (size_t)ch);
+            }
+        }
+      }
       // C = 16: the tap-pair stream of resblock_c16_bf16.hip, rearranged from the per-conv bf16 stream just written (same bf16 values)
       m.rb16_w_off[i][j] = m.rb16_b_off[i][j] = -1;
       if (m.n_rbd <= BV2_RBCL_MAX_D && resblock_c16_bf16_supported(ch, k, c.resblock_dilation_sizes[j], m.n_rbd)) {

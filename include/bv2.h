@@ -30,7 +30,7 @@ extern "C" {
 
 #define BV2_ABI_VERSION 3   /* 3: bv2_decode_in.nz_tstride, the six ONNX-seam stage calls, bv2_detach_weights,
                                pack-layout version in the blob header */
-#define BV2_PACK_LAYOUT 13   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
+#define BV2_PACK_LAYOUT 14   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
                                a blob cached on disk by an older packer is rejected by bv2_attach_weights */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
@@ -269,6 +269,10 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "xcd_affine"      1 (default): in the fp16 Encoder stacks at batch >= 16, batch item b runs on XCD b % 8 in EVERY kernel of a layer (q/k/v,
  *                     attention, conv_o, LayerNorms, FFN convs), so a layer's tensors are handed on inside one XCD's L2 (the eight L2s are
  *                     not coherent with each other); 0: plain grids
+ *   "resblock_sw"     default 0 (pair by pair, respair_cl_bf16.hip).  Bit 0 — the C = 64, bit 1 — the C = 32 bf16 stage as ONE whole-ResBlock launch
+ *                     per stage on unpadded XOR-swizzled LDS rows (two tensor passes per branch instead of six: kernels/resblock_sw_bf16.hip).
+ *                     Bit-identical to the pair kernels; measured SLOWER at B = 32 (C = 64: 2.58 against 2.17 ms per step, C = 32: 1.44
+ *                     against 1.36) — kept as an option and as the record of the experiment
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
