@@ -532,7 +532,7 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
           pk[(size_t)conv_w_index(j, ci, co, cin_pad, k)] = w_host[((size_t)co * cin + ci) * k + j];
     const size_t boff = (size_t)k * cin_pad * ld;
     if (w_host && bias_host) for (int co = 0; co < cout; ++co) pk[boff + co] = bias_host[co];
-    const bool x6 = tile >= TILE_X6 && cin % 32 == 0;
+    const bool x6 = tile >= TILE_X6 && cin % (tile == TILE_SPLITK_X6 ? 16 : 32) == 0;
     if (w_host && x6) {
       uint16_t* wx = reinterpret_cast<uint16_t*>(pk.data() + t_x6_off(cin, cout, k));
       for (int j = 0; j < k; ++j)

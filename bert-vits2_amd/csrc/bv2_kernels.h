@@ -141,7 +141,8 @@ unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int ti
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6, TILE_128x64 = 7,
        TILE_X6 = 8,            // the split-bf16 form of the LDS-tiled kernel (kernels/conv_x6.hip); TILE_AUTO picks it when every problem has w6
-       TILE_X6_128x64 = 9, TILE_X6_128x64_LD = 10, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12 };   // tests / tuning: one x6 tile forced
+       TILE_X6_128x64 = 9, TILE_X6_128x64_LD = 10, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12,     // tests / tuning: one x6 tile forced
+       TILE_SPLITK_X6 = 13 };  // the split-K kernel's split-bf16 form (kernels/splitk_x6.hip); TILE_AUTO picks it in the small-N regime when the problem has w6
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 // fp32 conv on the bf16 matrix core (kernels/conv_x6.hip): every fp32 operand is the exact sum of three bf16 values
 // (v = h1 + h2 + h3, 8 + 8 + 8 significand bits), and the product is accumulated from the six largest of the nine cross terms
@@ -175,6 +176,8 @@ inline void x6_split(float v, uint16_t h[3]) {
   }
 }
 bool conv_x6_supported(const ConvLaunch& L);        // every problem carries w6 and fits the staged tile
+bool splitk_x6_supported(const ConvLaunch& L);      // kernels/splitk_x6.hip: one problem with w6, whole 16-channel groups, <= 64 staged columns
+int launch_splitk_x6(hipStream_t stream, const ConvLaunch& L, const char** variant_name);
 int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 void conv_x6_occupancy(int out[4]);                              // workgroups per CU granted to {128x64, 128x64 + loaders, 64x128, 32x256}
 void conv_x6_set_tuning(int t256, int t128, int t64, int ck);   // tuning experiments only (tools/tune_x6.py); 0 = shipped choice

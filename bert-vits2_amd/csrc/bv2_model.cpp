@@ -260,6 +260,10 @@ EncoderW pack_encoder(Packer& P, const std::string& p, int hidden, int filter, i
     L.g1 = P.vec(p + ".norm_layers_1." + std::to_string(i) + ".gamma", {hidden});
     L.b1 = P.vec(p + ".norm_layers_1." + std::to_string(i) + ".beta", {hidden});
     const std::string f = p + ".ffn_layers." + std::to_string(i);
+    // (Round 5, measured and not kept: these two convs also as the three split-bf16 planes, so that at batch 1 their split-K launches
+    // run on kernels/splitk_x6.hip — config 2 3.611 / 3.596 -> 3.584 / 3.588 ms for +195 MB of blob: a split-K launch at batch 1 is 10k
+    // ticks of prologue (first bytes of x and of the weights), 10k of K loop and 2k of epilogue behind a ~3 us launch gap, and only the
+    // loop gets shorter; profiles/r05_ab_splitk_x6_not_kept.txt.  The kernel stays, with its tests, behind TILE_SPLITK_X6.)
     L.ffn1 = P.conv1d(f + ".conv_1", filter, hidden, ksize);
     L.ffn2 = P.conv1d(f + ".conv_2", hidden, filter, ksize);
     L.g2 = P.vec(p + ".norm_layers_2." + std::to_string(i) + ".gamma", {hidden});
