@@ -29,7 +29,12 @@ import os
 import sys
 import time
 
-import torch
+# Kernel arguments in DEVICE memory: the ROCm 7 default on this part, stated here because the batch-1 step is ~190 dependent launches
+# whose first instruction is a scalar load from the kernarg segment — with host-resident kernargs (=0) the same step takes 4.29 ms
+# instead of 3.64 (profiles/r05_hip_force_dev_kernarg.txt).  Must be in the environment before the HIP runtime loads.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
