@@ -1,5 +1,6 @@
 // bv2_api.cpp — the extern "C" surface declared in include/bv2.h.
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -30,12 +31,16 @@ int bv2_create(const bv2_config* cfg, bv2_handle** out) {
   try {
     h = new bv2_handle();
     std::memset(&h->model.cfg, 0, sizeof(bv2_config));
-    if (cfg->struct_bytes != (int32_t)sizeof(bv2_config)) {
+    // the struct grew by one trailing field (resblock_type, round 5): the shorter form is still accepted and means ResBlock1
+    const int32_t old_bytes = (int32_t)offsetof(bv2_config, resblock_type);
+    if (cfg->struct_bytes != (int32_t)sizeof(bv2_config) && cfg->struct_bytes != old_bytes) {
       g_create_err = "bv2_create: bv2_config.struct_bytes mismatch (ABI drift)";
       delete h;
       return -1;
     }
-    h->model.cfg = *cfg;
+    std::memcpy(&h->model.cfg, cfg, (size_t)cfg->struct_bytes);
+    h->model.cfg.struct_bytes = (int32_t)sizeof(bv2_config);
+    if (h->model.cfg.resblock_type == 0) h->model.cfg.resblock_type = 1;
     std::string err;
     if (int rc = build_layout(h->model, err)) {
       g_create_err = "bv2_create: " + err;

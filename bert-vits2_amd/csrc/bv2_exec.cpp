@@ -849,10 +849,11 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
     }
     // the n_rbk ResBlock1 branches run side by side
     const int nb = m.n_rbk;
-    bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock;
+    const bool rb2 = m.rb_type == 2;
+    bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock && !rb2;
     // C = 32: two split-bf16 launches per pair (HBM-bound, 5 tensor passes) against one fused fp32-MFMA launch (MFMA-bound, 3 passes)
     // C = 32 with the planes packed: the pair in ONE launch on the bf16 matrix core (respair_x6.hip: two passes AND the fast pipe)
-    bool x6pair = nb <= 3 && !c.h->no_fused_resblock && !c.h->no_conv_x6 && !c.h->no_x6_pair &&
+    bool x6pair = !rb2 && nb <= 3 && !c.h->no_fused_resblock && !c.h->no_conv_x6 && !c.h->no_x6_pair &&
                   (U.cout == 32 || (U.cout == 16 && !c.h->no_x6_pair_c16) || (U.cout == 64 && !c.h->no_x6_pair_c64) ||
                    (U.cout == 128 && c.h->x6_pair_c128));
     for (int j = 0; j < nb && x6pair; ++j)
@@ -865,7 +866,28 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
       for (int d = 0; d < m.n_rbd; ++d)
         fused = fused && resblock_fused_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
     float* branch_out[BV2_MAX_RESBLOCK_KERNELS];
-    if (fused) {
+    if (rb2) {
+      // modules.ResBlock2 (reference modules.py:348-357): for each of the two dilations x = x + conv_d(lrelu(x)) — one conv per launch
+      // with the residual in its epilogue, the branches side by side; branch j ping-pongs between S[1 + nb + j] and S[1 + j] and ends in S[1 + j]
+      for (int d = 0; d < m.n_rbd; ++d) {
+        ConvLaunch c1;
+        c1.nprob = nb; c1.B = B; c1.L = Lo; c1.lens = lens; c1.len_mul = up * U.u;
+        const bool to_cur = ((m.n_rbd - 1 - d) & 1) == 0;
+        for (int jj = 0; jj < nb; ++jj) {
+          const int j = nb - 1 - jj;                            // widest kernel first
+          float* cur = S[1 + j];
+          float* tmp = S[1 + nb + j];
+          const float* xin = d == 0 ? x : (to_cur ? tmp : cur);
+          ConvProb p = c.prob(m.rb[i][j][d][0], xin, to_cur ? cur : tmp, Lo, cf.resblock_dilation_sizes[j][d]);
+          p.pre_act = PRE_LRELU; p.slope = 0.1f;
+          p.res = xin; p.res_mode = RES_ADD;
+          p.w6 = (!c.h->no_conv_x6 && m.rb[i][j][d][0].wx_off >= 0) ? reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off)) : nullptr;
+          c1.p[jj] = p;
+        }
+        c.conv(c1, "dec.resblock2.conv");
+      }
+      for (int j = 0; j < nb; ++j) branch_out[j] = S[1 + j];
+    } else if (fused) {
       // narrow stages: ONE launch per dilation step = the whole (conv, conv) pair of every branch, intermediate in LDS;
       // the pair ping-pongs between the branch's two buffers (a tile reads its neighbours' halo: no in-place update)
       for (int j = 0; j < nb; ++j) branch_out[j] = nullptr;
@@ -1025,7 +1047,8 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     }
     tap_cl("dec.ups." + std::to_string(i), x, U.cout, Lo);
     const int nb = m.n_rbk;
-    bool whole = nb <= 3 && !c.h->no_fused_resblock;
+    const bool rb2 = m.rb_type == 2;
+    bool whole = nb <= 3 && !c.h->no_fused_resblock && !rb2;
     for (int j = 0; j < nb && whole; ++j) whole = m.rbcl_w_off[i][j] >= 0;
     // C = 32: pair by pair (respair_cl_bf16.hip, one wave owns all 32 channels) — six tensor passes per ResBlock instead of two, but
     // every launch streams near the HBM rate with three workgroups per CU, where the whole-ResBlock kernel's one resident workgroup
@@ -1033,7 +1056,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     // on a half-empty MFMA block: 1.49 -> 1.72 ms, not kept.)
     if (whole && U.cout == 32 && !c.h->no_respair_c32 && !c.h->no_fused_respair) whole = false;
     // C = 64 / 32 (round 5): the whole ResBlock on the unpadded swizzled tile (resblock_sw_bf16.hip) — two tensor passes per branch
-    bool sw = nb <= 3 && !c.h->no_fused_resblock && ((U.cout == 64 && (c.h->resblock_sw & 1)) || (U.cout == 32 && (c.h->resblock_sw & 2)));
+    bool sw = !rb2 && nb <= 3 && !c.h->no_fused_resblock && ((U.cout == 64 && (c.h->resblock_sw & 1)) || (U.cout == 32 && (c.h->resblock_sw & 2)));
     for (int j = 0; j < nb && sw; ++j) sw = m.rbsw_w_off[i][j] >= 0;
     if (sw) {
       RbClLaunch F;
@@ -1092,7 +1115,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     }
     // wide stages: one (dilated conv, conv) pair per launch, the intermediate in LDS (respair_cl_bf16.hip).  A tile's halo rows are
     // another tile's outputs, so a pair never runs in place: branch j ping-pongs between S[1 + j] and S[1 + nb + j] and ends in S[1 + j]
-    bool pairs = !whole && !sw && nb <= 3 && !c.h->no_fused_respair && !narrow_layerwise;
+    bool pairs = !rb2 && !whole && !sw && nb <= 3 && !c.h->no_fused_respair && !narrow_layerwise;
     for (int j = 0; j < nb && pairs; ++j)
       for (int d = 0; d < m.n_rbd && pairs; ++d)
         pairs = respair_cl_bf16_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]) &&
@@ -1126,7 +1149,23 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
         if (r) c.fail("dec.resblock.pair", r);
       }
     }
-    for (int d = 0; d < m.n_rbd && !whole && !pairs && !sw; ++d) {
+    for (int d = 0; d < m.n_rbd && rb2; ++d) {
+      // modules.ResBlock2 in bf16: x = bf16(conv_d(bf16(lrelu(x))) + x), one conv per launch, ending in S[1 + j]
+      ClLaunch c1;
+      c1.nprob = nb; c1.B = B; c1.L = Lo; c1.lens = lens; c1.len_mul = up * U.u;
+      const bool to_cur = ((m.n_rbd - 1 - d) & 1) == 0;
+      for (int jj = 0; jj < nb; ++jj) {
+        const int j = nb - 1 - jj;
+        uint16_t* cur = U16(S[1 + j]);
+        uint16_t* tmp = U16(S[1 + nb + j]);
+        const uint16_t* xin = d == 0 ? x : (to_cur ? tmp : cur);
+        ClProb p = prob(m.rb[i][j][d][0], xin, to_cur ? cur : tmp, Lo, cf.resblock_dilation_sizes[j][d]);
+        p.pre_lrelu = 1; p.res = xin;
+        c1.p[jj] = p;
+      }
+      launch(c1, "dec.resblock2.conv", flops_of(c1));
+    }
+    for (int d = 0; d < m.n_rbd && !rb2 && !whole && !pairs && !sw; ++d) {
       ClLaunch c1, c2;
       c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
       c1.lens = c2.lens = lens; c1.len_mul = c2.len_mul = up * U.u;

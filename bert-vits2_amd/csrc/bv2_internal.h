@@ -94,6 +94,7 @@ struct Model {
   ConvW conv_pre;
   GemvW dec_cond;
   int n_ups = 0, n_rbk = 0, n_rbd = 0;
+  int rb_type = 1;                   // 1 = ResBlock1 ((dilated conv, conv) pairs), 2 = ResBlock2 (one conv per dilation: rb[..][d][0] only)
   UpW ups[BV2_MAX_UPS];
   ConvW rb[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS][BV2_MAX_RESBLOCK_DILATIONS][2];
   // whole-ResBlock bf16 streams of the narrow stages (kernels/resblock_cl_bf16.hip); -1 where the stage is too wide

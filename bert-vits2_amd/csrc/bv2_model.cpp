@@ -387,7 +387,7 @@ int pack_all(Model& m, Packer& P) {
   P.emit_bf16 = true;
   m.conv_pre = P.conv1d("dec.conv_pre", c0, inter, 7);
   m.dec_cond = P.gemv("dec.cond", c0, gin, true);
-  m.n_ups = c.n_upsamples; m.n_rbk = c.n_resblock_kernels; m.n_rbd = c.n_resblock_dilations;
+  m.n_ups = c.n_upsamples; m.n_rbk = c.n_resblock_kernels; m.n_rbd = c.n_resblock_dilations; m.rb_type = c.resblock_type == 2 ? 2 : 1;
   m.total_up = 1;
   int ch = c0;
   for (int i = 0; i < m.n_ups; ++i) {
@@ -440,11 +440,21 @@ int pack_all(Model& m, Packer& P) {
       const std::string rp = "dec.resblocks." + std::to_string(i * m.n_rbk + j);
       // wide stages (the ones the LDS-tiled fp32 conv runs): the weights also as the three bf16 planes of conv_x6.hip
       P.emit_x6 = ch >= 16 && ch % 16 == 0;        // C = 16: the pair kernel only (respair_x6.hip; conv_x6.hip wants whole 32-channel chunks)
+      const bool rb2 = c.resblock_type == 2;       // modules.ResBlock2: one weight-normed conv per dilation, `convs.<d>`
       for (int d = 0; d < m.n_rbd; ++d) {
-        m.rb[i][j][d][0] = P.conv1d(rp + ".convs1." + std::to_string(d), ch, ch, k, true, true);
-        m.rb[i][j][d][1] = P.conv1d(rp + ".convs2." + std::to_string(d), ch, ch, k, true, true);
+        if (rb2) {
+          m.rb[i][j][d][0] = P.conv1d(rp + ".convs." + std::to_string(d), ch, ch, k, true, true);
+          m.rb[i][j][d][1] = ConvW();
+        } else {
+          m.rb[i][j][d][0] = P.conv1d(rp + ".convs1." + std::to_string(d), ch, ch, k, true, true);
+          m.rb[i][j][d][1] = P.conv1d(rp + ".convs2." + std::to_string(d), ch, ch, k, true, true);
+        }
       }
       P.emit_x6 = false;
+      if (rb2) {                                   // the fused / whole-ResBlock streams describe (conv, conv) pairs: ResBlock1 only
+        m.rbcl_w_off[i][j] = m.rbcl_b_off[i][j] = m.rbsw_w_off[i][j] = m.rbsw_b_off[i][j] = m.rb16_w_off[i][j] = m.rb16_b_off[i][j] = -1;
+        continue;
+      }
       // narrow stages: the 2*n_rbd convs of the block once more as ONE contiguous bf16 stream (+ one bias block) for the
       // whole-ResBlock kernel; copied out of the per-conv streams just written (m-tile 0 = the whole channel dim)
       m.rbcl_w_off[i][j] = m.rbcl_b_off[i][j] = -1;
@@ -544,6 +554,8 @@ int validate(const bv2_config& c, std::string& err) {
   if ((c.upsample_initial_channel >> c.n_upsamples) % 16) return bad("final Generator width must be a multiple of 16");
   for (int j = 0; j < c.n_resblock_kernels; ++j)
     if (c.resblock_kernel_sizes[j] % 2 == 0) return bad("resblock kernels must be odd");
+  if (c.resblock_type != 1 && c.resblock_type != 2) return bad("resblock_type must be 1 (ResBlock1) or 2 (ResBlock2)");
+  if (c.resblock_type == 2 && c.n_resblock_dilations != 2) return bad("ResBlock2 has exactly two convs (dilation[0], dilation[1]: modules.py:318-346)");
   if (c.kernel_size % 2 == 0) return bad("FFN kernel_size must be odd");
   return 0;
 }

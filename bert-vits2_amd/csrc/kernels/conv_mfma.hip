@@ -941,7 +941,9 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
     case TILE_128x128: return launch_variant<2, 2, 2, 2, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
     case TILE_64x128:  return launch_variant<2, 2, 1, 2, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
     case TILE_64x64:   return launch_variant<2, 2, 1, 1, 2>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
-    case TILE_32x128:  return launch_variant<1, 4, 1, 1, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+    case TILE_32x128:                             // halo > 64 columns (ResBlock2's k = 7, dilation 12: 72): the same tile on a 256-column staged chunk
+      if (128 + max_extra > 3 * 64) return launch_variant<1, 4, 1, 1, 4>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
+      return launch_variant<1, 4, 1, 1, 3>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
     case TILE_32x256:  return launch_variant<1, 4, 1, 2, 5>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
     case TILE_128x64:  return launch_variant<2, 2, 2, 1, 2>(stream, L, ck, max_cout_pad, max_extra, max_chunks);
   }

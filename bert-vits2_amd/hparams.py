@@ -68,8 +68,10 @@ class HParams:
         return r
 
     def validate(self) -> None:
-        if self.resblock != "1":
-            raise NotImplementedError("only ResBlock1 (resblock='1') is on the v2.3 hot path")
+        if str(self.resblock) not in ("1", "2"):
+            raise ValueError("resblock must be '1' (modules.ResBlock1) or '2' (modules.ResBlock2): reference models.py:508")
+        if str(self.resblock) == "2" and any(len(d) < 2 for d in self.resblock_dilation_sizes):
+            raise ValueError("ResBlock2 takes dilation[0] and dilation[1] (reference modules.py:318-346)")
         if self.flow_share_parameter:
             # the reference itself crashes here: attentions.FFT does not exist (models.py:107)
             raise NotImplementedError("flow_share_parameter=True is broken in the reference (models.py:107)")

@@ -35,6 +35,7 @@ class Config(C.Structure):
         ("resblock_kernel_sizes", C.c_int32 * MAX_RBK),
         ("n_resblock_dilations", C.c_int32),
         ("resblock_dilation_sizes", (C.c_int32 * MAX_RBD) * MAX_RBK),
+        ("resblock_type", C.c_int32),            # appended in round 5: 1 = ResBlock1, 2 = ResBlock2 (the library still takes the shorter struct)
     ]
 
 
@@ -201,6 +202,9 @@ def make_config(hp: H.HParams) -> Config:
         c.upsample_rates[i], c.upsample_kernel_sizes[i] = int(u), int(k)
     c.upsample_initial_channel = hp.upsample_initial_channel
     rk, rd = list(hp.resblock_kernel_sizes), [list(d) for d in hp.resblock_dilation_sizes]
+    c.resblock_type = 2 if str(hp.resblock) == "2" else 1
+    if c.resblock_type == 2:                     # modules.ResBlock2 builds exactly two convs, from dilation[0] and dilation[1]
+        rd = [d[:2] for d in rd]
     if len(rk) > MAX_RBK or len(rd) != len(rk) or any(len(d) != len(rd[0]) or len(d) > MAX_RBD for d in rd):
         raise ValueError("bad resblock configuration")
     c.n_resblock_kernels = len(rk)

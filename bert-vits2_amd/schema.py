@@ -100,6 +100,10 @@ def param_shapes(hp: H.HParams) -> "OrderedDict[str, Tuple[int, ...]]":
         for j, k in enumerate(hp.resblock_kernel_sizes):
             r = i * nk + j
             nd = len(hp.resblock_dilation_sizes[j])
+            if str(hp.resblock) == "2":          # modules.ResBlock2 (reference modules.py:318-346): `convs.0`, `convs.1`
+                for m in range(2):
+                    _wn_conv(d, f"dec.resblocks.{r}.convs.{m}", ch, ch, k)
+                continue
             for cs in ("convs1", "convs2"):
                 for m in range(nd):
                     _wn_conv(d, f"dec.resblocks.{r}.{cs}.{m}", ch, ch, k)

@@ -55,6 +55,10 @@ typedef struct bv2_config {
   int32_t resblock_kernel_sizes[BV2_MAX_RESBLOCK_KERNELS];
   int32_t n_resblock_dilations;
   int32_t resblock_dilation_sizes[BV2_MAX_RESBLOCK_KERNELS][BV2_MAX_RESBLOCK_DILATIONS];
+  /* appended in round 5 (a caller built against the shorter struct passes its own struct_bytes and gets ResBlock1):
+   * 0 / 1 = modules.ResBlock1 (convs1 / convs2 pairs, reference modules.py:239-315), 2 = modules.ResBlock2 (ONE conv per dilation,
+   * n_resblock_dilations = 2: `resblock: "2"` of models.py:508, modules.py:318-363) */
+  int32_t resblock_type;
 } bv2_config;
 
 enum { BV2_F32 = 0, BV2_F16 = 1, BV2_BF16 = 2 };

@@ -364,6 +364,19 @@ def resblock1(sd, p, x, k, dilations, fold_cache=None):
     return x
 
 
+def resblock2(sd, p, x, k, dilations, fold_cache=None):
+    """modules.ResBlock2.forward without a mask (reference modules.py:348-357): one conv per dilation, dilation[0] and dilation[1]."""
+    for m, d in enumerate(dilations[:2]):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = F.conv1d(xt, _fw(sd, f"{p}.convs.{m}", fold_cache), sd[f"{p}.convs.{m}.bias"], padding=(k * d - d) // 2, dilation=d)
+        x = xt + x
+    return x
+
+
+def _resblock(hp):
+    return resblock2 if str(getattr(hp, "resblock", "1")) == "2" else resblock1
+
+
 def generator(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
     x = F.conv1d(z, sd["dec.conv_pre.weight"], sd["dec.conv_pre.bias"], padding=3) + conv1x1(sd, "dec.cond", g)
     nk = len(hp.resblock_kernel_sizes)
@@ -375,8 +388,8 @@ def generator(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
             taps[f"dec.ups.{i}"] = x
         xs = None
         for j in range(nk):
-            r = resblock1(sd, f"dec.resblocks.{i * nk + j}", x, hp.resblock_kernel_sizes[j],
-                          hp.resblock_dilation_sizes[j], fold_cache)
+            r = _resblock(hp)(sd, f"dec.resblocks.{i * nk + j}", x, hp.resblock_kernel_sizes[j],
+                              hp.resblock_dilation_sizes[j], fold_cache)
             xs = r if xs is None else xs + r
         x = xs / nk
         if taps is not None:
@@ -408,6 +421,13 @@ def resblock1_bf16(sd, p, x, k, dilations, fold_cache=None):
     return x
 
 
+def resblock2_bf16(sd, p, x, k, dilations, fold_cache=None):
+    for m, d in enumerate(dilations[:2]):
+        xt = _bf(F.leaky_relu(x, LRELU_SLOPE))
+        x = _bf(F.conv1d(xt, _bf(_fw(sd, f"{p}.convs.{m}", fold_cache)), sd[f"{p}.convs.{m}.bias"], padding=(k * d - d) // 2, dilation=d) + x)
+    return x
+
+
 def generator_bf16(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
     x = _bf(F.conv1d(_bf(z), _bf(sd["dec.conv_pre.weight"]), sd["dec.conv_pre.bias"], padding=3) + conv1x1(sd, "dec.cond", g))
     nk = len(hp.resblock_kernel_sizes)
@@ -420,8 +440,8 @@ def generator_bf16(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
             taps[f"dec.ups.{i}"] = x
         xs = None
         for j in range(nk):
-            r = resblock1_bf16(sd, f"dec.resblocks.{i * nk + j}", x, hp.resblock_kernel_sizes[j],
-                               hp.resblock_dilation_sizes[j], fold_cache)
+            rb = resblock2_bf16 if str(getattr(hp, "resblock", "1")) == "2" else resblock1_bf16
+            r = rb(sd, f"dec.resblocks.{i * nk + j}", x, hp.resblock_kernel_sizes[j], hp.resblock_dilation_sizes[j], fold_cache)
             xs = r if xs is None else xs + r
         x = xs * inv if nk > 1 else xs
         if taps is not None:

@@ -37,6 +37,9 @@ CASES = {
     # also carries the reference's autocast runs: `flow` here is the ResidualCouplingBlock / WN stack under fp16 autocast
     "wn_b2_t40": dict(hp=dict(use_transformer_flow=False), lengths=[40, 33], languages=[0, 1], sids=[11, 12], seed=0,
                       kw=INFER_KW, autocast=True),
+    # `resblock: "2"` (reference models.py:508, modules.py:318-363): ONE weight-normed conv per dilation, VITS's small-vocoder setting
+    "rb2_b2_t14": dict(hp=dict(resblock="2", resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12))),
+                       lengths=[14, 9], languages=[0, 2], sids=[4, 77], seed=0, kw=INFER_KW),
 }
 # cases whose fixture also stores the reference's autocast runs
 AUTOCAST_CASES = [n for n, c in CASES.items() if c.get("autocast")] + ["mix_b2_ragged"]

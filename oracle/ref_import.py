@@ -71,6 +71,9 @@ def build_reference_net(hp, state_dict):
     model_kwargs["use_transformer_flow"] = hp.use_transformer_flow
     model_kwargs["n_flow_layer"] = hp.n_flow_layer
     model_kwargs["n_layers_trans_flow"] = hp.n_layers_trans_flow
+    model_kwargs["resblock"] = str(hp.resblock)                      # "1" = modules.ResBlock1, anything else ResBlock2 (models.py:508)
+    model_kwargs["resblock_kernel_sizes"] = [int(k) for k in hp.resblock_kernel_sizes]
+    model_kwargs["resblock_dilation_sizes"] = [[int(v) for v in d] for d in hp.resblock_dilation_sizes]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         net = models.SynthesizerTrn(hp.n_vocab, hp.spec_channels, hp.segment_size,

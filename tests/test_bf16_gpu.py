@@ -112,7 +112,7 @@ def _relrms(a, b):
     return rms(a - b) / max(rms(b), 1e-30)
 
 
-@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged"])
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "rb2_b2_t14"])      # rb2: `resblock: "2"` (modules.ResBlock2), layer-wise
 def test_stage_generator_bf16_vs_bf16_oracle(name):
     hp, seed, batch, nw, nz, kw = cases.build_case(name)
     sd = cached_state_dict(hp, seed)

@@ -338,3 +338,34 @@ def test_x6_split_is_exact_and_round_to_nearest():
         assert h[0] == 0x7f7f and not np.isfinite(bf(h[1]))
         lib.bv2_test_x6_split(float("nan"), h)
         assert np.isnan(bf(h[0]))
+
+
+def test_resblock2_config_packs_and_the_shorter_config_struct_still_means_resblock1():
+    """`resblock: "2"` (reference models.py:508, modules.py:318-363): the schema names `dec.resblocks.N.convs.{0,1}`, the packer takes them
+    (no CPU compute here), and a caller built against the pre-round-5 bv2_config (no trailing resblock_type) is still accepted."""
+    lib = L.load()
+    hp = H.default_v23(resblock="2", resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)))
+    names = schema.inference_schema(hp) if hasattr(schema, "inference_schema") else None
+    m = models.from_hparams(hp)
+    keys = set(m.state_dict().keys())
+    assert "dec.resblocks.0.convs.1.weight_v" in keys and "dec.resblocks.14.convs.0.weight_g" in keys
+    assert not any(".convs1." in k or ".convs2." in k for k in keys)
+    from bert_vits2_amd import synth
+    m.load_state_dict(synth.synthetic_state_dict(hp, seed=1), strict=False)
+    blob = m.pack_host_blob()                                       # bv2_create + bv2_load_tensor x N + bv2_pack_weights
+    assert blob.numel() > 1 << 20
+    cfg = L.make_config(hp)
+    assert cfg.resblock_type == 2 and cfg.n_resblock_dilations == 2
+    with pytest.raises(ValueError):
+        H.default_v23(resblock="2", resblock_dilation_sizes=((1,), (1,), (1,))).validate()
+    # the shorter struct: everything up to (not including) resblock_type
+    cfg1 = L.make_config(H.default_v23())
+    cfg1.struct_bytes = C.sizeof(L.Config) - 4
+    h = C.c_void_p()
+    assert lib.bv2_create(C.byref(cfg1), C.byref(h)) == 0, lib.bv2_last_error(None)
+    n_short = lib.bv2_packed_bytes(h)
+    lib.bv2_destroy(h)
+    cfg1 = L.make_config(H.default_v23())
+    assert lib.bv2_create(C.byref(cfg1), C.byref(h)) == 0
+    assert lib.bv2_packed_bytes(h) == n_short                        # same layout either way
+    lib.bv2_destroy(h)

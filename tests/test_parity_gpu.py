@@ -71,7 +71,7 @@ def test_stage_flow(name):
     assert maxrel(z, ref["z"]) < 1e-4, maxrel(z, ref["z"])
 
 
-@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged"])
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "rb2_b2_t14"])      # rb2: `resblock: "2"` (modules.ResBlock2)
 def test_stage_generator_with_taps(name):
     hp, seed, batch, nw, nz, kw, sd, ref = oracle_run(name)
     m = gpu_model(hp, seed)
