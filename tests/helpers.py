@@ -31,7 +31,9 @@ _SD_CACHE = {}
 
 def cached_state_dict(hp, seed, **kw):
     from bert_vits2_amd import synth
-    key = (hp.use_transformer_flow, seed, tuple(sorted(kw.items())))
+    import dataclasses
+    # every field that shapes the checkpoint (round 5: resblock type / kernel sizes, inter_channels, ... — not only the flow variant)
+    key = (repr(dataclasses.astuple(hp)), seed, tuple(sorted(kw.items())))
     if key not in _SD_CACHE:
         _SD_CACHE[key] = synth.synthetic_state_dict(hp, seed, **kw)
     return _SD_CACHE[key]
