@@ -19,7 +19,8 @@ _MODELS = {}
 
 def gpu_model(hp, seed, **kw):
     from bert_vits2_amd import models
-    key = (hp.use_transformer_flow, seed, tuple(sorted(kw.items())))
+    import dataclasses
+    key = (repr(dataclasses.astuple(hp)), seed, tuple(sorted(kw.items())))      # every field that shapes the model (resblock type, ...)
     if key not in _MODELS:
         m = models.from_hparams(hp)
         m.load_state_dict(cached_state_dict(hp, seed, **kw), strict=False)
