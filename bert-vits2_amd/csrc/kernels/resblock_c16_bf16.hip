@@ -50,7 +50,9 @@ __device__ __forceinline__ unsigned r16_act(unsigned u, float slope) {   // bf16
 constexpr int R16_G = 32;            // guard rows on each side of the LDS tiles (dilated taps reach <= 30 rows outside)
 constexpr int R16_NW = 8;            // waves per workgroup
 constexpr int R16_NB = 8;            // 16-row blocks per wave (128 rows)
-constexpr int R16_HB = 2;            // blocks per GEMM pass (four passes per conv: 8 accumulator + 16 B-operand registers live)
+// blocks per GEMM pass: HB = 4 (two passes: 16 accumulator + 32 B-operand registers live) where the conv's weight set leaves room
+// (KU <= 4 units), HB = 2 for the k = 9 / 11 branches (KU = 5 / 6: 24 weight registers)
+template <int KU> struct R16Hb { static constexpr int v = KU <= 4 ? 4 : 2; };
 constexpr int R16_R = 16 * R16_NB * R16_NW;   // 1024 rows per tile incl. halo
 constexpr int R16_ROWS = R16_R + 2 * R16_G;
 constexpr int R16_P = 16;            // elements per LDS row (32 bytes, unpadded)
@@ -93,6 +95,7 @@ __device__ __forceinline__ void r16_conv(R16Ctx c, bf16x8 (&W)[KU], const uint16
   const unsigned ustep = (unsigned)(2 * dil) * (R16_P * 2);            // bytes between the rows of tap 2u and tap 2u + 2
   const unsigned rd0 = src_tile + c.rd + (unsigned)((c.qt - halfk) * dil * (R16_P * 2));
   const unsigned wr0 = dst_tile + c.own;
+  constexpr int R16_HB = R16Hb<KU>::v;
 #pragma unroll
   for (int h = 0; h < R16_NB / R16_HB; ++h) {
     const unsigned xb = rd0 + h * R16_HB * R16_BLK;
