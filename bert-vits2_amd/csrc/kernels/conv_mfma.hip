@@ -867,6 +867,12 @@ bool conv_use_splitk(const ConvLaunch& L) {
     if (L.p[i].nsrc != 1 || (L.p[i].in_mask != nullptr) != (L.p[0].in_mask != nullptr)) return false;
   const long cols = (long)L.B * L.L;
   const long tiles128 = (long)L.nprob * mt * ((L.L + 127) / 128) * L.B;
+  // Round 5: a long-K conv on a medium batch (the text encoder's FFN conv_2 at B = 32: 768 x 3 taps -> 192 rows x 4 096 columns, 3.6 GFLOP)
+  // fell on this side of the line with 192 "tiles" and ran as 6 144 four-wave split-K workgroups writing eight partial slabs: 76 us against
+  // 41 us for its twin conv_1 on the LDS-tiled kernel.  Enough work AND enough 128-column tiles AND whole 64-column tiles per item: LDS-tiled.
+  double flops = 0;
+  for (int i = 0; i < L.nprob; ++i) flops += 2.0 * L.p[i].cout * L.p[i].cin * L.p[i].k * (double)cols;
+  if (flops >= 2e9 && tiles128 >= 128 && L.L >= 64) return false;
   return cols <= 4096 && tiles128 < 512;
 }
 
