@@ -469,14 +469,31 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       }
     }
   } else if (ig < T) {
-    for (int c = tid >> 5; c < D; c += 2 * NW) {
-      float o = 0.f;
+    // the plain output [B][H D][T] (the fp16 flow at batch >= 8, BERT): the band term as in `normalise` above — the thread's NR probabilities
+    // once into registers, compile-time band bound (as a runtime `for (r < NR)` inside the channel loop it was 6 x 9 dependent LDS round
+    // trips: 11.4k of a 31k-tick workgroup at B = 32, profiles/r05_timeline_c3_f16_convs.txt)
+    auto finish = [&](auto nrm_c) __attribute__((always_inline)) {
+      constexpr int NRM = decltype(nrm_c)::value;
+      float sbv[NRM];
 #pragma unroll
-      for (int sl = 0; sl < NSLOT; ++sl) o += Os[sl * (D * AQ) + c * AQ + i];
-      o *= il;
-      for (int r = 0; r < NR; ++r) o += Sb[r * AQ + i] * Ev[r * D + c];
-      op[(int64_t)c * T + ig] = o;
-    }
+      for (int r = 0; r < NRM; ++r) {
+        const float pv = Sb[(r < NR ? r : 0) * AQ + i];
+        sbv[r] = r < NR ? pv : 0.f;
+      }
+#pragma unroll 2
+      for (int c = tid >> 5; c < D; c += 2 * NW) {
+        float o = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) o += Os[sl * (D * AQ) + c * AQ + i];
+        o *= il;
+#pragma unroll
+        for (int r = 0; r < NRM; ++r) o += sbv[r] * Ev[(r < NR ? r : 0) * D + c];
+        op[(int64_t)c * T + ig] = o;
+      }
+    };
+    if (NR <= 1) finish(std::integral_constant<int, 1>{});
+    else if (NR <= 9) finish(std::integral_constant<int, 9>{});
+    else finish(std::integral_constant<int, 2 * AMAXW + 1>{});
   }
   if (A.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
