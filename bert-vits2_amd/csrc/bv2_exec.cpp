@@ -1041,6 +1041,16 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
       ClProb p = prob(U.cl, src[0], x, Lc, 1);
       p.x[1] = src[1]; p.x[2] = src[2]; p.nsrc = nsrc; p.in_scale = 1.f / (float)nsrc;
       p.pre_lrelu = 1; p.pad_left = U.cl_pad_left;
+      if (!c.h->no_ups_phase_taps && U.u <= 16) {                  // phase ph's taps inside the union window: [off, off + ntaps)
+        unsigned long long offs = 0;
+        bool fits = true;
+        for (int ph = 0; ph < U.u; ++ph) {
+          const int off = U.cl_pad_left - U.pad_left[ph];
+          fits = fits && off >= 0 && off <= 15;
+          offs |= (unsigned long long)(off & 15) << (4 * ph);
+        }
+        if (fits) { p.ph_cout = U.cout; p.ph_ntaps = U.ntaps; p.ph_offs = offs; }
+      }
       cl.p[0] = p;
       // algorithmic FLOPs: the true taps of the transposed conv (the zero-padded window taps are not counted)
       launch(cl, "dec.ups", 2.0 * U.cin * U.cout * U.k * (double)Lc * B);
@@ -1197,6 +1207,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
   a.nsrc = nsrc; a.in_scale = 1.f / (float)nsrc;
   a.w = c.W(m.conv_post.off); a.out = o; a.C = m.post_c; a.k = m.post_k; a.L = Lc; a.B = B;
   a.slope = 0.01f;                                            // F.leaky_relu default (models.py:553)
+  a.generic = c.h->no_conv_post_rows ? 1 : 0;
   c.chk(launch_conv_post_cl(c.s, a), "dec.conv_post");
 }
 

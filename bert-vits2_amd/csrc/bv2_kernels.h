@@ -242,6 +242,10 @@ struct ClProb {
   int64_t res_bstride;
   int cin, cout, cout_pad, k, dil, pad_left;
   int pre_lrelu; float slope;
+  // ConvTranspose1d as ONE conv with C_out' = u*C_out (ph_cout > 0): output channels [ph*ph_cout, +ph_cout) are phase ph, whose
+  // non-zero weights are the window taps [off, off + ph_ntaps), off = nibble ph of ph_offs — the GEMM of a wave runs only the taps of the
+  // phases its output channels belong to (the others are zeros the packer wrote to make the u phases one problem)
+  int ph_cout, ph_ntaps; unsigned long long ph_offs;
 };
 struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; const int64_t* lens = nullptr; int len_mul = 1;
                   unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
@@ -323,6 +327,7 @@ struct ConvPostClArgs {
   float* out;               // [B][L] fp32
   int C, k, L, B; float slope;
   const int64_t* lens = nullptr; int len_mul = 1;
+  int generic = 0;          // 1: the any-width kernel also at C = 16, k = 7 ("conv_post_rows" = 0; tests)
 };
 int launch_conv_post_cl(hipStream_t stream, const ConvPostClArgs& a);
 

@@ -98,14 +98,19 @@ __device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const ui
 // MFMA issue rate).
 template <int MI, int NI, int PD>
 __device__ __forceinline__ void cl_gemm(f32x16 (&acc)[MI][NI], const uint16_t* wp, int64_t mstride, int U, int k,
-                                        const unsigned short* xb, int pitch, int tstep) {
+                                        const unsigned short* xb, int pitch, int tstep, int kfull) {
+  // k taps of a stream laid out for kfull >= k taps per group (wp points at the first tap that is run): U = groups * k units
   bf16x8 ar[PD][MI];
-  int lu = 0;
+  int lu = 0, lj = 0;
+  int64_t loff = 0;
+  const int64_t gskip = (int64_t)(kfull - k) * 512;
   auto load_unit = [&](int slot) __attribute__((always_inline)) {
-    const int uc = lu < U ? lu : U - 1;                             // past the end: re-read the last unit, result unused
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) ar[slot][mi] = *reinterpret_cast<const bf16x8*>(wp + mi * mstride + (int64_t)uc * 512);
-    ++lu;
+    for (int mi = 0; mi < MI; ++mi) ar[slot][mi] = *reinterpret_cast<const bf16x8*>(wp + mi * mstride + loff);
+    if (++lu < U) {                                                 // past the end: re-read the last unit, result unused
+      loff += 512;
+      if (++lj == k) { lj = 0; loff += gskip; }
+    }
   };
 #pragma unroll
   for (int i = 0; i < PD; ++i) { load_unit(i); __builtin_amdgcn_sched_barrier(0); }
@@ -151,7 +156,8 @@ __device__ __forceinline__ void cl_gemm(f32x16 (&acc)[MI][NI], const uint16_t* w
 typedef __attribute__((address_space(1))) bf16x8 GlobalFrag;
 template <int MI, int NI, int G>
 __device__ __forceinline__ void cl_gemm_tm(f32x16 (&acc)[MI][NI], const uint16_t* wbase, int64_t mstride, unsigned wlane_bytes,
-                                           int k, const unsigned short* xb, int tstep) {   // wbase: wave-uniform stream start
+                                           int k, const unsigned short* xb, int tstep, int kfull) {   // wbase: wave-uniform stream start
+  // k taps of a stream laid out for kfull >= k taps per group (wbase = the first tap that is run)
   constexpr int PITCH = 16 * G + 8;
   static_assert(G % 2 == 0, "the B double buffer alternates with the group index");
   bf16x8 ar[G][MI];
@@ -161,7 +167,7 @@ __device__ __forceinline__ void cl_gemm_tm(f32x16 (&acc)[MI][NI], const uint16_t
   for (int s = 0; s < G; ++s) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      wq[s][mi] = wbase + mi * mstride + (int64_t)s * k * 512;
+      wq[s][mi] = wbase + mi * mstride + (int64_t)s * kfull * 512;
       ar[s][mi] = *(const GlobalFrag*)(reinterpret_cast<const char*>(wq[s][mi]) + wlane_bytes);
       wq[s][mi] += first_step;
     }

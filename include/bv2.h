@@ -265,6 +265,11 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "resblock_c16"    1 (default): the C = 16 bf16 stage's whole-ResBlock launch on v_mfma_f32_16x16x32_bf16 (two taps x 16 channels per
  *                     instruction, unpadded 32-byte LDS rows, two workgroups per CU: kernels/resblock_c16_bf16.hip); 0: the 32x32x16
  *                     whole-ResBlock kernel (resblock_cl_bf16.hip), whose MFMA block is half zero padding at this width
+ *   "conv_post_rows"  1 (default): the bf16 path's conv_post + tanh at C = 16, k = 7 row-wise (a thread owns one 32-byte input row per branch, K floats
+ *                     per thread through LDS); 0: the any-width kernel (C*K scalar LDS reads per output sample).  fp32 arithmetic in both
+ *   "ups_phase_taps"  1 (default): a bf16 ConvTranspose1d launch (one conv with C_out' = u*C_out over the union of the phases' tap windows) runs,
+ *                     per wave, only the window taps of the phases its output channels belong to — the zero weights that pad the other
+ *                     phases' taps are stepped over (1/3 of the matrix work at k = 2u); 0: every tap of the window (same results)
  *   "prefetch"        default 0 (measured: within noise at config 2 — the batch-1 launches do not wait for their weights; the BERT extractor,
  *                     where it is worth 0.6 %, has it on: bv2_bert_set_option).  Batch 1 (small-N regime): bit 0 — a LayerNorm launch carries the NEXT launch's weight stream (FFN conv_1 behind
  *                     LayerNorm-1, the next layer's q/k/v projection behind LayerNorm-2), bit 1 — a split-K conv launch does (conv_2 behind

@@ -183,3 +183,61 @@ def test_infer_bf16_generator_end_to_end_vs_reference_golden():
 def maxrel_z(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged"])
+def test_convtranspose_phase_taps_bit_identical(name):
+    """Round 5: a bf16 ConvTranspose1d launch (one conv over the union of the u phases' tap windows, reference models.py:538-549) runs per wave
+    only the taps of the phases its output channels belong to ("ups_phase_taps", default 1).  The taps it steps over are zeros the packer
+    wrote, so every stage's output — and the waveform — must be bit-identical to the run that multiplies through them (= 0)."""
+    hp, seed, batch, nw, nz, kw = cases.build_case(name)
+    sd = cached_state_dict(hp, seed)
+    ref32 = O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"], batch["bert"],
+                    batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, want_taps=True, **kw)
+    m = _gpu_model(hp, seed)
+    m.set_generator_dtype(torch.bfloat16)
+    B, Cc, Ty = ref32["z"].shape
+    got = {}
+    for v in (1, 0):
+        m.set_option("ups_phase_taps", v)
+        taps = {}
+        up = 1
+        for i, u in enumerate(hp.upsample_rates):
+            up *= u
+            taps[f"dec.ups.{i}"] = torch.zeros(B, hp.upsample_initial_channel // 2 ** (i + 1), Ty * up, device="cuda")
+        for k, t in taps.items():
+            m.set_tap(k, t)
+        try:
+            o = m.stage_generator(ref32["z"], ref32["y_lengths"], ref32["g"])
+            torch.cuda.synchronize()
+        finally:
+            m.set_tap(None)
+        got[v] = (o.cpu(), {k: t.cpu() for k, t in taps.items()})
+    m.set_option("ups_phase_taps", 1)
+    for k in got[1][1]:
+        assert torch.equal(got[1][1][k], got[0][1][k]), k
+        assert float(got[1][1][k].abs().max()) > 0
+    assert torch.equal(got[1][0], got[0][0])
+
+
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged"])
+def test_conv_post_rowwise_kernel_vs_any_width_kernel(name):
+    """Round 5: conv_post + tanh of the bf16 path (reference models.py:553-555) at C = 16, k = 7 on the row-wise kernel (default) against the
+    any-width kernel ("conv_post_rows" = 0): the same fp32 products summed in another order -> a few ulp on a waveform in [-1, 1]; ragged
+    lengths included (rows past an utterance's end are the conv's zero padding in both)."""
+    hp, seed, batch, nw, nz, kw = cases.build_case(name)
+    assert hp.upsample_initial_channel >> len(hp.upsample_rates) == 16
+    sd = cached_state_dict(hp, seed)
+    ref32 = O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"], batch["bert"],
+                    batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, want_taps=True, **kw)
+    m = _gpu_model(hp, seed)
+    m.set_generator_dtype(torch.bfloat16)
+    outs = {}
+    for v in (1, 0):
+        m.set_option("conv_post_rows", v)
+        outs[v] = m.stage_generator(ref32["z"], ref32["y_lengths"], ref32["g"]).cpu()
+    m.set_option("conv_post_rows", 1)
+    d = (outs[1] - outs[0]).abs().max().item()
+    print(f"\n[{name}] conv_post row-wise vs any-width: max |delta| {d:.3e} (signal rms {rms(outs[0]):.3e})")
+    assert rms(outs[0]) > 0 and d < 2e-6
+    assert not torch.equal(outs[1], outs[0]) or d == 0.0
