@@ -1003,7 +1003,7 @@ def rank_main(args):
         lib = model._lib
         lib.bv2_test_set_variants.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         lib.bv2_test_set_variants.restype = None
-        lib.bv2_test_set_variants(spec.encode(), int(clg), int(hcg))
+        lib.bv2_test_set_variants(spec.replace(";", ",").encode(), int(clg), int(hcg))     # "32:1;4:2,1,0": several <tiles>:<variant> pairs
         log(f"variants {args.variants}")
     for kv in args.option:
         key, val = kv.split("=")

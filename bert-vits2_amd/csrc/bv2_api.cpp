@@ -414,6 +414,8 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "respair_c32") h->no_respair_c32 = value == 0;
   else if (k == "resblock_c16") h->no_resblock_c16 = value == 0;
   else if (k == "resblock_sw") h->resblock_sw = value & 3;
+  else if (k == "f16_fused_ln") h->no_f16_fused_ln = value == 0;
+  else if (k == "f16_ksplit") h->no_f16_ksplit = value == 0;
   else if (k == "conv_post_rows") h->no_conv_post_rows = value == 0;
   else if (k == "ups_phase_taps") h->no_ups_phase_taps = value == 0;
   else if (k == "xcd_affine") h->no_xcd_affine = value == 0;

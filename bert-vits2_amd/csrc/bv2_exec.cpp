@@ -132,7 +132,7 @@ struct Ctx {
   void conv_h(const HcProb& p, int B, int L, const char* tag, const HcProb* p2 = nullptr, bool xcd = false) {
     if (rc) return;
     HcLaunch hl;
-    hl.p[0] = p; hl.nprob = 1; hl.B = B; hl.L = L; hl.xcd_b = xcd ? 1 : 0;
+    hl.p[0] = p; hl.nprob = 1; hl.B = B; hl.L = L; hl.xcd_b = xcd ? 1 : 0; hl.no_ksplit = h->no_f16_ksplit ? 1 : 0;
     if (p2) { hl.p[1] = *p2; hl.nprob = 2; }
     const char* vn = "conv_f16";
     const int pi = prof_begin(tag);
@@ -171,9 +171,12 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
                  int vec2_bstride = 0, FbArgs* fb = nullptr) {
   const int H = e.hidden, ld = attn_ld(T), R = qkv_rows(e);
   const bool xcd = f16 && c.xcd_affine(B);
+  // fp16 stacks: the LayerNorms that need nothing but the conv's own columns run in conv_o's / conv_2's epilogue (enc_f16.hip)
+  const bool ln_in_conv = f16 && !c.h->no_f16_fused_ln && conv_f16_ln_supported(H);
   // cond_layer_idx == 2 > 0: the speaker add always rides on the previous layer's LN2 epilogue
   for (int i = 0; i < e.n_layers; ++i) {
     const EncLayerW& L = e.layer[i];
+    bool ln2_in_conv = false;
     ConvProb p = c.prob(L.qkv, b.x, b.qkv, T);
     p.out_rstride = ld; p.out_bstride = (int64_t)R * ld;      // rows padded to 32 columns: aligned tile loads
     if (f16) {
@@ -215,6 +218,9 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     } else if (f16) {
       HcProb q = c.hprob(L.o, b.att, true, b.s, true, T);
       q.res = b.x; q.res_mode = RES_ADD;
+      if (ln_in_conv) {                            // LayerNorm-1 in conv_o's epilogue: x = LN1(x + conv_o(att)) written in place
+        q.out = b.x; q.ln_gamma = c.W(L.g1.off); q.ln_beta = c.W(L.b1.off); q.ln_eps = 1e-5f;
+      }
       c.conv_h(q, B, T, "enc.o", nullptr, xcd);
     } else {
       p = c.prob(L.o, b.att, b.s, T);
@@ -227,7 +233,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     l.gamma = c.W(L.g1.off); l.beta = c.W(L.b1.off); l.eps = 1e-5f; l.out = b.x; l.B = B; l.C = H; l.T = T; l.xcd_b = xcd ? 1 : 0;
     if (ks > 1) { l.ml = b.ml; l.ml_H = e.heads; l.ml_ks = ks; l.bias = c.W(L.o.b_off); l.add = b.x; }
     if (!f16) l.pf = c.pf_of(L.ffn1, B, 1);                       // the FFN's first weight set lands in L2 under this LayerNorm
-    c.ln(l, "enc.ln1");
+    if (!(f16 && ln_in_conv)) c.ln(l, "enc.ln1");
     l.ml = nullptr; l.bias = nullptr; l.add = nullptr; l.ml_H = l.ml_ks = 0; l.pf = Prefetch{nullptr, 0};
     if (f16) {
       // FFN (attentions.py:438-446): hidden activation relu(conv_1(x*mask))*mask kept as fp16 channels-last in b.f1
@@ -236,6 +242,9 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       c.conv_h(q, B, T, "enc.ffn1", nullptr, xcd);
       q = c.hprob(L.ffn2, b.f1, false, b.s, true, T);
       q.out_mask = mask; q.mask_pre = 1; q.res = b.x; q.res_mode = RES_ADD;
+      // a plain LayerNorm-2 (no speaker add for the next layer, not the stack's last layer) rides in conv_2's epilogue the same way
+      ln2_in_conv = ln_in_conv && !(i + 1 == kCondLayer && i + 1 < e.n_layers) && i + 1 < e.n_layers;
+      if (ln2_in_conv) { q.out = b.x; q.ln_gamma = c.W(L.g2.off); q.ln_beta = c.W(L.b2.off); q.ln_eps = 1e-5f; }
       c.conv_h(q, B, T, "enc.ffn2", nullptr, xcd);
       ns = 1;
     } else {
@@ -245,6 +254,10 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       p = c.prob(L.ffn2, b.f1, b.s, T);
       p.in_mask = mask; p.out_mask = mask; p.mask_pre = 1; p.res = b.x; p.res_mode = RES_ADD;
       ns = c.conv1(p, B, T, "enc.ffn2", kSlabs, b.slab);
+    }
+    if (ln2_in_conv) {                             // x already holds LN2's output
+      if (tapname) c.tap((std::string(tapname) + ".layer." + std::to_string(i)).c_str(), b.x, (int64_t)B * H * T);
+      continue;
     }
     l.a = b.s; l.nslab = ns; l.gamma = c.W(L.g2.off); l.beta = c.W(L.b2.off);
     if (!f16 && i + 1 < e.n_layers) l.pf = c.pf_of(e.layer[i + 1].qkv, B, 1);   // the next layer's q/k/v projection
@@ -1037,7 +1050,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     const int Lo = Lc * U.u;
     {
       ClLaunch cl;
-      cl.nprob = 1; cl.B = B; cl.L = Lc; cl.lens = lens; cl.len_mul = up;
+      cl.nprob = 1; cl.B = B; cl.L = Lc; cl.lens = lens; cl.len_mul = up; cl.ups = 1;
       ClProb p = prob(U.cl, src[0], x, Lc, 1);
       p.x[1] = src[1]; p.x[2] = src[2]; p.nsrc = nsrc; p.in_scale = 1.f / (float)nsrc;
       p.pre_lrelu = 1; p.pad_left = U.cl_pad_left;

@@ -248,7 +248,8 @@ struct ClProb {
   int ph_cout, ph_ntaps; unsigned long long ph_offs;
 };
 struct ClLaunch { ClProb p[BV2_MAX_PROBS]; int nprob, B, L; const int64_t* lens = nullptr; int len_mul = 1;
-                  unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only
+                  unsigned long long* dbg = nullptr;      // dbg: tools/timeline.py only
+                  int ups = 0; };                          // a ConvTranspose1d launch (tile choice of its own: launch_conv_cl_bf16)
 int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** variant_name);
 void conv_cl_set_tuning(const char* spec, int generic);      // tests / tuning only (bv2_test_set_variants)
 bool conv_cl_bf16_supported(int cin, int cout, int k, int dil);
@@ -355,7 +356,11 @@ struct HcProb {
   const float* out_mask; int out_mask_bstride;
   int mask_pre, mask_post, act;
   int cin, cout, cout_pad, k, dil, pad_left;
+  // out_ct, cout = 192 (conv_f16_ln_supported): out = LayerNorm over the cout channels of the conv's result (after bias /
+  // residual / masks), eps ln_eps, scale / shift ln_gamma / ln_beta [cout]; null = no LayerNorm.  out may be the residual's tensor
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
 };
+bool conv_f16_ln_supported(int cout);
 // act == ACT_GATE (out_ct = 0 only; WN, reference commons.py:98-105): the weight rows come in gate order (bv2_model.cpp wn_gate_row:
 // rows [0,16) of every 32-row tile = tanh half, rows [16,32) = sigmoid half of the same 16 channels); the epilogue writes
 // out[b][t][16*mt + j] = fp16( tanh(v[j]) * sigmoid(v[j+16]) ), `out` has cout/2 channels (out_bstride = cout/2 * L).
@@ -365,6 +370,7 @@ struct HcProb {
 // hardware's round-robin): the kernels of an Encoder layer then hand a batch item's tensors on inside ONE XCD's L2 (the eight L2s are not
 // coherent: a tile produced on another XCD comes back through the fabric).  Same switch in LnArgs / AttnArgs; see xcd_decode.
 struct HcLaunch { HcProb p[2]; int nprob = 1; int B, L; unsigned long long* dbg = nullptr;   // dbg: tools/timeline.py only
+                  int no_ksplit = 0;                 // 1: the FFN conv_2 shape without the in-workgroup K split ("f16_ksplit" = 0)
                   int xcd_b = 0; int xcd_gx = 0, xcd_per = 0; };    // xcd_gx / xcd_per: filled by the launcher
 int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name);
 void conv_f16_set_tuning(int generic);                       // tests / tuning only (bv2_test_set_variants)

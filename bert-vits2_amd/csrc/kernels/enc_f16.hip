@@ -87,10 +87,9 @@ __device__ __forceinline__ void hc_gemm(f32x16 (&acc)[NI], const uint16_t* wp, i
 // slot = channel group (unit (s, tap j) is followed by (s, j+1)), groups of a tap fully unrolled, every LDS offset an
 // immediate, explicit global loads — 3.5 instead of ~9 instructions per MFMA (same restructuring as gen_bf16.hip cl_gemm_tm).
 typedef __attribute__((address_space(1))) f16x8 GlobalFragH;
-template <int NI, int G>
+template <int NI, int G, int PITCH = 16 * G + 8>   // PITCH: elements per LDS row (a tile wider than the 16*G channels this call runs: K split)
 __device__ __forceinline__ void hc_gemm_tm(f32x16 (&acc)[NI], const uint16_t* wbase, unsigned wlane_bytes, int k,
                                            const unsigned short* xb, int tstep) {
-  constexpr int PITCH = 16 * G + 8;
   static_assert(G % 2 == 0, "the B double buffer alternates with the group index");
   f16x8 ar[G];
   const uint16_t* wq[G];
@@ -224,9 +223,17 @@ __device__ __forceinline__ void hc_stage_cl(unsigned short* xs, int pitch, const
   }
 }
 
-template <int WN, int NI, bool IN_CT, bool OUT_CT, int G>   // G > 0: every chunk has 16*G channels (tap-major GEMM)
-__global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, const int ngrp) {
-  constexpr int NT = 64 * WN, BT = 32 * NI;
+// KS > 1 (round 5, the FFN's conv_2: C_in = 768 -> 192 rows, k = 5): the K dimension split INSIDE the workgroup.  One 32-row output tile per
+// wave makes that conv 6 waves per 64 columns = 192 workgroups at B = 32, each streaming the WHOLE 1.47 MB weight set through a loop of
+// 240 units per wave that tools/timeline.py had at 58k of the workgroup's 88k ticks (MFMA-only: 15k) with three re-stagings of the tile in
+// it.  Here the whole C_in = KS*16*G tile is staged once (68 rows x 1552 B = 105 KB), wave (wm, kh) runs channel groups [kh*G, +G) of
+// output tile wm, the KS partial accumulators meet in LDS (over the dead tile) and the waves kh = 0 run the epilogue: half the loop per
+// wave, twice the waves per CU to hide the weight stream's latency, one staging phase instead of three.
+// LN: the channel LayerNorm of the result in the epilogue (its own instantiations: the 50 extra live registers stay out of the others)
+template <int WN, int NI, bool IN_CT, bool OUT_CT, int G, int KS = 1, bool LN = false>   // G > 0: every chunk has 16*G channels (tap-major GEMM)
+__global__ void __launch_bounds__(64 * WN * KS) conv_f16_kernel(const HcLaunch L, const int ngrp) {
+  constexpr int NT = 64 * WN * KS, BT = 32 * NI;
+  static_assert(KS == 1 || (G > 0 && !IN_CT && OUT_CT), "the in-workgroup K split: tap-major, channels-last input, [C][T] output");
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
   int b, cg, tile, pz = blockIdx.z;
   if (L.xcd_b) {                                                    // batch item -> XCD affinity (bv2_kernels.h xcd_decode)
@@ -245,7 +252,8 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
   const int l31 = lane & 31, lh = lane >> 5;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;                    // timeline stamps (tools/timeline.py; L.dbg is null in the product)
   if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
-  const int mt = cg * WN + wid;
+  const int wm = KS > 1 ? wid % WN : wid, kh = KS > 1 ? wid / WN : 0;
+  const int mt = cg * WN + wm;
   const int t0 = tile * BT;
   const int cin = P.cin, k = P.k, dil = P.dil;
   const int rows = BT + (k - 1) * dil;
@@ -258,6 +266,31 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
+  if constexpr (KS > 1) {
+    constexpr int PITCH = KS * 16 * G + 8;         // cin == KS*16*G (launcher)
+    hc_stage_cl<NT>(xs, PITCH, static_cast<const uint16_t*>(P.x) + (int64_t)b * P.x_bstride, cin, t0 - P.pad_left, rows, 0, cin, P.Lin, tid);
+    __syncthreads();
+    if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
+    if (active)
+      hc_gemm_tm<NI, G, PITCH>(acc, P.w + ((int64_t)mt * Utot + (int64_t)kh * G * k) * 512, 16u * (unsigned)lane, k,
+                               xs + l31 * PITCH + lh * 8 + kh * G * 16, dil);
+    __syncthreads();                               // every wave is done reading the tile: it becomes the merge buffer [wm][kh-1][ni][r][lane]
+    float* red = reinterpret_cast<float*>(xs);
+    if (kh > 0) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((((kh - 1) * WN + wm) * NI + ni) * 16 + r) * 64 + lane] = acc[ni][r];
+    }
+    __syncthreads();
+    if (kh > 0) return;
+#pragma unroll
+    for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][r] += red[(((q * WN + wm) * NI + ni) * 16 + r) * 64 + lane];
+  } else {
   for (int c0 = 0; c0 < cin; c0 += HC_CK) {
     const int ck = cin - c0 < HC_CK ? cin - c0 : HC_CK;
     const int pitch = ck + 8;
@@ -278,6 +311,7 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
         hc_gemm<NI>(acc, P.w + ((int64_t)mt * Utot + (int64_t)(c0 >> 4) * k) * 512 + lane * 8, (ck >> 4) * k, k,
                     xs + l31 * pitch + lh * 8, pitch, dil);
     }
+  }
   }
   if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
   if (!active) return;
@@ -318,6 +352,78 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
         }
       }
     }
+    if constexpr (LN) {
+      const float* const lng = P.ln_gamma;
+      // ---- channel LayerNorm of the conv's result in this epilogue (reference attentions.py:103-120: x = norm_layers_1(x + y), x =
+      // norm_layers_2(x + y); modules.LayerNorm = F.layer_norm over channels, eps 1e-5, biased variance).  The workgroup owns ALL cout
+      // channels of its columns (launcher: one 32-row tile per wave, cout = 32 * waves), so the two passes (mean, centred sum of squares)
+      // are a 16-register sum per lane, one cross-half shuffle and a WN-entry LDS exchange each — instead of writing s, a launch of its
+      // own and s read back (7.7 us per LayerNorm at B = 32).  out may be the residual's tensor: every lane has read its residual values.
+      const float* const lnb = P.ln_beta;
+      const float eps = P.ln_eps, invc = 1.f / (float)cout;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[ni][r] + bs[r];
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          if (mask_pre) v *= om[ni];
+          if (res_mode == RES_ADD) v += rv[ni][r];
+          else if (res_mode == RES_RSUB) v = rv[ni][r] - v;
+          if (mask_post) v *= om[ni];
+          acc[ni][r] = v;
+        }
+      __syncthreads();                             // every wave is done with the tile (K split: with the merge buffer): LDS is free
+      float* lnr = reinterpret_cast<float*>(xs);   // [2][WN][NI][32]
+      float mean[NI], rstd[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[ni][r];
+        sacc += __shfl_xor(sacc, 32);
+        if (lh == 0) lnr[(wm * NI + ni) * 32 + l31] = sacc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) t += lnr[(w * NI + ni) * 32 + l31];
+        mean[ni] = t * invc;
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[ni][r] - mean[ni]; q += d * d; }
+        q += __shfl_xor(q, 32);
+        if (lh == 0) lnr[WN * NI * 32 + (wm * NI + ni) * 32 + l31] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) t += lnr[WN * NI * 32 + (w * NI + ni) * 32 + l31];
+        rstd[ni] = rsqrtf(t * invc + eps);
+      }
+      // scale / shift of this lane's 16 rows: loaded here (L2-hot, one exposed round trip), not in front of the reductions — with the
+      // residual values and the accumulators live they did not fit the K-split variant's 168 registers
+      float g16[16], b16[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        g16[r] = lng[co]; b16[r] = lnb[co];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int t = t0 + ni * 32 + l31;
+        if (t >= Lout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          outp[(unsigned)co * o_rs + (unsigned)t] = (acc[ni][r] - mean[ni]) * rstd[ni] * g16[r] + b16[r];
+        }
+      }
+    } else {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int t = t0 + ni * 32 + l31;
@@ -334,6 +440,7 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
         if (mask_post) v *= om[ni];
         outp[(unsigned)co * o_rs + (unsigned)t] = v;
       }
+    }
     }
   } else if (P.act == ACT_GATE) {
     // fused_add_tanh_sigmoid_multiply (commons.py:98-105) on gate-ordered rows: registers r and r + 8 of a lane are the (tanh,
@@ -421,6 +528,10 @@ __global__ void __launch_bounds__(64 * WN) conv_f16_kernel(const HcLaunch L, con
   }
 }
 
+// the LayerNorm epilogue needs the workgroup to own every output channel: one 32-row tile per wave and no idle wave (the epilogue's
+// barriers are workgroup-wide); instantiated for the Encoder stacks' hidden width
+bool conv_f16_ln_supported(int cout) { return cout == 192; }   // six waves x 64 columns: the instantiations below
+
 bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl) {
   if (cin < 16 || cin % 16 || cout < 1 || k < 1 || dil < 1) return false;
   if (out_cl && cout % 4) return false;
@@ -428,7 +539,7 @@ bool conv_f16_supported(int cin, int cout, int k, int dil, bool out_cl) {
   return (int64_t)(64 + (k - 1) * dil) * (ck + 8) * 2 <= 160 * 1024;
 }
 
-template <int WN, int NI, bool IN_CT, bool OUT_CT, int G>
+template <int WN, int NI, bool IN_CT, bool OUT_CT, int G, bool LN = false>
 static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   constexpr int BT = 32 * NI;
   const HcProb& p = L.p[0];
@@ -437,7 +548,7 @@ static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   if (lds > 160 * 1024) return -2;
   const int ngrp = (nt + WN - 1) / WN;
   dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, L.nprob);
-  auto kern = conv_f16_kernel<WN, NI, IN_CT, OUT_CT, G>;
+  auto kern = conv_f16_kernel<WN, NI, IN_CT, OUT_CT, G, 1, LN>;
   ensure_dyn_lds((const void*)kern, lds);
   HcLaunch Lt = L;
   if (L.xcd_b) {
@@ -449,15 +560,39 @@ static int launch_hc_g(hipStream_t stream, const HcLaunch& L, int nt) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// the in-workgroup K split (KS waves per output tile; C_in = KS*16*G staged whole)
+template <int WN, int NI, int G, int KS, bool LN = false>
+static int launch_hc_ks(hipStream_t stream, const HcLaunch& L, int nt) {
+  constexpr int BT = 32 * NI;
+  const HcProb& p = L.p[0];
+  if (p.cin != KS * 16 * G || L.nprob != 1) return -2;
+  const size_t lds_tile = (size_t)(BT + (p.k - 1) * p.dil) * (size_t)(p.cin + 8) * 2;
+  const size_t lds_red = (size_t)(KS - 1) * WN * NI * 16 * 64 * 4;
+  const size_t lds = lds_tile > lds_red ? lds_tile : lds_red;
+  if (lds > 160 * 1024) return -2;
+  const int ngrp = (nt + WN - 1) / WN;
+  dim3 grid((L.L + BT - 1) / BT, L.B * ngrp, 1);
+  auto kern = conv_f16_kernel<WN, NI, false, true, G, KS, LN>;
+  ensure_dyn_lds((const void*)kern, lds);
+  HcLaunch Lt = L;
+  if (L.xcd_b) {
+    Lt.xcd_gx = (int)grid.x; Lt.xcd_per = (int)grid.x * ngrp;
+    grid = dim3(xcd_grid(L.B, Lt.xcd_per), 1, 1);
+  }
+  Lt.dbg = timeline_slice(grid.x, grid.y, 1, 99000 + WN * 100 + NI * 10 + 1 + 4, p.k, p.cin, L.L);   // 99xx5: K split
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WN * KS), lds, stream, Lt, ngrp);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 static bool g_hc_generic = false;     // tests / tuning only (bv2_test_set_variants): the generic GEMM loop instead of the C_in-specialised one
 void conv_f16_set_tuning(int generic) { g_hc_generic = generic != 0; }
 
-template <int WN, int NI, bool IN_CT, bool OUT_CT>
+template <int WN, int NI, bool IN_CT, bool OUT_CT, bool LN = false>
 static int launch_hc(hipStream_t stream, const HcLaunch& L, int nt) {
   const bool generic = g_hc_generic;
-  if (!generic && L.p[0].cin == 192) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 12>(stream, L, nt);
-  if (!generic && L.p[0].cin % 256 == 0) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 16>(stream, L, nt);
-  return launch_hc_g<WN, NI, IN_CT, OUT_CT, 0>(stream, L, nt);
+  if (!generic && L.p[0].cin == 192) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 12, LN>(stream, L, nt);
+  if (!generic && L.p[0].cin % 256 == 0) return launch_hc_g<WN, NI, IN_CT, OUT_CT, 16, LN>(stream, L, nt);
+  return launch_hc_g<WN, NI, IN_CT, OUT_CT, 0, LN>(stream, L, nt);
 }
 
 template <int WN, int NI>
@@ -482,6 +617,7 @@ int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_
     if (!q.out_ct && (q.res_mode != RES_NONE)) return -1;          // the residual add lives in the fp32 [C][T] epilogue
     if (q.act == ACT_GATE && (q.out_ct || q.cout % 32)) return -1; // the gate writes fp16 channels-last, whole (tanh, sigmoid) tiles
     if (q.bias2 && q.act != ACT_GATE) return -1;                   // the per-batch bias only exists in the gate epilogue
+    if (q.ln_gamma && (!conv_f16_ln_supported(q.cout) || !q.out_ct || !q.ln_beta || q.cout_pad != q.cout || L.nprob != 1)) return -1;
   }
   const int nt = p.cout_pad / 32;
   // waves per workgroup (each owns one 32-channel output tile): the count in {8, 6, 4} that wastes the fewest wave slots
@@ -501,6 +637,26 @@ int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_
   static const char* names[3][2] = {{"conv_f16<8w,64>", "conv_f16<8w,128>"}, {"conv_f16<6w,64>", "conv_f16<6w,128>"},
                                     {"conv_f16<4w,64>", "conv_f16<4w,128>"}};
   if (variant_name) *variant_name = names[wn == 8 ? 0 : (wn == 6 ? 1 : 2)][ni == 4 ? 1 : 0];
+  const bool ks_shape = wn == 6 && nt == 6 && p.cin == 768 && !p.in_ct && p.out_ct && L.nprob == 1 && !L.no_ksplit && !g_hc_generic;
+  if (p.ln_gamma) {                               // LayerNorm epilogue: 6 waves x 64 columns (the 128-column tile has no registers left for it)
+    if (wn != 6 || nt != 6) return -1;
+    int r = -2;
+    if (ks_shape) r = launch_hc_ks<6, 2, 24, 2, true>(stream, L, nt);
+    if (r != -2) {
+      if (variant_name) *variant_name = "conv_f16<6w x 2k,64,ln>";
+      return r;
+    }
+    if (variant_name) *variant_name = "conv_f16<6w,64,ln>";
+    return p.in_ct ? launch_hc<6, 2, true, true, true>(stream, L, nt) : launch_hc<6, 2, false, true, true>(stream, L, nt);
+  }
+  // FFN conv_2 (768 -> 192 rows) on 64-column tiles: K halves inside the workgroup (12 waves)
+  if (ks_shape && ni == 2) {
+    const int r = launch_hc_ks<6, 2, 24, 2>(stream, L, nt);
+    if (r != -2) {
+      if (variant_name) *variant_name = "conv_f16<6w x 2k,64>";
+      return r;
+    }
+  }
   if (wn == 8) return ni == 4 ? launch_hc_io<8, 4>(stream, L, nt) : launch_hc_io<8, 2>(stream, L, nt);
   if (wn == 6) return ni == 4 ? launch_hc_io<6, 4>(stream, L, nt) : launch_hc_io<6, 2>(stream, L, nt);
   return ni == 4 ? launch_hc_io<4, 4>(stream, L, nt) : launch_hc_io<4, 2>(stream, L, nt);

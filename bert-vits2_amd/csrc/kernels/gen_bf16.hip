@@ -299,11 +299,22 @@ int launch_conv_cl_bf16(hipStream_t stream, const ClLaunch& L, const char** vari
   // measured at B=32 (profiles/r01_j_*): C=64 is fastest as 8 waves x [64 ch x 64 t] (2x2 register blocking: every B fragment
   // feeds two MFMAs), C >= 128 as one 32-channel tile per wave x 128 t (the 2 x NI forms lose more to fewer resident waves
   // than they gain in LDS traffic)
-  if (v < 0) v = nt >= 8 ? 0 : (nt >= 3 ? 1 : (nt == 2 ? (cin == 64 ? 9 : 2) : 3));
+  bool generic = g_cl_generic;
+  if (v < 0) {
+    v = nt >= 8 ? 0 : (nt >= 3 ? 1 : (nt == 2 ? (cin == 64 ? 9 : 2) : 3));
+    // The ConvTranspose1d launches (one or two taps per phase, three summed sources): staging and the output tile are 3/4 of a workgroup's
+    // life (tools/timeline.py at B = 32: 15k + 12k ticks around a 7.8k-tick GEMM at C_in = 256), so what counts is how many workgroups a CU
+    // holds, not the GEMM loop: the tap-major <8x1> needs 167 registers = ONE 8-wave workgroup per CU.  Per-launch HIP-event times of every
+    // variant, same box (tools/ab_ups.py, profiles/r05_ab_ups_variants.txt): C_in = 256: <4x2,2x2> generic (124 registers, two workgroups)
+    // 242 -> 217 us; C_in = 64 (a 1 x 1 conv, HBM-bound): <2x2> generic 202 -> 158 us.
+    if (L.ups && !generic) {
+      if (nt == 32 && cin == 256) { v = 8; generic = true; }
+      else if (nt == 2 && cin == 64) { v = 2; generic = true; }
+    }
+  }
   static const char* names[] = {"conv_cl_bf16<8x1>", "conv_cl_bf16<4x1>", "conv_cl_bf16<2x2>", "conv_cl_bf16<1x4>",
                                 "conv_cl_bf16<4x1,2x4>", "conv_cl_bf16<2x2,2x4>", "conv_cl_bf16<2x4,2x2>", "conv_cl_bf16<1x4,2x4>",
                                 "conv_cl_bf16<4x2,2x2>", "conv_cl_bf16<1x8,2x2>", "conv_cl_bf16<4x1,t64>", "conv_cl_bf16<8x1,t64>"};
-  const bool generic = g_cl_generic;
   int r = -1;
   for (int attempt = 0; attempt < 2; ++attempt) {
     switch (v) {

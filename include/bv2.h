@@ -265,6 +265,12 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "resblock_c16"    1 (default): the C = 16 bf16 stage's whole-ResBlock launch on v_mfma_f32_16x16x32_bf16 (two taps x 16 channels per
  *                     instruction, unpadded 32-byte LDS rows, two workgroups per CU: kernels/resblock_c16_bf16.hip); 0: the 32x32x16
  *                     whole-ResBlock kernel (resblock_cl_bf16.hip), whose MFMA block is half zero padding at this width
+ *   "f16_fused_ln"    1 (default): in the fp16 Encoder stacks LayerNorm-1 runs in conv_o's epilogue and every LayerNorm-2 that needs nothing else (no
+ *                     speaker add for the next layer, not the stack's last layer) in the FFN conv_2's — the workgroup owns all 192 channels of
+ *                     its columns (kernels/enc_f16.hip); 0: LayerNorm launches of their own (layernorm.hip)
+ *   "f16_ksplit"      1 (default): the fp16 Encoder stacks' FFN conv_2 (C_in = 768 -> 192 rows) on 64-column tiles splits K inside the workgroup:
+ *                     the whole 768-channel tile staged once, 12 waves = 6 output tiles x 2 channel halves, partial sums merged through LDS
+ *                     (kernels/enc_f16.hip); 0: 6 waves over three staged 256-channel chunks.  Same products, another fp32 summation order
  *   "conv_post_rows"  1 (default): the bf16 path's conv_post + tanh at C = 16, k = 7 row-wise (a thread owns one 32-byte input row per branch, K floats
  *                     per thread through LDS); 0: the any-width kernel (C*K scalar LDS reads per output sample).  fp32 arithmetic in both
  *   "ups_phase_taps"  1 (default): a bf16 ConvTranspose1d launch (one conv with C_out' = u*C_out over the union of the phases' tap windows) runs,

@@ -223,3 +223,57 @@ def test_xcd_affine_placement_changes_nothing_but_the_placement(B, Ty):
     m.set_flow_dtype(torch.float32)
     assert torch.isfinite(outs[1]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged"])
+def test_f16_ffn_conv2_ksplit_on_and_off(name):
+    """Round 5: the fp16 FFN conv_2 (reference attentions.py:438-446, 768 -> 192 rows) with K split inside the workgroup ("f16_ksplit" = 1,
+    default: 12 waves on the two channel halves of ONE staged tile, partial sums merged in LDS) and without (6 waves over three staged
+    chunks): the same fp16 products in another fp32 summation order — both at the fp16 oracle's level, and closer to each other than to it."""
+    hp, seed, batch, nw, nz, kw = cases.build_case(name)
+    sd = cached_state_dict(hp, seed)
+    ref32 = O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"], batch["bert"],
+                    batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, **kw)
+    with torch.no_grad():
+        z16 = O.flow_reverse(sd, hp, ref32["z_p"], ref32["y_mask"], ref32["g"], None, "fp16")
+    m = _gpu_model(hp, seed)
+    m.set_flow_dtype(torch.float16)
+    ym = ref32["y_mask"]
+    zs = {}
+    for v in (1, 0):
+        m.set_option("f16_ksplit", v)
+        zs[v] = m.stage_flow(ref32["z_p"], ref32["y_lengths"], ref32["g"]).cpu() * ym
+    m.set_option("f16_ksplit", 1)
+    e1, e0, e10 = _relrms(zs[1], z16 * ym), _relrms(zs[0], z16 * ym), _relrms(zs[1], zs[0])
+    print(f"\n[{name}] fp16 flow vs fp16 oracle: K split {e1:.3e}, chunked {e0:.3e}; the two against each other {e10:.3e}")
+    assert torch.isfinite(zs[1]).all()
+    assert e1 < 2e-3 and e0 < 2e-3 and e10 < 2e-3
+    assert not torch.equal(zs[1], zs[0])               # the switch really changed the kernel
+
+
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "t3_b1"])
+def test_f16_layernorm_in_conv_epilogue_on_and_off(name):
+    """Round 5: in the fp16 Encoder stacks LayerNorm-1 runs in conv_o's epilogue and the plain LayerNorm-2s in the FFN conv_2's
+    ("f16_fused_ln" = 1, default; reference attentions.py:103-120, modules.LayerNorm) — against LayerNorm launches of their own (= 0): the same
+    two-pass statistics over the 192 channels of a column in another summation order.  Both at the fp16 oracle's level, closer to each other
+    than to it; ragged batch and a 3-frame utterance included (columns past an utterance's end are normalised like any other, as in the
+    reference, and masked later)."""
+    hp, seed, batch, nw, nz, kw = cases.build_case(name)
+    sd = cached_state_dict(hp, seed)
+    ref32 = O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"], batch["bert"],
+                    batch["ja_bert"], batch["en_bert"], noise_w=nw, noise_z=nz, **kw)
+    with torch.no_grad():
+        z16 = O.flow_reverse(sd, hp, ref32["z_p"], ref32["y_mask"], ref32["g"], None, "fp16")
+    m = _gpu_model(hp, seed)
+    m.set_flow_dtype(torch.float16)
+    ym = ref32["y_mask"]
+    zs = {}
+    for v in (1, 0):
+        m.set_option("f16_fused_ln", v)
+        zs[v] = m.stage_flow(ref32["z_p"], ref32["y_lengths"], ref32["g"]).cpu() * ym
+    m.set_option("f16_fused_ln", 1)
+    e1, e0, e10 = _relrms(zs[1], z16 * ym), _relrms(zs[0], z16 * ym), _relrms(zs[1], zs[0])
+    print(f"\n[{name}] fp16 flow vs fp16 oracle: LayerNorm in the conv epilogues {e1:.3e}, as launches {e0:.3e}; the two against each other {e10:.3e}")
+    assert torch.isfinite(zs[1]).all()
+    assert e1 < 2e-3 and e0 < 2e-3 and e10 < 2e-3
+    assert not torch.equal(zs[1], zs[0])               # the switch really changed the path

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--symbols", type=int, default=128)
     ap.add_argument("--bf16", action="store_true", help="bf16 Generator + fp16 flow (configs 3 / 5)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=V", help="bv2_set_option before the pass")
     a = ap.parse_args()
     lib = L.load()
     lib.bv2_test_conv_timeline.argtypes = [C.c_void_p, C.c_longlong]
@@ -38,6 +39,9 @@ def main():
     if a.bf16:
         m.set_generator_dtype(torch.bfloat16)
         m.set_flow_dtype(torch.float16)
+    for kv in a.option:
+        key, val = kv.split("=")
+        m.set_option(key, int(val))
     b = {k: v.cuda() for k, v in synth.synthetic_batch([a.symbols] * a.batch).items()}
     kw = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
     call = lambda: m.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"], **kw)
