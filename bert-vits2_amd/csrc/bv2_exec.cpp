@@ -242,9 +242,12 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
       c.conv_h(q, B, T, "enc.ffn1", nullptr, xcd);
       q = c.hprob(L.ffn2, b.f1, false, b.s, true, T);
       q.out_mask = mask; q.mask_pre = 1; q.res = b.x; q.res_mode = RES_ADD;
-      // a plain LayerNorm-2 (no speaker add for the next layer, not the stack's last layer) rides in conv_2's epilogue the same way
-      ln2_in_conv = ln_in_conv && !(i + 1 == kCondLayer && i + 1 < e.n_layers) && i + 1 < e.n_layers;
-      if (ln2_in_conv) { q.out = b.x; q.ln_gamma = c.W(L.g2.off); q.ln_beta = c.W(L.b2.off); q.ln_eps = 1e-5f; }
+      // every LayerNorm-2 but the stack's last (masks, second output, flow_boundary.hip) rides in conv_2's epilogue the same way
+      ln2_in_conv = ln_in_conv && i + 1 < e.n_layers;
+      if (ln2_in_conv) {
+        q.out = b.x; q.ln_gamma = c.W(L.g2.off); q.ln_beta = c.W(L.b2.off); q.ln_eps = 1e-5f;
+        if (i + 1 == kCondLayer) { q.ln_vec = spk; q.ln_vec_bstride = spk_bstride; q.ln_mask = mask; }   // the next layer is the conditioning layer
+      }
       c.conv_h(q, B, T, "enc.ffn2", nullptr, xcd);
       ns = 1;
     } else {

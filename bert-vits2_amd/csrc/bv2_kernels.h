@@ -358,7 +358,9 @@ struct HcProb {
   int cin, cout, cout_pad, k, dil, pad_left;
   // out_ct, cout = 192 (conv_f16_ln_supported): out = LayerNorm over the cout channels of the conv's result (after bias /
   // residual / masks), eps ln_eps, scale / shift ln_gamma / ln_beta [cout]; null = no LayerNorm.  out may be the residual's tensor
+  // ln_vec [B][ln_vec_bstride] / ln_mask [B][out_mask_bstride] (each may be null): out = (LayerNorm(...) + ln_vec[b][c]) * ln_mask[b][t]
   const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const float* ln_vec; int ln_vec_bstride; const float* ln_mask;
 };
 bool conv_f16_ln_supported(int cout);
 // act == ACT_GATE (out_ct = 0 only; WN, reference commons.py:98-105): the weight rows come in gate order (bv2_model.cpp wn_gate_row:

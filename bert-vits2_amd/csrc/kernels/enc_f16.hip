@@ -413,14 +413,23 @@ __global__ void __launch_bounds__(64 * WN * KS) conv_f16_kernel(const HcLaunch L
         const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         g16[r] = lng[co]; b16[r] = lnb[co];
       }
+      // what layernorm.hip folds behind a LayerNorm-2: the speaker vector of the NEXT (conditioning) layer (attentions.py:103-109:
+      // x = x + spk_emb_linear(g), then x * x_mask) — (y + vec[b][c]) * mask[b][t]
+      if (P.ln_vec) {
+        const float* const vp = P.ln_vec + (int64_t)b * P.ln_vec_bstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b16[r] += vp[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      }
+      const float* const lmp = P.ln_mask ? P.ln_mask + (int64_t)b * P.out_mask_bstride : nullptr;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int t = t0 + ni * 32 + l31;
         if (t >= Lout) continue;
+        const float lm = lmp ? lmp[t] : 1.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          outp[(unsigned)co * o_rs + (unsigned)t] = (acc[ni][r] - mean[ni]) * rstd[ni] * g16[r] + b16[r];
+          outp[(unsigned)co * o_rs + (unsigned)t] = ((acc[ni][r] - mean[ni]) * rstd[ni] * g16[r] + b16[r]) * lm;
         }
       }
     } else {

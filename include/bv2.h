@@ -265,8 +265,8 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "resblock_c16"    1 (default): the C = 16 bf16 stage's whole-ResBlock launch on v_mfma_f32_16x16x32_bf16 (two taps x 16 channels per
  *                     instruction, unpadded 32-byte LDS rows, two workgroups per CU: kernels/resblock_c16_bf16.hip); 0: the 32x32x16
  *                     whole-ResBlock kernel (resblock_cl_bf16.hip), whose MFMA block is half zero padding at this width
- *   "f16_fused_ln"    1 (default): in the fp16 Encoder stacks LayerNorm-1 runs in conv_o's epilogue and every LayerNorm-2 that needs nothing else (no
- *                     speaker add for the next layer, not the stack's last layer) in the FFN conv_2's — the workgroup owns all 192 channels of
+ *   "f16_fused_ln"    1 (default): in the fp16 Encoder stacks LayerNorm-1 runs in conv_o's epilogue and every LayerNorm-2 but the stack's last (with the speaker add of the
+ *                     conditioning layer where it follows) in the FFN conv_2's — the workgroup owns all 192 channels of
  *                     its columns (kernels/enc_f16.hip); 0: LayerNorm launches of their own (layernorm.hip)
  *   "f16_ksplit"      1 (default): the fp16 Encoder stacks' FFN conv_2 (C_in = 768 -> 192 rows) on 64-column tiles splits K inside the workgroup:
  *                     the whole 768-channel tile staged once, 12 waves = 6 output tiles x 2 channel halves, partial sums merged through LDS

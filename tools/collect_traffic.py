@@ -32,7 +32,7 @@ def family(kname):
         return "conv1d_splitk<32x32>"
     if "conv_cl_bf16_kernel" in kname:
         for k, v in {"<8, 1, 1, 4,": "conv_cl_bf16<8x1>", "<4, 1, 1, 4,": "conv_cl_bf16<4x1>", "<2, 2, 1, 4,": "conv_cl_bf16<2x2>",
-                     "<1, 4, 1, 4,": "conv_cl_bf16<1x4>", "<1, 8, 2, 2,": "conv_cl_bf16<1x8,2x2>"}.items():
+                     "<1, 4, 1, 4,": "conv_cl_bf16<1x4>", "<1, 8, 2, 2,": "conv_cl_bf16<1x8,2x2>", "<4, 2, 2, 2,": "conv_cl_bf16<4x2,2x2>"}.items():
             if "conv_cl_bf16_kernel" + k in kname:
                 return v
     if "respair_cl_bf16_kernel<" in kname:      # <WN, WM, NI, G>: C = 16 G -> the name launch_respair_cl_bf16 reports
