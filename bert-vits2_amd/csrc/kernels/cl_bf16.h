@@ -88,7 +88,7 @@ __device__ __forceinline__ void cl_stage(unsigned short* xs, int pitch, const ui
                                          const uint16_t* s2, int nsrc, float in_scale, bool lrelu, float slope, int tb,
                                          int rows, int cin, int Lin, int tid) {
   if (nsrc == 1) cl_stage_impl<NT, 12, false>(xs, pitch, s0, s1, s2, nsrc, in_scale, lrelu, slope, tb, rows, cin, Lin, tid);
-  else cl_stage_impl<NT, 4, true>(xs, pitch, s0, s1, s2, nsrc, in_scale, lrelu, slope, tb, rows, cin, Lin, tid);
+  else cl_stage_impl<NT, 6, true>(xs, pitch, s0, s1, s2, nsrc, in_scale, lrelu, slope, tb, rows, cin, Lin, tid);
 }
 
 // acc[mi][ni] += sum over units u = (s, j) of Wfrag(mi, u) x B(u, ni);  B(u, ni) = 8 channels [16s + 8lh, +8) of LDS row
