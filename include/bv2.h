@@ -293,12 +293,17 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)
  *   "x6_pair"         fp32 mode, the C = 64 / 32 / 16 Generator stages one (dilated conv, conv) ResBlock pair per launch with both convs on
  *                     the bf16 matrix core and the intermediate planes in LDS (kernels/respair_x6.hip; bit-identical to the two conv_x6
- *                     launches); 0: two launches per pair.  "x6_pair_c64" / "x6_pair_c16" = 0: without that stage (C = 16: back on
- *                     resblock_fused.hip); "x6_pair_c128" = 1: also C = 128 (no gain)
+ *                     launches); 0: two launches per pair
+ *   "x6_pair_c64"     1 (default); 0: "x6_pair" without the C = 64 stage
+ *   "x6_pair_c16"     1 (default); 0: "x6_pair" without the C = 16 stage (back on resblock_fused.hip)
+ *   "x6_pair_c128"    0 (default); 1: "x6_pair" also on the C = 128 stage (one 8-wave workgroup per CU: measured, no gain)
  *   "fused_boundary"  transformer flow, small-batch fp32 regime: LayerNorm-2 of a coupling's last Encoder layer, its `post` and the next
  *                     coupling's `pre` in one launch (kernels/flow_boundary.hip); 0: three launches
  *   "fused_attn_o"    MultiHeadAttention.conv_o inside the attention kernel in the small-batch fp32 regime: head h writes partial
  *                     slab h, the LayerNorm sums the slabs (0: conv_o as its own launch)
+ *   "attn_ksplit"     -1 (default): the key ranges per (head, query tile) of the fused attention are picked per shape (2 or 4 at batch 1 and long
+ *                     sequences: each range's workgroup writes its own partial slab, LayerNorm-1 merges them with the flash-decoding weights);
+ *                     0 / 1: no key split; 2 / 4: that many ranges where the slabs allow it
  *   "overlap_dp"      default 0: 1 runs the DurationPredictor on an internal side stream beside the stochastic one (fork / join
  *                     with events on the caller's stream; measured slower at batch 1, kept for experiments)
  * Captured graphs keep whatever was selected when they were recorded. */

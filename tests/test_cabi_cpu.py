@@ -369,3 +369,19 @@ def test_resblock2_config_packs_and_the_shorter_config_struct_still_means_resblo
     assert lib.bv2_create(C.byref(cfg1), C.byref(h)) == 0
     assert lib.bv2_packed_bytes(h) == n_short                        # same layout either way
     lib.bv2_destroy(h)
+
+
+def test_every_option_key_is_documented_and_every_documented_key_exists():
+    """`bv2_set_option` keys (csrc/bv2_api.cpp) against the option list in include/bv2.h's comment: a switch nobody can find in the header, or
+    a documented one the library rejects, is a boundary bug.  ("bv2_bert_set_option" keys live in include/bv2_bert.h.)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "bert-vits2_amd", "csrc", "bv2_api.cpp")).read()
+    body = api[api.index("int bv2_set_option("):]
+    body = body[:body.index("unknown key")]
+    keys = set(re.findall(r'k == "([a-z0-9_]+)"', body))
+    hdr = open(os.path.join(root, "include", "bv2.h")).read()
+    documented = set(re.findall(r'^ \*   "([a-z0-9_]+)"', hdr, flags=re.M))
+    assert len(keys) >= 20
+    assert keys - documented == set(), f"undocumented option keys: {sorted(keys - documented)}"
+    assert documented - keys == set(), f"documented but unknown to bv2_set_option: {sorted(documented - keys)}"
