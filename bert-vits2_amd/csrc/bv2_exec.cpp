@@ -719,6 +719,7 @@ static void flow_core(Ctx& c, const PlanB& P, float* z, const float* ymask, cons
   const int H = cf.hidden_channels, C = cf.inter_channels, half = C / 2;
   float* gv_flow = P.gv + cf.upsample_initial_channel;
   bool pre_done = false;                            // the previous coupling's boundary launch already wrote this coupling's h
+  if (m.flow_flip_first) c.chk(launch_flip_channels(c.s, z, B, C, Ty), "flow.flip");   // odd coupling count: see bv2_model.cpp
   for (int a = 0; a < m.n_coupling; ++a) {
     const CouplingW& K = m.coupling[a];
     float* x0 = z + (K.flipped ? (int64_t)half * Ty : 0);

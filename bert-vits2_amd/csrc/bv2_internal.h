@@ -72,6 +72,7 @@ struct UpW {
 
 struct Model {
   bv2_config cfg;
+  bool flow_flip_first = false;      // odd number of couplings: the reverse pass starts with a real channel Flip of z (bv2_model.cpp)
   // enc_p
   VecW emb, tone_emb, lang_emb;
   ConvW bert[3];

@@ -537,6 +537,7 @@ struct EmbedArgs {
 int launch_embed(hipStream_t stream, const EmbedArgs& a);
 
 // out[b][c][t] = (a[b][c][t] + vec[b][c]) * mask[b][t]     (vec / mask may be null)
+int launch_flip_channels(hipStream_t stream, float* z, int B, int C, int T);   // z[b][c][t] <-> z[b][C-1-c][t] in place (modules.Flip)
 int launch_add_vec_mask(hipStream_t stream, const float* a, const float* vec, int vec_bstride, const float* mask,
                         float* out, int B, int C, int T);
 

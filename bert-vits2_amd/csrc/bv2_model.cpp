@@ -349,7 +349,11 @@ int pack_all(Model& m, Packer& P) {
     CouplingW& C = m.coupling[a];
     const int f = m.n_coupling - 1 - a;
     const std::string p = "flow.flows." + std::to_string(2 * f);
-    C.flipped = (a % 2) == 0;                      // a+1 Flips have been applied before coupling a
+    // a+1 Flips have been applied before coupling a (reverse pass: Flip, C_{n-1}, Flip, ..., C_0).  They are folded into pre's input /
+    // post's output channel order instead of moving data — which leaves the tensor un-flipped at the end only if their number n is even.
+    // Odd n: the FIRST Flip is real data movement (flow_core, one launch per pass), the remaining n - 1 are folded
+    m.flow_flip_first = (m.n_coupling % 2) == 1;
+    C.flipped = m.flow_flip_first ? (a % 2) == 1 : (a % 2) == 0;
     C.pre = P.conv1d(p + ".pre", hid, half, 1, true, false, 0, -1, /*rev_in=*/C.flipped, false);
     if (c.use_transformer_flow) {
       P.emit_f16 = true;                           // BASELINE config 5 "fp16 flow": q/k/v/o and FFN convs also as fp16 streams

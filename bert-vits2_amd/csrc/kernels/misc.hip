@@ -329,6 +329,23 @@ int launch_add_vec_mask(hipStream_t stream, const float* a, const float* vec, in
   return BV2_CHECK_LAUNCH();
 }
 
+// modules.Flip (reference modules.py:374-381: torch.flip(x, [1])) as data movement, in place: z[b][c][t] <-> z[b][C-1-c][t].  Only for a flow
+// with an ODD number of couplings, once per reverse pass (bv2_exec.cpp flow_core): the other Flips are folded into the packed pre / post
+// weights, which cancels out only for an even count
+__global__ void flip_channels_kernel(float* z, int C, int T) {
+  const int b = blockIdx.z, c = blockIdx.y;       // c < C / 2
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int64_t lo = ((int64_t)b * C + c) * T + t, hi = ((int64_t)b * C + (C - 1 - c)) * T + t;
+  const float a = z[lo], h = z[hi];
+  z[lo] = h; z[hi] = a;
+}
+int launch_flip_channels(hipStream_t stream, float* z, int B, int C, int T) {
+  if (C < 2) return 0;
+  hipLaunchKernelGGL(flip_channels_kernel, dim3((T + 255) / 256, C / 2, B), dim3(256), 0, stream, z, C, T);
+  return BV2_CHECK_LAUNCH();
+}
+
 __global__ void scale_kernel(const float* in, float* out, float s, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = in[i] * s;

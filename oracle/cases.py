@@ -40,6 +40,13 @@ CASES = {
     # `resblock: "2"` (reference models.py:508, modules.py:318-363): ONE weight-normed conv per dilation, VITS's small-vocoder setting
     "rb2_b2_t14": dict(hp=dict(resblock="2", resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12))),
                        lengths=[14, 9], languages=[0, 2], sids=[4, 77], seed=0, kw=INFER_KW),
+    # a NARROWER model than any released config — every width the kernels template on takes another value: hidden 128 (head dim 64), FFN 512,
+    # inter 128 (the flow's half = 64), 4 + 3 Encoder layers, 3 couplings, gin 256, three upsampling stages 8 x 4 x 2 with kernels 16 / 8 / 4
+    # (2 taps per phase everywhere; final Generator width 32)
+    "narrow_b2_t18": dict(hp=dict(hidden_channels=128, filter_channels=512, inter_channels=128, n_layers=4, n_layers_trans_flow=3,
+                                  n_flow_layer=3, gin_channels=256, upsample_rates=(8, 4, 2), upsample_kernel_sizes=(16, 8, 4),
+                                  upsample_initial_channel=256),
+                          lengths=[18, 11], languages=[0, 1], sids=[2, 640], seed=0, kw=INFER_KW),
 }
 # cases whose fixture also stores the reference's autocast runs
 AUTOCAST_CASES = [n for n, c in CASES.items() if c.get("autocast")] + ["mix_b2_ragged"]

@@ -74,6 +74,12 @@ def build_reference_net(hp, state_dict):
     model_kwargs["resblock"] = str(hp.resblock)                      # "1" = modules.ResBlock1, anything else ResBlock2 (models.py:508)
     model_kwargs["resblock_kernel_sizes"] = [int(k) for k in hp.resblock_kernel_sizes]
     model_kwargs["resblock_dilation_sizes"] = [[int(v) for v in d] for d in hp.resblock_dilation_sizes]
+    # every width / depth the shim's HParams carries (a case may describe a narrower model than configs/config.json)
+    for k in ("inter_channels", "hidden_channels", "filter_channels", "n_heads", "n_layers", "kernel_size", "upsample_initial_channel",
+              "gin_channels"):
+        model_kwargs[k] = int(getattr(hp, k))
+    model_kwargs["upsample_rates"] = [int(v) for v in hp.upsample_rates]
+    model_kwargs["upsample_kernel_sizes"] = [int(v) for v in hp.upsample_kernel_sizes]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         net = models.SynthesizerTrn(hp.n_vocab, hp.spec_channels, hp.segment_size,

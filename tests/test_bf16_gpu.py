@@ -112,7 +112,7 @@ def _relrms(a, b):
     return rms(a - b) / max(rms(b), 1e-30)
 
 
-@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "rb2_b2_t14"])      # rb2: `resblock: "2"` (modules.ResBlock2), layer-wise
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "rb2_b2_t14", "narrow_b2_t18"])      # rb2: `resblock: "2"` (modules.ResBlock2), layer-wise; narrow: three stages 8 x 4 x 2, final width 32
 def test_stage_generator_bf16_vs_bf16_oracle(name):
     hp, seed, batch, nw, nz, kw = cases.build_case(name)
     sd = cached_state_dict(hp, seed)
@@ -185,7 +185,7 @@ def maxrel_z(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
 
 
-@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged"])
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "narrow_b2_t18"])      # narrow: rates 8 / 4 / 2 with kernels 16 / 8 / 4
 def test_convtranspose_phase_taps_bit_identical(name):
     """Round 5: a bf16 ConvTranspose1d launch (one conv over the union of the u phases' tap windows, reference models.py:538-549) runs per wave
     only the taps of the phases its output channels belong to ("ups_phase_taps", default 1).  The taps it steps over are zeros the packer

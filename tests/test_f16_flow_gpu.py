@@ -116,7 +116,7 @@ def _relrms(a, b):
     return rms(a - b) / max(rms(b), 1e-30)
 
 
-@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "wn_b1_t16", "wn_b2_t40"])
+@pytest.mark.parametrize("name", ["zh_b1_t24", "mix_b2_ragged", "wn_b1_t16", "wn_b2_t40", "narrow_b2_t18"])   # narrow: hidden 128, FFN 512, half = 64
 def test_stage_flow_f16_vs_f16_oracle(name):
     hp, seed, batch, nw, nz, kw = cases.build_case(name)
     sd = cached_state_dict(hp, seed)
