@@ -13,10 +13,10 @@ SCRIPT = """
 import sys, torch
 sys.path.insert(0, %r)
 from bert_vits2_amd.bert_encoder import BertEncoder
-from oracle import bert_oracle as BO
-cfg = BO.LARGE
-enc = BertEncoder(**cfg).load_state_dict(BO.synthetic_state_dict(cfg, 0, layers=22), device="cuda:0")
-ids, _ = BO.synthetic_inputs(cfg, [53], 0)          # bench.py's bert_zh_features workload: B = 1, S = 53
+from bert_vits2_amd import bert_synth as BS
+cfg = BS.LARGE
+enc = BertEncoder(**cfg).load_state_dict(BS.bert_state_dict(cfg, 0, layers=22), device="cuda:0")
+ids, _ = BS.synthetic_inputs(cfg, [53], 0)          # bench.py's bert_zh_features workload: B = 1, S = 53
 ids = ids.cuda()
 for _ in range(10):
     enc(ids)
