@@ -228,6 +228,49 @@ def parity_block(model, hp, dev, par):
     return res
 
 
+def parity_unpinned_block(hp, dev, T=128):
+    """The parity check that CAN fail on the integer outputs: an un-pinned checkpoint (dp.proj as drawn, not zeroed), sdp_ratio 0.5 (both
+    duration predictors, the spline flows), NO w_ceil injection — the HIP path's own ceil'd durations / frame count / alignment path against the
+    oracle's on a 128-symbol utterance.  (parity_block above runs the MEASURED utterance, whose durations are pinned to ceil(2.5) so that T_y is the
+    same on every box: its w_ceil_match / attn_equal cannot fail.)  If a 1-ulp logw difference flips a ceil(), the downstream comparison is repeated
+    with the oracle's durations and says so."""
+    from oracle import bv2_oracle as O, mel
+    kw = dict(KW, sdp_ratio=0.5)
+    sd = synth.synthetic_state_dict(hp, seed=0)
+    batch = synth.synthetic_batch([T], languages=[0], sids=[3])
+    nw, nz = synth.synthetic_noise(1, T, 8 * T, hp.inter_channels)
+    with torch.no_grad():
+        ref = O.infer(sd, hp, batch["x"], batch["x_lengths"], batch["sid"], batch["tone"], batch["language"], batch["bert"], batch["ja_bert"],
+                      batch["en_bert"], noise_w=nw, noise_z=nz, **kw)
+    m = models.from_hparams(hp)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    b = {k: v.to(dev) for k, v in batch.items()}
+    args = (b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"])
+    o, attn, y_mask, _ = m.infer(*args, noise_w=nw, noise_z=nz.to(dev), **kw)
+    torch.cuda.synchronize()
+    wc = m.last_encode["w_ceil"].cpu().reshape(ref["w_ceil"].shape)
+    match = float((wc == ref["w_ceil"]).float().mean())
+    res = dict(config=f"un-pinned synthetic checkpoint, B=1, T={T}, sdp_ratio 0.5, fp32, no duration injection: HIP path vs the CPU oracle",
+               w_ceil_match=match, distinct_durations=int(ref["w_ceil"].unique().numel()), frames=int(y_mask.sum().item()),
+               frames_oracle=int(ref["y_lengths"].sum()), pinned_after_flip=False)
+    if match < 1.0:
+        o, attn, y_mask, _ = m.infer(*args, noise_w=nw, noise_z=nz.to(dev), w_ceil=ref["w_ceil"], **kw)
+        torch.cuda.synchronize()
+        res["pinned_after_flip"] = True
+    o = o.cpu()
+    if o.shape == ref["o"].shape:
+        n = int(ref["y_lengths"][0]) * hp.total_upsample
+        d = (o[0, 0, :n] - ref["o"][0, 0, :n]).double()
+        res.update(wave_rms=float(d.pow(2).mean().sqrt()), signal_rms=float(ref["o"][0, 0, :n].double().pow(2).mean().sqrt()),
+                   mel_l1=float(mel.mel_l1(o[:, 0].numpy(), ref["o"][:, 0].numpy(), [n])),
+                   attn_equal=bool(torch.equal(attn.cpu(), ref["attn"])))
+    else:
+        res["error"] = f"shape mismatch {tuple(o.shape)} vs {tuple(ref['o'].shape)}"
+    del m
+    return res
+
+
 def file_digest(name):
     with open(os.path.join(ROOT, "bert-vits2_amd", "csrc", "kernels", name), "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
@@ -832,11 +875,16 @@ def headline(line, details_path=None):
         h["cpu_baseline"] = None
     if isinstance(line.get("parity"), dict):
         h["parity"] = _pick(line["parity"], ("w_ceil_match", "wave_rms", "wave_max_abs", "signal_rms", "mel_l1", "attn_equal", "error"))
-        for k, v in list(h["parity"].items()):
-            if isinstance(v, float):
-                h["parity"][k] = float(f"{v:.4g}")
-            elif isinstance(v, str):
-                h["parity"][k] = v[:120]
+        for blk in (h["parity"],):
+            if isinstance(line["parity"].get("unpinned"), dict):
+                blk["unpinned"] = _pick(line["parity"]["unpinned"], ("w_ceil_match", "distinct_durations", "frames", "frames_oracle", "pinned_after_flip",
+                                                                      "wave_rms", "mel_l1", "attn_equal", "error"))
+        for blk in (h["parity"], h["parity"].get("unpinned") or {}):
+            for k, v in list(blk.items()):
+                if isinstance(v, float):
+                    blk[k] = float(f"{v:.4g}")
+                elif isinstance(v, str):
+                    blk[k] = v[:120]
     u = line.get("upsampling_roofline")
     if isinstance(u, dict) and "error" not in u:
         h["upsampling_roofline"] = _pick(u, ("bound", "achieved", "peak", "unit", "frac", "ms_per_step"))
@@ -1126,6 +1174,8 @@ def rank_main(args):
                 try:
                     parity = parity_block(model, hp, dev, par)
                     log(f"parity (config 2's utterance vs the oracle): {parity}")
+                    parity["unpinned"] = parity_unpinned_block(hp, dev)
+                    log(f"parity (un-pinned utterance, no duration injection): {parity['unpinned']}")
                 except Exception as e:
                     parity = dict(error=repr(e)[:300])
         s = summary(res, hp, world, dt, audio)

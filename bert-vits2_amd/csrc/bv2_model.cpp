@@ -534,33 +534,49 @@ int pack_all(Model& m, Packer& P) {
   return 0;
 }
 
+// The accepted hyper-parameter envelope == the tested one (bert_vits2_amd/hparams.py ENVELOPE holds the same numbers; tests/test_envelope_cpu.py
+// checks both sides agree and that every bound below rejects).  Its corners are pinned on the GPU against goldens of the real reference
+// (oracle/cases.ENVELOPE), its interior against the oracle (cases.random_hparams).  Round 5 accepted far more than anything ran — and an accepted,
+// never-run config (odd coupling count) had been wrong for four rounds.
 int validate(const bv2_config& c, std::string& err) {
   auto bad = [&](const char* s) { err = s; return -1; };
+  auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
   if (c.struct_bytes != (int32_t)sizeof(bv2_config)) return bad("bv2_config.struct_bytes does not match this library");
+  if (c.n_vocab < 1 || c.n_tones < 1 || c.n_languages < 1 || c.bert_dim < 8 || c.bert_dim % 8)
+    return bad("n_vocab / n_tones / n_languages must be >= 1 and bert_dim a multiple of 8");
   if (c.n_heads < 1 || c.hidden_channels % c.n_heads) return bad("hidden_channels must be divisible by n_heads (attentions.py:223)");
+  if (!in(c.hidden_channels, 96, 256) || c.hidden_channels % 32) return bad("hidden_channels must be a multiple of 32 in 96..256");
   const int dk = c.hidden_channels / c.n_heads;
-  if (dk % 32 || dk > 128) return bad("head dim must be a multiple of 32, <= 128");
-  if (c.hidden_channels > 256 || c.hidden_channels % 16) return bad("hidden_channels must be a multiple of 16, <= 256");
-  if (c.inter_channels % 32) return bad("inter_channels must be a multiple of 32");
-  if (c.n_layers < 1 || c.n_layers > kMaxLayers || c.n_layers_trans_flow > kMaxLayers) return bad("too many encoder layers");
-  if (c.n_layers <= kCondLayer) return bad("n_layers must exceed cond_layer_idx=2 (attentions.py:73-75)");
-  if (c.use_transformer_flow && c.n_layers_trans_flow <= kCondLayer) return bad("n_layers_trans_flow must exceed cond_layer_idx=2");
-  if (c.n_flow_layer < 1 || c.n_flow_layer > kMaxFlows) return bad("n_flow_layer out of range");
-  if (c.gin_channels < 1 || c.n_speakers < 1) return bad("gin_channels and n_speakers must be >= 1 (ReferenceEncoder path is out of scope)");
-  if (c.n_upsamples < 1 || c.n_upsamples > BV2_MAX_UPS) return bad("n_upsamples out of range");
-  if (c.n_resblock_kernels < 1 || c.n_resblock_kernels > 3) return bad("1..3 resblock kernels supported");
-  if (c.n_resblock_dilations < 1 || c.n_resblock_dilations > BV2_MAX_RESBLOCK_DILATIONS) return bad("resblock dilations out of range");
+  if (dk % 32 || dk > 128) return bad("head dim (hidden_channels / n_heads) must be 32, 64, 96 or 128");
+  if (!in(c.filter_channels, 128, 1024) || c.filter_channels % 64) return bad("filter_channels must be a multiple of 64 in 128..1024");
+  if (!in(c.inter_channels, 64, 256) || c.inter_channels % 32) return bad("inter_channels must be a multiple of 32 in 64..256");
+  if (c.kernel_size != 1 && c.kernel_size != 3 && c.kernel_size != 5 && c.kernel_size != 7) return bad("FFN kernel_size must be 1, 3, 5 or 7");
+  if (!in(c.n_layers, kCondLayer + 1, 8)) return bad("n_layers must be 3..8 (cond_layer_idx = 2 < n_layers, attentions.py:69-75)");
+  if (c.use_transformer_flow && !in(c.n_layers_trans_flow, kCondLayer + 1, 8)) return bad("n_layers_trans_flow must be 3..8");
+  if (!in(c.n_flow_layer, 1, kMaxFlows)) return bad("n_flow_layer must be 1..8");
+  if (c.n_speakers < 1) return bad("n_speakers must be >= 1 (the ReferenceEncoder path, models.py:1047-1048, is out of scope)");
+  if (!in(c.gin_channels, 64, 768) || c.gin_channels % 64) return bad("gin_channels must be a multiple of 64 in 64..768");
+  if (!in(c.n_upsamples, 2, 5)) return bad("2..5 upsampling stages supported");
+  if (!in(c.n_resblock_kernels, 1, 3)) return bad("1..3 resblock kernels supported");
+  if (c.resblock_type != 1 && c.resblock_type != 2) return bad("resblock_type must be 1 (ResBlock1) or 2 (ResBlock2)");
+  // modules.ResBlock1 reads dilation[0..2], ResBlock2 dilation[0..1] and ignores the rest (modules.py:208-258, 318-346): hand over exactly those
+  if (c.resblock_type == 1 && c.n_resblock_dilations != 3) return bad("ResBlock1 has exactly three (dilated conv, conv) pairs: n_resblock_dilations must be 3");
+  if (c.resblock_type == 2 && c.n_resblock_dilations != 2) return bad("ResBlock2 has exactly two convs (dilation[0], dilation[1]: modules.py:318-346)");
   for (int i = 0; i < c.n_upsamples; ++i) {
     const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
-    if (u < 1 || u > BV2_MAX_UPS || k < u || k % u || (k - u) % 2) return bad("upsample kernel must be a multiple of its rate with even (k-u)");
-    if ((c.upsample_initial_channel >> (i + 1)) < 1) return bad("upsample_initial_channel too small");
+    if (!in(u, 2, BV2_MAX_UPS)) return bad("upsample rates must be 2..8");
+    if (k < u || k % u || (k - u) % 2 || k / u > 4) return bad("upsample kernel must be 1..4 x its rate with even (kernel - rate)");
   }
-  if ((c.upsample_initial_channel >> c.n_upsamples) % 16) return bad("final Generator width must be a multiple of 16");
-  for (int j = 0; j < c.n_resblock_kernels; ++j)
-    if (c.resblock_kernel_sizes[j] % 2 == 0) return bad("resblock kernels must be odd");
-  if (c.resblock_type != 1 && c.resblock_type != 2) return bad("resblock_type must be 1 (ResBlock1) or 2 (ResBlock2)");
-  if (c.resblock_type == 2 && c.n_resblock_dilations != 2) return bad("ResBlock2 has exactly two convs (dilation[0], dilation[1]: modules.py:318-346)");
-  if (c.kernel_size % 2 == 0) return bad("FFN kernel_size must be odd");
+  // 512 = the released width; a 1024-channel channels-last bf16 ConvTranspose tile does not fit the 160 KB LDS (gen_bf16.hip conv_cl_bf16_supported)
+  if (!in(c.upsample_initial_channel, 64, 512) || c.upsample_initial_channel % (1 << c.n_upsamples))
+    return bad("upsample_initial_channel must be 64..512 and divisible by 2^n_upsamples");
+  const int fw = c.upsample_initial_channel >> c.n_upsamples;
+  if (fw != 16 && fw != 32 && fw != 64) return bad("final Generator width (upsample_initial_channel >> n_upsamples) must be 16, 32 or 64");
+  for (int j = 0; j < c.n_resblock_kernels; ++j) {
+    if (c.resblock_kernel_sizes[j] % 2 == 0 || !in(c.resblock_kernel_sizes[j], 3, 11)) return bad("resblock kernels must be odd, 3..11");
+    for (int d = 0; d < c.n_resblock_dilations; ++d)
+      if (!in(c.resblock_dilation_sizes[j][d], 1, 12)) return bad("resblock dilations must be 1..12");
+  }
   return 0;
 }
 

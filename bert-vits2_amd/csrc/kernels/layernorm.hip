@@ -198,7 +198,11 @@ static void launch_ln_cfg(hipStream_t stream, const LnArgs& a, dim3 grid) {
   }
   switch (a.nslab) {
     case 2: hipLaunchKernelGGL((layernorm_kernel<CPT, 2, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((layernorm_kernel<CPT, 4, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<CPT, 3, 0, GUARD>), grid, dim3(256), 0, stream, a); break;   // 3 / 5 / 6 / 7: one slab per head of the
+    case 4: hipLaunchKernelGGL((layernorm_kernel<CPT, 4, 0, GUARD>), grid, dim3(256), 0, stream, a); break;   // fused attention + conv_o with n_heads off the powers of two
+    case 5: hipLaunchKernelGGL((layernorm_kernel<CPT, 5, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((layernorm_kernel<CPT, 6, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
+    case 7: hipLaunchKernelGGL((layernorm_kernel<CPT, 7, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
     case 8: hipLaunchKernelGGL((layernorm_kernel<CPT, 8, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
     default: hipLaunchKernelGGL((layernorm_kernel<CPT, 1, 0, GUARD>), grid, dim3(256), 0, stream, a); break;
   }
@@ -208,7 +212,7 @@ int launch_layernorm(hipStream_t stream, const LnArgs& a) {
   if (a.C > LN_G * 8 || a.C < 1 || a.T < 1 || a.B < 1) return -1;
   if ((int64_t)a.C * a.T >= (1ll << 31)) return -1;             // 32-bit in-batch offsets
   const int ns = a.nslab < 1 ? 1 : a.nslab;
-  if (a.mode == 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8) return -1;
+  if (a.mode == 0 && ns > 8) return -1;
   if (a.ml && (a.mode != 0 || (ns != 4 && ns != 8) || (a.ml_ks != 2 && a.ml_ks != 4) || a.ml_H * a.ml_ks != ns)) return -1;
   dim3 grid((a.T + LN_TT - 1) / LN_TT, a.B);
   LnArgs ax = a;

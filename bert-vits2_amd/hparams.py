@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import dataclasses
 import json
+import warnings
 from typing import List, Sequence
 
 # symbol-table sizes of reference text/symbols.py:167-183 (v2.3): 112 symbols, 12 tones, 3 languages
@@ -28,6 +29,28 @@ DP_KERNEL = 3
 FLOW_KERNEL = 5           # reference models.py:903-924 (both flow variants use 5)
 WN_DILATION_RATE = 1
 LRELU_SLOPE = 0.1         # reference modules.py:14
+
+# The hyper-parameter envelope bv2_create() accepts (csrc/bv2_model.cpp validate(), the same numbers) — every range below is exercised on the
+# GPU against goldens of the real reference at its corners (oracle/cases.ENVELOPE) and against the oracle in its interior
+# (cases.random_hparams); a config outside is rejected with a message rather than run untested.  Lists are value sets, pairs are inclusive ranges.
+ENVELOPE = dict(
+    hidden_channels=[96, 128, 160, 192, 224, 256],
+    head_dim=[32, 64, 96, 128],                          # hidden_channels / n_heads
+    filter_channels=[128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 832, 896, 960, 1024],     # multiples of 64
+    inter_channels=[64, 96, 128, 160, 192, 224, 256],    # multiples of 32
+    kernel_size=[1, 3, 5, 7],
+    n_layers=(3, 8),                                     # > cond_layer_idx = 2 (attentions.py:69-75); also n_layers_trans_flow
+    n_flow_layer=(1, 8),
+    gin_channels=[64, 128, 192, 256, 384, 512, 768],     # multiples of 64 up to 768
+    n_resblock_kernels=(1, 3),
+    resblock_kernel=[3, 5, 7, 9, 11],
+    resblock_dilation=(1, 12),
+    n_upsamples=(2, 5),
+    upsample_rate=[2, 3, 4, 5, 6, 7, 8],
+    upsample_taps_per_phase=(1, 4),                      # kernel / rate, with (kernel - rate) even
+    upsample_initial_channel=(64, 512),                  # 1024 would need a K-chunked bf16 ConvTranspose tile (LDS); the fp32 form has no such limit
+    final_generator_width=[16, 32, 64],                  # upsample_initial_channel >> n_upsamples
+)
 
 
 @dataclasses.dataclass
@@ -69,9 +92,14 @@ class HParams:
 
     def validate(self) -> None:
         if str(self.resblock) not in ("1", "2"):
-            raise ValueError("resblock must be '1' (modules.ResBlock1) or '2' (modules.ResBlock2): reference models.py:508")
-        if str(self.resblock) == "2" and any(len(d) < 2 for d in self.resblock_dilation_sizes):
-            raise ValueError("ResBlock2 takes dilation[0] and dilation[1] (reference modules.py:318-346)")
+            # reference models.py:508: `modules.ResBlock1 if resblock == "1" else modules.ResBlock2` — every other value means ResBlock2
+            warnings.warn(f"resblock={self.resblock!r}: the reference treats every value but '1' as ResBlock2 (models.py:508); doing the same")
+        need = 3 if str(self.resblock) == "1" else 2
+        if len(self.resblock_dilation_sizes) != len(self.resblock_kernel_sizes):
+            # the reference zips the two lists (models.py:524-527) and silently drops the tail of the longer one; a config like that is a typo
+            raise ValueError("resblock_kernel_sizes and resblock_dilation_sizes must have the same length")
+        if any(len(d) < need for d in self.resblock_dilation_sizes):
+            raise ValueError(f"ResBlock{'1' if need == 3 else '2'} reads dilation[0..{need - 1}] (reference modules.py:208-258, 318-346)")
         if self.flow_share_parameter:
             # the reference itself crashes here: attentions.FFT does not exist (models.py:107)
             raise NotImplementedError("flow_share_parameter=True is broken in the reference (models.py:107)")

@@ -202,9 +202,10 @@ def make_config(hp: H.HParams) -> Config:
         c.upsample_rates[i], c.upsample_kernel_sizes[i] = int(u), int(k)
     c.upsample_initial_channel = hp.upsample_initial_channel
     rk, rd = list(hp.resblock_kernel_sizes), [list(d) for d in hp.resblock_dilation_sizes]
-    c.resblock_type = 2 if str(hp.resblock) == "2" else 1
-    if c.resblock_type == 2:                     # modules.ResBlock2 builds exactly two convs, from dilation[0] and dilation[1]
-        rd = [d[:2] for d in rd]
+    c.resblock_type = 1 if str(hp.resblock) == "1" else 2          # reference models.py:508: anything but "1" is modules.ResBlock2
+    # modules.ResBlock1 reads dilation[0..2], ResBlock2 dilation[0..1]; longer lists are ignored by the reference (modules.py:208-258, 318-346),
+    # shorter ones raise IndexError there and ValueError in hp.validate().  A direct C caller must hand over exactly 3 / 2 (bv2.h).
+    rd = [d[:3] if c.resblock_type == 1 else d[:2] for d in rd]
     if len(rk) > MAX_RBK or len(rd) != len(rk) or any(len(d) != len(rd[0]) or len(d) > MAX_RBD for d in rd):
         raise ValueError("bad resblock configuration")
     c.n_resblock_kernels = len(rk)
