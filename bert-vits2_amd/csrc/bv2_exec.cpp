@@ -392,6 +392,7 @@ PlanA plan_a(Arena& A, const Model& m, int B, int T) {
 struct PlanB {
   float *gv, *zp, *z, *h, *acts, *outacc, *pre, *ymask;
   int* fidx;
+  int64_t* len_cap;                  // [B] the batch's longest y_length, broadcast (exact_lengths == 2)
   EncBufs enc;
   float* set[2][7];
   int gv_stride;
@@ -415,6 +416,7 @@ PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
   p.gv = A.get<float>((int64_t)B * p.gv_stride);
   p.fidx = A.get<int>(BT);
   p.ymask = A.get<float>(BT);
+  p.len_cap = A.get<int64_t>(B);
   p.zp = A.get<float>(BT * c.inter_channels);
   p.z = A.get<float>(BT * c.inter_channels);
   p.h = A.get<float>(BT * H);
@@ -1272,7 +1274,11 @@ int run_decode(bv2_handle* h, hipStream_t s, const bv2_decode_in& in, const bv2_
   phase_b_gemv(c, P, in.g, B);
   flow_core(c, P, z, ymask, in.g, B, Ty);
   const int L = (in.max_len > 0 && in.max_len < Ty) ? in.max_len : Ty;
-  const int64_t* lens = in.exact_lengths ? in.y_lengths : nullptr;
+  const int64_t* lens = in.exact_lengths == 1 ? in.y_lengths : nullptr;
+  if (in.exact_lengths == 2) {                       // Ty is a bucket >= max(y_lengths): cap the Generator at the longest utterance (bv2.h)
+    lens = in.y_lengths;                             // B == 1: the cap is the utterance's own length
+    if (B > 1) { c.chk(launch_len_cap(s, in.y_lengths, P.len_cap, B), "len_cap"); lens = P.len_cap; }
+  }
   if (h->gen_dtype == BV2_BF16) gen_core_bf16(c, P, z, Ty, ymask, B, L, out.o, lens);
   else gen_core(c, P, z, Ty, ymask, B, L, out.o, lens);
   return c.rc;

@@ -520,6 +520,7 @@ struct FrontArgs {
 int launch_front(hipStream_t stream, const FrontArgs& a);
 
 int launch_gather_rows(hipStream_t stream, const float* table, const int64_t* idx, float* out, int B, int C, int nrows);
+int launch_len_cap(hipStream_t stream, const int64_t* lengths, int64_t* cap, int B);     // cap[b] = max_b lengths[b]
 int launch_seq_mask(hipStream_t stream, const int64_t* lengths, float* mask, int B, int T);
 
 // text-encoder front: out[b][c][t] = (emb[x][c] + tone_emb[tone][c] + lang_emb[lang][c] + bsum[b][c][t]) * scale * mask

@@ -271,6 +271,23 @@ __global__ void seq_mask_kernel(const int64_t* lengths, float* mask, int T) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < T) mask[(int64_t)b * T + t] = (!lengths || (int64_t)t < lengths[b]) ? 1.f : 0.f;      // lengths == null: all valid
 }
+// cap[b] = max over the batch of lengths[] for every b (bv2_decode_in.exact_lengths == 2: the Generator of a run padded to a T_y bucket treats
+// every position past the LONGEST utterance as zero padding, i.e. sees exactly the tensor the reference's dec sees, commons.py:119-123 / models.py:1073)
+__global__ void len_cap_kernel(const int64_t* lengths, int64_t* cap, int B) {
+  long long mx = 0;
+  for (int b = threadIdx.x; b < B; b += 64) mx = lengths[b] > mx ? lengths[b] : mx;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const long long v = __shfl_xor(mx, o);
+    mx = v > mx ? v : mx;
+  }
+  for (int b = threadIdx.x; b < B; b += 64) cap[b] = mx;
+}
+int launch_len_cap(hipStream_t stream, const int64_t* lengths, int64_t* cap, int B) {
+  hipLaunchKernelGGL(len_cap_kernel, dim3(1), dim3(64), 0, stream, lengths, cap, B);
+  return BV2_CHECK_LAUNCH();
+}
+
 int launch_seq_mask(hipStream_t stream, const int64_t* lengths, float* mask, int B, int T) {
   hipLaunchKernelGGL(seq_mask_kernel, dim3((T + 255) / 256, B), dim3(256), 0, stream, lengths, mask, T);
   return BV2_CHECK_LAUNCH();

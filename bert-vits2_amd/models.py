@@ -95,6 +95,8 @@ class SynthesizerTrn(nn.Module):
         self.flow_dtype = torch.float32
         self._graphs_on = False
         self._graphs_static = False
+        self._ty_bucket = 32
+        self.graph_stats = dict(captures=0, replays=0)
         self._graphs: Dict[tuple, dict] = {}
         self._cap_stream = None
         self._options: Dict[str, int] = {}
@@ -236,10 +238,18 @@ class SynthesizerTrn(nn.Module):
         return self._ws
 
     # ------------------------------------------------------------------ hipGraph replay of the two phases
-    def enable_graphs(self, on: bool = True, static_io: bool = False) -> None:
+    def enable_graphs(self, on: bool = True, static_io: bool = False, ty_bucket: int = 32) -> None:
         """Record each phase once per shape as a hipGraph (``bv2_graph_capture_*``) and replay it on later calls: one
         ``hipGraphLaunch`` per phase instead of ~230 kernel launches.  Default: inputs are copied into buffers the graph owns and
         outputs are returned as fresh tensors, so the call behaves exactly like the eager one.
+
+        ``ty_bucket`` (frames): ``T_y = max(y_lengths)`` is data-dependent (reference commons.py:119-123, models.py:1058), so with real
+        durations nearly every batch has a T_y of its own.  Phase B is therefore recorded once per BUCKET — T_y rounded up to a multiple of
+        ``ty_bucket`` — and replayed for every T_y inside it: the flow masks frames past ``y_lengths`` as in any ragged batch, the Generator
+        treats everything past the batch's longest utterance as zero padding (``bv2_decode_in.exact_lengths`` 2, or 1 with
+        ``exact_lengths=True``), and the returned tensors are views cut back to the true T_y.  The results are those of the eager call up to
+        fp32 summation order (a bucket may pick another split-K factor); ``ty_bucket=1`` keys graphs on the exact T_y (bit-identical to
+        eager, one capture per distinct T_y).  ``graph_stats`` counts captures and replays.
 
         ``static_io=True`` (serving loops): no staging copies — a graph is recorded reading the caller's input tensors IN PLACE
         (when a tensor with another address shows up the shape's graph is re-recorded ONCE with input buffers of its own and the
@@ -247,6 +257,8 @@ class SynthesizerTrn(nn.Module):
         the CPU draw of models.py:248-251 is uploaded into the graph's buffer, the device draw of :1071 is made in place."""
         self._graphs_on = bool(on)
         self._graphs_static = bool(on and static_io)
+        self._ty_bucket = max(1, int(ty_bucket))
+        self.graph_stats = dict(captures=0, replays=0)
         self._drop_graphs()
 
     def _drop_graphs(self) -> None:
@@ -278,12 +290,16 @@ class SynthesizerTrn(nn.Module):
         else:
             own = not self._graphs_static
         if ent is None:
-            if len(self._graphs) >= 16:                   # bounded cache: drop the oldest shape
+            if len(self._graphs) >= 16:                   # bounded cache: drop the least recently used shape
                 old = next(iter(self._graphs))
                 self._lib.bv2_graph_destroy(self._graphs.pop(old)["graph"])
             ent = build(own)
             ent["own_inputs"], ent["ptrs"] = own, ptrs
             self._graphs[key] = ent
+            self.graph_stats["captures"] += 1
+        else:
+            self._graphs[key] = self._graphs.pop(key)     # most recently used last
+            self.graph_stats["replays"] += 1
         return ent
 
     def set_tap(self, name: Optional[str], tensor: Optional[torch.Tensor] = None) -> None:
@@ -387,8 +403,10 @@ class SynthesizerTrn(nn.Module):
 
     @torch.no_grad()
     def decode(self, enc: Dict[str, torch.Tensor], noise_z: torch.Tensor, Ty: int, noise_scale=0.667, max_len=None,
-               want_attn: bool = True, exact_lengths: bool = False) -> Dict[str, torch.Tensor]:
-        """Phase B = reference models.py:1058-1073.  ``noise_z`` [B,inter,>=Ty] replaces randn_like at :1071."""
+               want_attn: bool = True, exact_lengths: bool = False, ty_bucket: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Phase B = reference models.py:1058-1073.  ``noise_z`` [B,inter,>=Ty] replaces randn_like at :1071.
+        ``ty_bucket``: run at T_y rounded up to a multiple of it and cut the outputs back (default: the ``enable_graphs`` bucket when a
+        graph is replayed, none on the eager path; tests pass it to the eager path to compare like with like)."""
         if self._blob is None:
             self.repack()
         dev = self.device
@@ -401,6 +419,28 @@ class SynthesizerTrn(nn.Module):
         L_dec = Ty if (max_len is None or max_len <= 0 or max_len >= Ty) else int(max_len)
         S = L_dec * hp.total_upsample
         okeys = ("o", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")
+        # ---- T_y bucket: everything below runs at Ty (the bucket); Ty_true / S_true cut the results back
+        if ty_bucket is None:
+            ty_bucket = self._ty_bucket if (self._graphs_on and not self._taps) else 1
+        Ty_true, S_true, L_true = Ty, S, L_dec
+        mode = int(bool(exact_lengths))
+        if ty_bucket > 1:
+            Ty = (Ty + ty_bucket - 1) // ty_bucket * ty_bucket
+            if L_dec == Ty_true:                        # no max_len cut: the Generator runs over the bucket, capped on the device
+                L_dec = Ty
+                mode = 1 if exact_lengths else 2
+            S = L_dec * hp.total_upsample
+        bucketed = Ty != Ty_true
+
+        def cut(out):
+            if not bucketed:
+                return out
+            r = dict(out)
+            r["o"] = out["o"][:, :, :S_true]
+            for k in ("z", "z_p", "m_p", "logs_p", "y_mask"):
+                r[k] = None if out[k] is None else out[k][:, :, :Ty_true]
+            r["attn"] = None if out["attn"] is None else out["attn"][:, :, :Ty_true]
+            return r
 
         def mk_out():
             # ONE allocation carved into the six secondary outputs (+ one for the waveform): this runs between the reference's host sync and the first launch of
@@ -427,11 +467,11 @@ class SynthesizerTrn(nn.Module):
             def build(own_inputs):
                 sin = {k: (torch.empty_like(enc[k]) if own_inputs else enc[k]) for k in ikeys}
                 # the reference's strides for the prior noise (draw_noise_z): an in-place normal_() on it IS randn_like(m_p)
-                sin["noise_z"] = torch.empty(B, Ty, Ci, dtype=torch.float32, device=dev).transpose(1, 2)
+                sin["noise_z"] = torch.zeros(B, Ty, Ci, dtype=torch.float32, device=dev).transpose(1, 2)   # zeros: a bucket's tail is never drawn
                 sout = mk_out()
                 din = L.DecodeIn(B, T, int(Ty), int(L_dec), *[_ptr(sin[k]) for k in ikeys], _ptr(sin["noise_z"]),
                                  sin["noise_z"].stride(0), sin["noise_z"].stride(1), sin["noise_z"].stride(2),
-                                 float(noise_scale), int(exact_lengths))
+                                 float(noise_scale), mode)
                 dout = L.DecodeOut(*[_ptr(sout[k]) for k in okeys])
                 with torch.cuda.device(dev):
                     g = self._capture(self._lib.bv2_graph_capture_decode, C.byref(din), C.byref(dout),
@@ -439,46 +479,52 @@ class SynthesizerTrn(nn.Module):
                 return dict(graph=g, sin=sin, sout=sout)
 
             ptrs = tuple(enc[k].data_ptr() for k in ikeys) if static else ()
-            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale), bool(exact_lengths)),
-                                    build, ptrs)
+            ent = self._graph_entry(("B", B, T, int(Ty), int(L_dec), bool(want_attn), float(noise_scale), mode), build, ptrs)
             if ent["own_inputs"]:
                 for k in ikeys:
                     ent["sin"][k].copy_(enc[k])
-            if draw_z:
+            if draw_z and not bucketed:
                 ent["sin"]["noise_z"].normal_()
+            elif draw_z:                                # the reference draws exactly [B, C, T_y] in its memory order (draw_noise_z): keep the RNG contract
+                ent["sin"]["noise_z"][:, :, :Ty_true].copy_(draw_noise_z(B, Ci, Ty_true, dev))
             else:
-                ent["sin"]["noise_z"].copy_(noise_z[:, :, :Ty])
+                ent["sin"]["noise_z"][:, :, :Ty_true].copy_(noise_z[:, :, :Ty_true])
             with torch.cuda.device(dev):
                 if self._lib.bv2_graph_launch(ent["graph"], C.c_void_p(torch.cuda.current_stream().cuda_stream)):
                     raise RuntimeError("bv2_graph_launch (decode) failed")
             if static:
-                return dict(ent["sout"])
-            return {k: (None if v is None else v.clone()) for k, v in ent["sout"].items()}
+                return cut(dict(ent["sout"]))
+            return {k: (None if v is None else v.clone()) for k, v in cut(ent["sout"]).items()}
         if draw_z:
-            noise_z = draw_noise_z(B, Ci, Ty, dev)
+            noise_z = draw_noise_z(B, Ci, Ty_true, dev)
+        if bucketed:                                    # eager run at a bucket (tests): zero tail, reference-strided like the graph's buffer
+            nzb = torch.zeros(B, Ty, Ci, dtype=torch.float32, device=dev).transpose(1, 2)
+            nzb[:, :, :Ty_true].copy_(noise_z[:, :, :Ty_true])
+            noise_z = nzb
         out = mk_out()
         din = L.DecodeIn(B, T, int(Ty), int(L_dec), _ptr(enc["m_p"]), _ptr(enc["logs_p"]), _ptr(enc["x_mask"]),
                          _ptr(enc["w_ceil"]), _ptr(enc["y_lengths"]), _ptr(enc["g"]), _ptr(noise_z),
-                         noise_z.stride(0), noise_z.stride(1), noise_z.stride(2), float(noise_scale), int(exact_lengths))
+                         noise_z.stride(0), noise_z.stride(1), noise_z.stride(2), float(noise_scale), mode)
         dout = L.DecodeOut(*[_ptr(out[k]) for k in okeys])
         ws = self._workspace(B, T, Ty)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             self._check(self._lib.bv2_decode(self._handle, stream, C.byref(din), C.byref(dout), C.c_void_p(ws.data_ptr()),
                                              ws.numel()), "bv2_decode")
-        return out
+        return cut(out)
 
     # ------------------------------------------------------------------ the reference entry point
     @torch.no_grad()
     def infer(self, x, x_lengths, sid, tone, language, bert, ja_bert, en_bert, noise_scale=0.667, length_scale=1,
               noise_scale_w=0.8, max_len=None, sdp_ratio=0, y=None, *, noise_w=None, noise_z=None, w_ceil=None,
-              want_attn=True, exact_lengths=False, bert_index=None):
+              want_attn=True, exact_lengths=False, bert_index=None, ty_bucket=None):
         """reference models.py:1026-1074.  Keyword-only extras (not in the reference): ``noise_w`` [B,2,T] and
         ``noise_z`` [B,inter,>=T_y] inject the two N(0,1) draws (parity tests; the reference's ONNX export externalises
         them the same way), ``w_ceil`` substitutes the durations, ``want_attn=False`` skips materialising the path,
         ``exact_lengths=True`` makes every utterance of a ragged batch come out exactly as if it had been run alone (the
         reference's unmasked decoder lets the padding bleed into an utterance's last ~40 ms; bv2.h ``exact_lengths``),
-        ``bert_index`` hands BERT features over at word level (see ``encode_durations``)."""
+        ``bert_index`` hands BERT features over at word level (see ``encode_durations``), ``ty_bucket`` runs phase B at T_y rounded up to
+        a multiple of it (default: ``enable_graphs``' bucket when graphs are on, exact T_y otherwise; see ``enable_graphs``)."""
         if self.device.type != "cuda":
             raise RuntimeError("bert_vits2_amd.SynthesizerTrn.infer needs a GPU: no CPU fallback exists by design")
         dev = self.device
@@ -497,7 +543,7 @@ class SynthesizerTrn(nn.Module):
         if noise_z is not None:                        # None: decode() draws it (in place in the graph's buffer when replaying)
             noise_z = noise_z.to(dev, torch.float32)
         dec = self.decode(enc, noise_z, Ty, noise_scale=noise_scale, max_len=max_len, want_attn=want_attn,
-                          exact_lengths=exact_lengths)
+                          exact_lengths=exact_lengths, ty_bucket=ty_bucket)
         self.last_encode = enc
         return dec["o"], dec["attn"], dec["y_mask"], (dec["z"], dec["z_p"], dec["m_p"], dec["logs_p"])
 

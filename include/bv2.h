@@ -171,7 +171,12 @@ typedef struct bv2_decode_in {
                                 1: every Generator conv treats positions >= y_lengths[b]*(samples per frame at its stage) as
                                 zero padding, i.e. each utterance of a ragged batch gets exactly the audio it gets when run
                                 alone (what the reference produces, since it only ever infers at batch 1); tiles past an
-                                utterance's end are skipped. */
+                                utterance's end are skipped.
+                                2: Ty is a BUCKET >= max(y_lengths) (a hipGraph captured once per bucket instead of once per exact
+                                T_y — T_y = max(y_lengths) is data-dependent, commons.py:119-123): every Generator conv treats positions
+                                >= max_b(y_lengths) * (samples per frame at its stage) as zero padding for EVERY utterance, so the first
+                                max(y_lengths) frames of every output are what mode 0 produces at Ty = max(y_lengths); the flow needs
+                                nothing (frames past y_lengths[b] are masked in both).  Outputs past that frame are zeros / padding. */
 } bv2_decode_in;
 
 typedef struct bv2_decode_out {   /* all DEVICE, caller-allocated; any pointer except o may be NULL */

@@ -59,7 +59,7 @@ def test_word_level_features_through_the_gather_match_the_repeated_matrix():
                   noise_w=nw, noise_z=nz, w_ceil_override=enc_b["w_ceil"].cpu()[:, None], **kw)
     assert rms(b_[0].cpu() - ref["o"]) <= 5e-5
     # graph replay carries the index too
-    m.enable_graphs(True)
+    m.enable_graphs(True, ty_bucket=1)
     c = m.infer(*common, dev(word[1]), dev(word[2]), noise_w=nw, noise_z=nz.cuda(), bert_index=(None, index[1], index[2]), **kw)
     assert torch.equal(c[0], b_[0])
     with pytest.raises(ValueError):

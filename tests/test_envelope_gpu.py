@@ -98,7 +98,7 @@ def test_envelope_graph_replay_is_bit_identical_to_eager(name, reduced):
             m.set_generator_dtype(torch.bfloat16)
             m.set_flow_dtype(torch.float16)
         eager = _run(m, batch, nw, nz, kw)
-        m.enable_graphs(True)
+        m.enable_graphs(True, ty_bucket=1)
         first = _run(m, batch, nw, nz, kw)
         again = _run(m, batch, nw, nz, kw)
         assert len(m._graphs) == 2

@@ -76,7 +76,7 @@ def test_pair_fused_exact_lengths_and_graph_replay():
     vm = valid_wave_mask(outs[1][1], hp.total_upsample, outs[1][0].shape[2]).expand_as(outs[1][0])
     assert torch.equal(outs[1][0][vm], outs[0][0][vm])
     m.set_option("fused_respair", 1)
-    m.enable_graphs(True)
+    m.enable_graphs(True, ty_bucket=1)
     try:
         for _ in range(2):
             og = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), exact_lengths=True, **kw)[0].cpu()
