@@ -271,6 +271,64 @@ def parity_unpinned_block(hp, dev, T=128):
     return res
 
 
+def run_config3_unpinned(hp, dev, n_cold=20, n_steady=40):
+    """BASELINE config 3 with REAL durations: the same shape (B = 32 x 128 symbols, bf16 Generator + fp16 flow, hipGraph replay) on an UN-pinned
+    checkpoint at sdp_ratio 0.5, every step a batch nobody has seen — so T_y = max(y_lengths) moves from step to step and the captured decode
+    lives or dies by its T_y buckets (models.enable_graphs ty_bucket, 32 frames).  `cold`: the first n_cold distinct batches, captures inside
+    the clock.  `steady`: n_steady further distinct batches.  `eager`: those same n_steady batches with graphs off.  value = VALID audio seconds
+    (sum of y_lengths) per second; padded_value counts B x T_y (what the pinned config 3 figure counts, where every utterance is T_y long)."""
+    sd = synth.synthetic_state_dict(hp, seed=0)
+    m = models.from_hparams(hp)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    m.set_generator_dtype(torch.bfloat16)
+    m.set_flow_dtype(torch.float16)
+    B, T = CONFIGS[3]["batch"], CONFIGS[3]["symbols"]
+    kw = dict(KW, sdp_ratio=0.5)
+    n = n_cold + n_steady
+    # one speaker, as config 3 itself: the synthetic speaker table is N(0,1), which moves a SPEAKER's mean duration by 2x and more — nothing a
+    # trained table does; within one speaker the per-utterance spread (min / mean / max of y_lengths about 0.88 / 1 / 1.2) is what a
+    # length-bucketed serving batch looks like
+    batches = [{k: v.to(dev) for k, v in synth.synthetic_batch([T] * B, first_index=5000 + i * B).items()} for i in range(n)]
+    call = lambda b: m.infer(b["x"], b["x_lengths"], b["sid"], b["tone"], b["language"], b["bert"], b["ja_bert"], b["en_bert"], want_attn=False, **kw)
+
+    def timed(bs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames, padded, tys = 0, 0, []
+        outs = [call(b)[2] for b in bs]                     # y_mask views: lengths summed after the clock stops
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for ym in outs:
+            frames += int(ym.sum().item())
+            padded += B * ym.shape[2]
+            tys.append(int(ym.shape[2]))
+        return dt, frames, padded, tys
+
+    m.enable_graphs(False)
+    call(batches[0])                                        # workspace + allocator warm-up, eager
+    m.enable_graphs(True, static_io=True)
+    dt_c, fr_c, _, tys_c = timed(batches[:n_cold])
+    st_c = dict(m.graph_stats)
+    dt_s, fr_s, pad_s, tys_s = timed(batches[n_cold:])
+    st_s = {k: m.graph_stats[k] - st_c[k] for k in st_c}
+    m.enable_graphs(False)
+    dt_e, fr_e, _, _ = timed(batches[n_cold:])
+    sec = lambda fr: fr * hp.total_upsample / hp.sampling_rate
+    hit = lambda st: round(st["replays"] / max(1, st["replays"] + st["captures"]), 4)
+    res = dict(workload=f"config 3's shape (B={B} x {T} symbols, bf16 Generator, fp16 flow, hipGraph + {m._ty_bucket}-frame T_y buckets) on an UN-pinned "
+                        f"checkpoint, sdp_ratio 0.5, every step a new batch", value=round(sec(fr_s) / dt_s, 2), unit="audio-seconds/sec",
+               ms_per_step=round(dt_s / n_steady * 1e3, 4), padded_value=round(sec(pad_s) / dt_s, 2), steps=n_steady,
+               distinct_ty=len(set(tys_s)), ty_min=min(tys_s), ty_max=max(tys_s), distinct_buckets=len({(t + 31) // 32 for t in tys_s}),
+               graph_hit_rate=hit(st_s), captures=st_s["captures"],
+               cold=dict(steps=n_cold, value=round(sec(fr_c) / dt_c, 2), ms_per_step=round(dt_c / n_cold * 1e3, 4), graph_hit_rate=hit(st_c),
+                         captures=st_c["captures"], distinct_ty=len(set(tys_c))),
+               eager=dict(value=round(sec(fr_e) / dt_e, 2), ms_per_step=round(dt_e / n_steady * 1e3, 4)),
+               replay_over_eager=round(dt_e / dt_s, 4))
+    del m
+    return res
+
+
 def file_digest(name):
     with open(os.path.join(ROOT, "bert-vits2_amd", "csrc", "kernels", name), "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
@@ -391,6 +449,44 @@ def upsampling_block(ups, psteps, config):
                 launches=rows)
 
 
+def encoder_gemms_block(rows, psteps, config):
+    """north_star: "MFMA utilisation on the encoder GEMMs against gfx950 peak".  `rows`: a per-site HIP-event pass (profile mode 3).  The encoder
+    GEMMs are the launch sites `enc.qkv` / `enc.o` / `enc.ffn1` / `enc.ffn2` of attentions.Encoder (reference attentions.py:263-266, 438-446) — the
+    text encoder's six layers and every transformer-flow coupling's stack — grouped by kernel family: achieved = the convs' own FLOPs / HIP-event
+    time, against the dense matrix peak of the family's arithmetic (fp32 MFMA 157.3 TF, fp16 MFMA 2 500 TF); `pmc_mfma_util` = the SQ busy-cycle
+    figure of the same family from the newest committed PMC pass of this config (profiles/*pmc_c{2,3}.json), when there is one."""
+    fam = {}
+    for r in rows:
+        site, _, rest = r["name"].partition("|")
+        if not site.startswith("enc.") or not r["launches"]:
+            continue
+        name = rest.split(" n")[0]
+        f = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        f["launches"] += r["launches"]; f["ms"] += r["total_ms"]; f["flops"] += r["flops"]
+    if not fam:
+        return None
+    pmc, pmc_file = {}, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_c{2 if config == 2 else 3}.json")), reverse=True):
+        try:
+            pmc, pmc_file = json.load(open(path)).get("kernels", {}), os.path.basename(path)
+            break
+        except (OSError, ValueError):
+            continue
+    out = []
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        peak = PEAK_BF16_MFMA_TFLOPS if "f16" in name else PEAK_FP32_MFMA_TFLOPS
+        tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        key = "conv1d_splitk<32x32>" if name.startswith("conv1d_splitk") else name.split("<")[0] if name.startswith("conv_f16") else name
+        pk = pmc.get(name) or pmc.get(key) or next((v for k, v in pmc.items() if k.startswith(key)), None)
+        out.append(dict(kernel=name, launches_per_step=round(f["launches"] / psteps, 1), us_per_launch=round(f["ms"] * 1e3 / f["launches"], 2),
+                        ms_per_step=round(f["ms"] / psteps, 4), tflops=round(tf, 2), peak=peak, frac=round(tf / peak, 4),
+                        pmc_mfma_util=None if not pk else pk.get("mfma_util")))
+    tot_ms, tot_fl = sum(f["ms"] for f in fam.values()), sum(f["flops"] for f in fam.values())
+    return dict(sites="enc.qkv / enc.o / enc.ffn1 / enc.ffn2 (text encoder + transformer-flow stacks)", ms_per_step=round(tot_ms / psteps, 4),
+                tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), families=out, pmc_file=pmc_file,
+                timing="HIP events around every launch of these sites in a separate eager pass after the timed region")
+
+
 def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_profile=False, solo=False, collective=False,
                repeats=1, contract=True):
     """Time `steps` steps of BASELINE config `num` on this rank; returns the result dict (rank-local times; the caller reduces).
@@ -500,6 +596,17 @@ def run_config(num, model, hp, dev, rank, world, steps, warmup, overrides, full_
     except Exception as e:
         model.profile(0)
         res["upsampling_roofline"] = dict(error=repr(e)[:200])
+    try:
+        model.profile(3)               # one row per launch site and shape
+        esteps = max(2, min(psteps, 10))
+        for _ in range(esteps):
+            call()
+        torch.cuda.synchronize()
+        res["encoder_gemms"] = encoder_gemms_block(model.profile_report(), esteps, num)
+        model.profile(0)
+    except Exception as e:
+        model.profile(0)
+        res["encoder_gemms"] = dict(error=repr(e)[:200])
     if full_profile:
         model.profile(3)               # one row per launch site and shape
         for _ in range(3):
@@ -789,6 +896,8 @@ def summary(res, hp, world, dt=None, audio=None):
                                      note="inputs copied from pinned host memory and the audio copied back to pinned host memory every step")
     if res.get("roofline") is not None:
         out["roofline"] = res["roofline"]
+    if res.get("encoder_gemms") is not None:
+        out["encoder_gemms"] = res["encoder_gemms"]
     if res.get("upsampling_roofline") is not None:
         if res["config"] == 5 and "error" not in res["upsampling_roofline"]:
             # BASELINE config 5 names its roofline: HBM bandwidth on the Generator upsampling.  The dominant-kernel (MFMA) block stays beside it.
@@ -818,7 +927,8 @@ def _leg(v):
         return v
     if "error" in v:
         return dict(error=str(v["error"])[:80])
-    out = _pick(v, ("value", "ms_per_step", "ms_per_request", "ms_per_sentence", "sentences_per_sec", "launches"))
+    out = _pick(v, ("value", "ms_per_step", "ms_per_request", "ms_per_sentence", "sentences_per_sec", "launches", "graph_hit_rate", "distinct_ty",
+                    "replay_over_eager", "padded_value"))
     rp = v.get("repeats")
     if isinstance(rp, dict):
         out["min_max"] = [rp.get("min"), rp.get("max")]
@@ -843,7 +953,7 @@ def headline(line, details_path=None):
                                   "vs_baseline", "dtype", "data")}
     cfg = line.get("config") or {}
     h["config"] = _pick(cfg, ("workload", "utterances_per_gpu", "symbols", "frames", "parallelism", "rtf", "x_realtime_per_gpu", "hipgraph",
-                              "weight_broadcast_ms"))
+                              "weight_broadcast_ms", "hip_force_dev_kernarg"))
     if isinstance(h["config"].get("workload"), str):
         h["config"]["workload"] = h["config"]["workload"][:260]
     if isinstance(cfg.get("pcie_inclusive"), dict):
@@ -889,7 +999,16 @@ def headline(line, details_path=None):
     if isinstance(u, dict) and "error" not in u:
         h["upsampling_roofline"] = _pick(u, ("bound", "achieved", "peak", "unit", "frac", "ms_per_step"))
         h["upsampling_roofline"]["traffic"] = u.get("traffic")
+    def _eg(e):
+        if not isinstance(e, dict) or "families" not in e:
+            return None
+        return dict(ms_per_step=e.get("ms_per_step"), tflops=e.get("tflops"),
+                    families=[_pick(f, ("kernel", "us_per_launch", "tflops", "peak", "frac", "pmc_mfma_util")) for f in e["families"][:3]])
     sec = line.get("secondary")
+    eg = {k: v for k, v in (("config2", _eg(line.get("encoder_gemms"))),
+                            ("config3", _eg((sec or {}).get("config3", {}).get("encoder_gemms") if isinstance(sec, dict) else None))) if v}
+    if eg:
+        h["encoder_gemms"] = eg
     if isinstance(sec, dict):
         h["secondary"] = {k: _leg(v) for k, v in sec.items()}
         ctl = sec.get("config2_fp32_mfma")
@@ -912,7 +1031,7 @@ def headline(line, details_path=None):
         h["details"] = details_path
     txt = json.dumps(h, allow_nan=False, separators=(",", ":"))
     # belt and braces: shed optional blocks rather than ever print a line the driver cannot take
-    for drop in ("upsampling_roofline", "secondary", "per_rank", "parity"):
+    for drop in ("upsampling_roofline", "secondary", "encoder_gemms", "per_rank", "parity"):
         if len(txt) < HEADLINE_MAX_BYTES:
             break
         if drop in h:
@@ -1095,17 +1214,23 @@ def rank_main(args):
     if world == 1 and not use_dist and rank == 0 and not args.no_secondary and args.config is None and not args.residual_flow:
         for num in (3, 4, 5):
             try:
-                r = run_config(num, model, hp, dev, 0, 1, max(10, min(args.steps, 10)), 3, {}, repeats=3, contract=False)
+                r = run_config(num, model, hp, dev, 0, 1, max(3, min(args.steps, 10)), 3, {}, repeats=3, contract=False)
                 secondary[f"config{num}"] = summary(r, hp, 1)
                 log(f"secondary config {num}: {secondary[f'config{num}']['value']} audio-s/s ({secondary[f'config{num}']['ms_per_step']} ms/step)")
             except Exception as e:          # a secondary workload must never take the primary line down
                 secondary[f"config{num}"] = dict(error=repr(e)[:300])
 
+        try:
+            secondary["config3_unpinned"] = run_config3_unpinned(hp, dev, *((20, 40) if args.steps >= 10 else (4, 6)))
+            log(f"secondary config 3, un-pinned durations: {secondary['config3_unpinned']}")
+        except Exception as e:
+            secondary["config3_unpinned"] = dict(error=repr(e)[:300])
+
         # config 2 once more with the wide Generator convs on the fp32 matrix core (v_mfma_f32_32x32x2_f32, conv_mfma.hip) instead
         # of the split-bf16 form (conv_x6.hip): the same fp32 numerics at the fp32 MFMA rate — the kernel of rounds 1-2
         try:
             model.set_option("conv_x6", 0)
-            r = run_config(2, model, hp, dev, 0, 1, max(10, min(args.steps, 20)), 3, {}, repeats=3, contract=False)
+            r = run_config(2, model, hp, dev, 0, 1, max(3, min(args.steps, 20)), 3, {}, repeats=3, contract=False)
             secondary["config2_fp32_mfma"] = summary(r, hp, 1)
             rf = secondary["config2_fp32_mfma"].get("roofline")
             if isinstance(rf, dict) and rf.get("traffic") is not None:
@@ -1127,7 +1252,7 @@ def rank_main(args):
             m_wn.load_state_dict(synth.synthetic_state_dict(hp_wn, seed=0, pin_durations=2.5), strict=False)
             sharding.distribute_weights(m_wn, dev, src=0)
             for num, key, ov in ((2, "config2_residual_flow", dict(flow="f32")), (3, "config3_residual_flow", dict(flow=WN_FLOW_B32))):
-                r = run_config(num, m_wn, hp_wn, dev, 0, 1, max(10, min(args.steps, 20 if num == 2 else 10)), 3, ov, repeats=3, contract=False)
+                r = run_config(num, m_wn, hp_wn, dev, 0, 1, max(3, min(args.steps, 20 if num == 2 else 10)), 3, ov, repeats=3, contract=False)
                 secondary[key] = summary(r, hp_wn, 1)
                 log(f"secondary {key}: {secondary[key]['value']} audio-s/s ({secondary[key]['ms_per_step']} ms/step)")
             del m_wn
@@ -1186,6 +1311,7 @@ def rank_main(args):
             config=dict(workload=s["workload"], utterances_per_gpu=res["B"], symbols=res["T"], frames=res["Ty"],
                         parallelism=f"utterance-sharded x{world}", rtf=s["rtf"], x_realtime_per_gpu=round(s["value"] / world, 2),
                         hipgraph=res["graph"], weight_broadcast_ms=round(t_bcast * 1e3, 3),
+                        hip_force_dev_kernarg=os.environ.get("HIP_FORCE_DEV_KERNARG"),
                         pcie_inclusive=s.get("pcie_inclusive"),
                         note=("N=1 measures BASELINE config 2 (the metric's config); N>1 measures config 4 per GPU — the single-GPU figure of "
                               "that same workload is n1_same_workload of the N>1 line itself (and secondary.config4 of the N=1 line)"
@@ -1195,6 +1321,8 @@ def rank_main(args):
             line["repeats"] = s["repeats"]
         if s.get("upsampling_roofline") is not None:
             line["upsampling_roofline"] = s["upsampling_roofline"]
+        if s.get("encoder_gemms") is not None:
+            line["encoder_gemms"] = s["encoder_gemms"]
         if per_rank is not None:
             line["ranks_seen"] = len([r for r in per_rank if r is not None])
             line["launcher"] = ("self (torch.multiprocessing.spawn)" if os.environ.get("BV2_BENCH_SELF_LAUNCHED") else
