@@ -53,8 +53,8 @@ CONFIGS = {
 }
 WN_FLOW_B32 = "f16"               # flow arithmetic of secondary.config3_residual_flow: the WN convolutions on the fp16 matrix core
 KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
-KERNEL_SOURCES = {"conv1d_splitk_x6": "splitk_x6.hip", "conv1d_x6": "conv_x6.hip", "respair_x6": "respair_x6.hip", "conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
-                  "conv_cl_bf16": "gen_bf16.hip", "respair_cl_bf16": "respair_cl_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "resblock_c16_bf16": "resblock_c16_bf16.hip", "resblock_sw_bf16": "resblock_sw_bf16.hip", "conv_f16": "enc_f16.hip",
+KERNEL_SOURCES = {"conv1d_x6": "conv_x6.hip", "respair_x6": "respair_x6.hip", "conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
+                  "conv_cl_bf16": "gen_bf16.hip", "respair_cl_bf16": "respair_cl_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "resblock_c16_bf16": "resblock_c16_bf16.hip", "conv_f16": "enc_f16.hip",
                   "attention": "attention.hip"}
 
 

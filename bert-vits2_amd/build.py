@@ -22,7 +22,7 @@ STAMP = os.path.join(CSRC, ".libbv2.stamp")
 
 SOURCES = [
     "bv2_api.cpp", "bv2_model.cpp", "bv2_exec.cpp", "bv2_bert.cpp",
-    "kernels/conv_mfma.hip", "kernels/conv_x6.hip", "kernels/splitk_x6.hip", "kernels/respair_x6.hip", "kernels/resblock_fused.hip", "kernels/gen_bf16.hip", "kernels/resblock_cl_bf16.hip", "kernels/resblock_c16_bf16.hip", "kernels/resblock_sw_bf16.hip", "kernels/respair_cl_bf16.hip", "kernels/enc_f16.hip", "kernels/layernorm.hip", "kernels/attention.hip", "kernels/misc.hip", "kernels/dds_fused.hip", "kernels/flow_boundary.hip", "kernels/bert.hip", "kernels/deberta_attn.hip",
+    "kernels/conv_mfma.hip", "kernels/conv_x6.hip", "kernels/respair_x6.hip", "kernels/resblock_fused.hip", "kernels/gen_bf16.hip", "kernels/resblock_cl_bf16.hip", "kernels/resblock_c16_bf16.hip", "kernels/respair_cl_bf16.hip", "kernels/enc_f16.hip", "kernels/layernorm.hip", "kernels/attention.hip", "kernels/misc.hip", "kernels/dds_fused.hip", "kernels/flow_boundary.hip", "kernels/bert.hip", "kernels/deberta_attn.hip",
 ]
 EXPORTS = "libbv2.map"     # linker version script: export bv2_* only
 HEADERS = [EXPORTS, "bv2_internal.h", "bv2_kernels.h", "kernels/spline.h", "kernels/cl_bf16.h", os.path.join(ROOT, "include", "bv2.h"),

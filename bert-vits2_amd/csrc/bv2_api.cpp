@@ -413,7 +413,6 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "respair_form") h->respair_form = value;
   else if (k == "respair_c32") h->no_respair_c32 = value == 0;
   else if (k == "resblock_c16") h->no_resblock_c16 = value == 0;
-  else if (k == "resblock_sw") h->resblock_sw = value & 3;
   else if (k == "f16_fused_ln") h->no_f16_fused_ln = value == 0;
   else if (k == "f16_ksplit") h->no_f16_ksplit = value == 0;
   else if (k == "conv_post_rows") h->no_conv_post_rows = value == 0;
@@ -541,7 +540,7 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
           pk[(size_t)conv_w_index(j, ci, co, cin_pad, k)] = w_host[((size_t)co * cin + ci) * k + j];
     const size_t boff = (size_t)k * cin_pad * ld;
     if (w_host && bias_host) for (int co = 0; co < cout; ++co) pk[boff + co] = bias_host[co];
-    const bool x6 = tile >= TILE_X6 && cin % (tile == TILE_SPLITK_X6 ? 16 : 32) == 0;
+    const bool x6 = tile >= TILE_X6 && cin % 32 == 0;
     if (w_host && x6) {
       uint16_t* wx = reinterpret_cast<uint16_t*>(pk.data() + t_x6_off(cin, cout, k));
       for (int j = 0; j < k; ++j)
@@ -609,8 +608,6 @@ static inline uint16_t t_f2bf(float f) {
 
 int64_t bv2_test_resblock_cl_pack_bytes(int C, int k, int nd) {
   int64_t units = (int64_t)2 * nd * ((C / 16) * k + RBCL_PD) + RBCL_PD;                 // the largest of the stream formats
-  const int64_t sw = (int64_t)2 * nd * k * (C / 16) * (C / 32 > 0 ? C / 32 : 1) + 16;
-  if (sw > units) units = sw;
   return units * 1024 + (int64_t)2 * nd * (C > 32 ? C : 32) * 4 + 256;
 }
 
@@ -618,12 +615,11 @@ int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_
                          int C, int k, const int* dil, int nd, int L, float slope, int variant, const int64_t* lens) {
   try {
     if (nd < 1 || nd > BV2_RBCL_MAX_D) return -2;
-    if (variant == 2 ? !resblock_sw_bf16_supported(C, k, dil, nd)
-                     : (variant == 1 ? !resblock_c16_bf16_supported(C, k, dil, nd) : !resblock_cl_bf16_supported(C, k, dil, nd))) return -2;
-    const int Upad = variant == 2 ? 0 : resblock_cl_bf16_units(C, k), KU = rb16_units(k), G = C / 16;
-    const int64_t wunits = variant == 2 ? (resblock_sw_bf16_w_elems(C, k, nd) + 511) / 512 + 8
-                                        : (variant == 1 ? (int64_t)2 * nd * KU : (int64_t)2 * nd * Upad + RBCL_PD);
-    const int brow = variant == 2 ? C : (variant == 1 ? 16 : 32);
+    if (variant != 0 && variant != 1) return -2;
+    if (variant == 1 ? !resblock_c16_bf16_supported(C, k, dil, nd) : !resblock_cl_bf16_supported(C, k, dil, nd)) return -2;
+    const int Upad = resblock_cl_bf16_units(C, k), KU = rb16_units(k), G = C / 16;
+    const int64_t wunits = variant == 1 ? (int64_t)2 * nd * KU : (int64_t)2 * nd * Upad + RBCL_PD;
+    const int brow = variant == 1 ? 16 : 32;
     std::vector<uint16_t> pk((size_t)wunits * 512, 0);
     std::vector<float> pb((size_t)2 * nd * brow, 0.f);
     for (int d = 0; d < nd; ++d)
@@ -634,9 +630,7 @@ int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_
           for (int ci = 0; ci < C; ++ci)
             for (int j = 0; j < k; ++j) {
               const uint16_t v = t_f2bf(w[((size_t)co * C + ci) * k + j]);
-              if (variant == 2) {
-                pk[(size_t)rbsw_w_index(2 * d + e, j, ci, co, C, k)] = v;
-              } else if (variant == 1) {
+              if (variant == 1) {
                 pk[(size_t)(2 * d + e) * KU * 512 + (size_t)rb16_w_index(j, ci, co)] = v;
               } else {                                  // tap-major units of m-tile 0 (bv2_model.cpp): unit = tap * G + group
                 const int64_t in_unit = cl_w_index(j, ci, co, C, k) % 512;
@@ -656,7 +650,6 @@ int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_
     F.p[0].w = reinterpret_cast<const uint16_t*>(base); F.p[0].bias = reinterpret_cast<const float*>(base + boff);
     F.p[0].k = k;
     for (int d = 0; d < nd; ++d) F.p[0].dil[d] = dil[d];
-    if (variant == 2) return launch_resblock_sw_bf16(static_cast<hipStream_t>(stream), F);
     return variant == 1 ? launch_resblock_c16_bf16(static_cast<hipStream_t>(stream), F)
                         : launch_resblock_cl_bf16(static_cast<hipStream_t>(stream), F);
   } catch (...) { return -100; }

@@ -1084,32 +1084,6 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     // runs its six GEMM / epilogue / barrier phases in lock-step: 1.58 -> 1.36 ms per step at B = 32.  (C = 16 through the same kernel
     // on a half-empty MFMA block: 1.49 -> 1.72 ms, not kept.)
     if (whole && U.cout == 32 && !c.h->no_respair_c32 && !c.h->no_fused_respair) whole = false;
-    // C = 64 / 32 (round 5): the whole ResBlock on the unpadded swizzled tile (resblock_sw_bf16.hip) — two tensor passes per branch
-    bool sw = !rb2 && nb <= 3 && !c.h->no_fused_resblock && ((U.cout == 64 && (c.h->resblock_sw & 1)) || (U.cout == 32 && (c.h->resblock_sw & 2)));
-    for (int j = 0; j < nb && sw; ++j) sw = m.rbsw_w_off[i][j] >= 0;
-    if (sw) {
-      RbClLaunch F;
-      std::memset(&F, 0, sizeof(F));
-      F.nprob = nb; F.B = B; F.C = U.cout; F.L = Lo; F.nd = m.n_rbd; F.slope = 0.1f; F.lens = lens; F.len_mul = up * U.u;
-      for (int jj = 0; jj < nb; ++jj) {
-        const int j = nb - 1 - jj;                                // widest kernel first
-        RbClProb& p = F.p[jj];
-        p.x = x; p.out = U16(S[1 + j]);
-        p.w = reinterpret_cast<const uint16_t*>(c.W(m.rbsw_w_off[i][j])); p.bias = c.W(m.rbsw_b_off[i][j]);
-        p.k = cf.resblock_kernel_sizes[j];
-        for (int d = 0; d < m.n_rbd; ++d) p.dil[d] = cf.resblock_dilation_sizes[j][d];
-      }
-      if (!c.rc) {
-        const int pi = c.prof_begin("dec.resblock.whole");
-        if (pi >= 0 && c.h->prof_mode >= 3)
-          c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
-                        std::to_string(Lo) + " B" + std::to_string(B);
-        const int r = launch_resblock_sw_bf16(c.s, F);
-        c.prof_end(pi, U.cout == 64 ? "resblock_sw_bf16<64>" : "resblock_sw_bf16<32>", resblock_cl_bf16_flops(F), resblock_cl_bf16_bytes(F));
-        if (r) c.fail("dec.resblock.whole", r);
-      }
-      whole = false;
-    }
     const bool narrow_layerwise = c.h->no_fused_resblock && U.cout <= 32;    // "fused_resblock" = 0: one conv per launch on the narrow stages
     if (whole) {
       // narrow stages: every branch's whole ResBlock (all dilation pairs) in ONE launch, intermediates in LDS
@@ -1144,7 +1118,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     }
     // wide stages: one (dilated conv, conv) pair per launch, the intermediate in LDS (respair_cl_bf16.hip).  A tile's halo rows are
     // another tile's outputs, so a pair never runs in place: branch j ping-pongs between S[1 + j] and S[1 + nb + j] and ends in S[1 + j]
-    bool pairs = !rb2 && !whole && !sw && nb <= 3 && !c.h->no_fused_respair && !narrow_layerwise;
+    bool pairs = !rb2 && !whole && nb <= 3 && !c.h->no_fused_respair && !narrow_layerwise;
     for (int j = 0; j < nb && pairs; ++j)
       for (int d = 0; d < m.n_rbd && pairs; ++d)
         pairs = respair_cl_bf16_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]) &&
@@ -1194,7 +1168,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
       }
       launch(c1, "dec.resblock2.conv", flops_of(c1));
     }
-    for (int d = 0; d < m.n_rbd && !rb2 && !whole && !pairs && !sw; ++d) {
+    for (int d = 0; d < m.n_rbd && !rb2 && !whole && !pairs; ++d) {
       ClLaunch c1, c2;
       c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
       c1.lens = c2.lens = lens; c1.len_mul = c2.len_mul = up * U.u;

@@ -104,9 +104,6 @@ struct Model {
   // the C = 16 stage once more in the tap-pair layout of kernels/resblock_c16_bf16.hip (rb16_w_index); -1 elsewhere
   int64_t rb16_w_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
   int64_t rb16_b_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
-  // the C = 64 / C = 32 stages as whole-ResBlock streams of kernels/resblock_sw_bf16.hip (rbsw_w_index); -1 elsewhere
-  int64_t rbsw_w_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
-  int64_t rbsw_b_off[BV2_MAX_UPS][BV2_MAX_RESBLOCK_KERNELS];
   VecW conv_post;
   int post_c = 0, post_k = 7;
   int total_up = 1;
@@ -135,8 +132,7 @@ struct bv2_handle {
   bool x6_narrow = true;             // "conv_x6_c32" = 0: the C = 32 stage on the fused fp32 pair kernel instead of layer-wise on conv_x6.hip
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
   int prefetch = 0;                  // "prefetch": bit 0 LayerNorm launches, bit 1 split-K launches carry the next launch's weight stream (batch 1); measured: nothing at config 2 (profiles/r05_ab_prefetch_c2.txt), off
-  bool no_xcd_affine = false;        // "xcd_affine" = 0: plain grids for the fp16 Encoder stacks (default: batch item b on XCD b % 8 at B >= 16)
-  int resblock_sw = 0;               // "resblock_sw": bit 0 the C = 64, bit 1 the C = 32 bf16 stage as whole-ResBlock launches (resblock_sw_bf16.hip) instead of pair by pair; measured slower (profiles/r05_ab_resblock_sw_not_kept.txt): off
+  bool no_xcd_affine = false;        // "xcd_affine" = 0: plain grids for the fp16 Encoder stacks (default: batch item b on XCD b % 8 when B >= 8 && (B % 8 == 0 || B >= 32), Ctx::xcd_affine)
   bool no_f16_fused_ln = false;      // "f16_fused_ln" = 0: LayerNorm-1 / the plain LayerNorm-2s of the fp16 Encoder stacks as launches of their own instead of in conv_o's / conv_2's epilogue
   bool no_f16_ksplit = false;        // "f16_ksplit" = 0: the fp16 FFN conv_2 (768 -> 192 rows, 64-column tiles) as 6 waves over three staged chunks instead of 12 waves on K halves of one tile
   bool no_conv_post_rows = false;    // "conv_post_rows" = 0: the bf16 path's conv_post + tanh on the any-width kernel also at C = 16 (default: the row-wise kernel, gen_bf16.hip)

@@ -141,8 +141,9 @@ unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int ti
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6, TILE_128x64 = 7,
        TILE_X6 = 8,            // the split-bf16 form of the LDS-tiled kernel (kernels/conv_x6.hip); TILE_AUTO picks it when every problem has w6
-       TILE_X6_128x64 = 9, TILE_X6_128x64_LD = 10, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12,     // tests / tuning: one x6 tile forced
-       TILE_SPLITK_X6 = 13 };  // the split-K kernel's split-bf16 form (kernels/splitk_x6.hip); TILE_AUTO picks it in the small-N regime when the problem has w6
+       TILE_X6_128x64 = 9, TILE_X6_128x64_LD = 10, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12 };   // tests / tuning: one x6 tile forced
+// (13 was TILE_SPLITK_X6, the split-K kernel's split-bf16 form: measured at +0.4 % on config 2 for +195 MB of blob and deleted in round 6 —
+//  DESIGN.md "measured and not kept", profiles/r05_ab_splitk_x6_not_kept.txt)
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 // fp32 conv on the bf16 matrix core (kernels/conv_x6.hip): every fp32 operand is the exact sum of three bf16 values
 // (v = h1 + h2 + h3, 8 + 8 + 8 significand bits), and the product is accumulated from the six largest of the nine cross terms
@@ -176,8 +177,6 @@ inline void x6_split(float v, uint16_t h[3]) {
   }
 }
 bool conv_x6_supported(const ConvLaunch& L);        // every problem carries w6 and fits the staged tile
-bool splitk_x6_supported(const ConvLaunch& L);      // kernels/splitk_x6.hip: one problem with w6, whole 16-channel groups, <= 64 staged columns
-int launch_splitk_x6(hipStream_t stream, const ConvLaunch& L, const char** variant_name);
 int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 void conv_x6_occupancy(int out[4]);                              // workgroups per CU granted to {128x64, 128x64 + loaders, 64x128, 32x256}
 void conv_x6_set_tuning(int t256, int t128, int t64, int ck);   // tuning experiments only (tools/tune_x6.py); 0 = shipped choice
@@ -289,19 +288,6 @@ inline int64_t rb16_w_index(int j, int ci, int co) {            // tap j, input 
 }
 bool resblock_c16_bf16_supported(int C, int k, const int* dil, int nd);
 int launch_resblock_c16_bf16(hipStream_t stream, const RbClLaunch& L);
-
-// ... and for C = 64 / C = 32 on v_mfma_f32_32x32x16_bf16 with unpadded XOR-swizzled LDS rows (kernels/resblock_sw_bf16.hip, round 5): a wave
-// owns NB 32-row blocks x all C output channels.  Same RbClLaunch, but
-//   w    : [conv c = 2 d + e][tap j][16-channel group g][32-row tile mt][lane 64][8 bf16] (rbsw_w_index; a tap's fragments contiguous)
-//   bias : fp32 [2*nd][C]
-inline int64_t rbsw_w_index(int c, int j, int ci, int co, int C, int k) {
-  const int G = C / 16, MT = C / 32;
-  const int lane = (co & 31) + 32 * ((ci % 16) / 8);
-  return (((((int64_t)c * k + j) * G + ci / 16) * MT + co / 32) * 64 + lane) * 8 + (ci % 8);
-}
-bool resblock_sw_bf16_supported(int C, int k, const int* dil, int nd);
-int64_t resblock_sw_bf16_w_elems(int C, int k, int nd);
-int launch_resblock_sw_bf16(hipStream_t stream, const RbClLaunch& L);
 
 // one (dilated conv, conv) pair of ResBlock1 with its residual at C = 64 / 128 / 256 in one launch, bf16 channels-last, the
 // intermediate in LDS (kernels/respair_cl_bf16.hip).  x / out: [B][L][C], out != x; w1 / w2: the convs' ordinary fragment streams

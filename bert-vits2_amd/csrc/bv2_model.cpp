@@ -261,9 +261,9 @@ EncoderW pack_encoder(Packer& P, const std::string& p, int hidden, int filter, i
     L.b1 = P.vec(p + ".norm_layers_1." + std::to_string(i) + ".beta", {hidden});
     const std::string f = p + ".ffn_layers." + std::to_string(i);
     // (Round 5, measured and not kept: these two convs also as the three split-bf16 planes, so that at batch 1 their split-K launches
-    // run on kernels/splitk_x6.hip — config 2 3.611 / 3.596 -> 3.584 / 3.588 ms for +195 MB of blob: a split-K launch at batch 1 is 10k
+    // run on the bf16 matrix core — config 2 3.611 / 3.596 -> 3.584 / 3.588 ms for +195 MB of blob: a split-K launch at batch 1 is 10k
     // ticks of prologue (first bytes of x and of the weights), 10k of K loop and 2k of epilogue behind a ~3 us launch gap, and only the
-    // loop gets shorter; profiles/r05_ab_splitk_x6_not_kept.txt.  The kernel stays, with its tests, behind TILE_SPLITK_X6.)
+    // loop gets shorter; profiles/r05_ab_splitk_x6_not_kept.txt.  The kernel was deleted in round 6.)
     L.ffn1 = P.conv1d(f + ".conv_1", filter, hidden, ksize);
     L.ffn2 = P.conv1d(f + ".conv_2", hidden, filter, ksize);
     L.g2 = P.vec(p + ".norm_layers_2." + std::to_string(i) + ".gamma", {hidden});
@@ -456,7 +456,7 @@ int pack_all(Model& m, Packer& P) {
       }
       P.emit_x6 = false;
       if (rb2) {                                   // the fused / whole-ResBlock streams describe (conv, conv) pairs: ResBlock1 only
-        m.rbcl_w_off[i][j] = m.rbcl_b_off[i][j] = m.rbsw_w_off[i][j] = m.rbsw_b_off[i][j] = m.rb16_w_off[i][j] = m.rb16_b_off[i][j] = -1;
+        m.rbcl_w_off[i][j] = m.rbcl_b_off[i][j] = m.rb16_w_off[i][j] = m.rb16_b_off[i][j] = -1;
         continue;
       }
       // narrow stages: the 2*n_rbd convs of the block once more as ONE contiguous bf16 stream (+ one bias block) for the
@@ -481,25 +481,6 @@ int pack_all(Model& m, Packer& P) {
                               sizeof(uint16_t) * 512);
               (void)U;
               std::memcpy(P.blob + m.rbcl_b_off[i][j] + (2 * d + e) * 32, P.blob + cw.b_off, sizeof(float) * (size_t)ch);
-            }
-        }
-      }
-      // C = 64 / 32: the whole-ResBlock stream of resblock_sw_bf16.hip ([conv][tap][group][m-tile] fragments), same bf16 values
-      m.rbsw_w_off[i][j] = m.rbsw_b_off[i][j] = -1;
-      if (m.n_rbd <= BV2_RBCL_MAX_D && resblock_sw_bf16_supported(ch, k, c.resblock_dilation_sizes[j], m.n_rbd)) {
-        const int64_t ne = resblock_sw_bf16_w_elems(ch, k, m.n_rbd);
-        m.rbsw_w_off[i][j] = P.alloc((ne + 1) / 2 + 2048);          // + slack: nothing reads past the stream, kept for symmetry with the rings
-        m.rbsw_b_off[i][j] = P.alloc((int64_t)2 * m.n_rbd * ch);
-        if (P.fill()) {
-          uint16_t* dst = reinterpret_cast<uint16_t*>(P.blob + m.rbsw_w_off[i][j]);
-          for (int d = 0; d < m.n_rbd; ++d)
-            for (int e = 0; e < 2; ++e) {
-              const ConvW& cw = m.rb[i][j][d][e];
-              const uint16_t* src = reinterpret_cast<const uint16_t*>(P.blob + cw.wb_off);
-              for (int co = 0; co < ch; ++co)
-                for (int ci = 0; ci < ch; ++ci)
-                  for (int j2 = 0; j2 < k; ++j2) dst[rbsw_w_index(2 * d + e, j2, ci, co, ch, k)] = src[cl_w_index(j2, ci, co, ch, k)];
-              std::memcpy(P.blob + m.rbsw_b_off[i][j] + (2 * d + e) * ch, P.blob + cw.b_off, sizeof(float) * (size_t)ch);
             }
         }
       }

@@ -889,14 +889,10 @@ int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char*
   if (g_tune_force_ck == 16) ck = 16;
   for (int i = 0; i < L.nprob; ++i)
     if (L.p[i].cin_pad / ck > max_chunks) max_chunks = L.p[i].cin_pad / ck;
-  if (tile == TILE_SPLITK_X6) return (L.ksplit < 1 || L.ksplit > BV2_MAX_KSPLIT) ? -1 : launch_splitk_x6(stream, L, variant_name);
   const bool auto_sk = tile == TILE_AUTO && conv_use_splitk(L);
   if (auto_sk) tile = TILE_SPLITK;
   if (tile == TILE_SPLITK) {
     if (L.ksplit < 1 || L.ksplit > BV2_MAX_KSPLIT) return -1;
-    // the problem carries its split-bf16 weight planes: the same tile on the bf16 matrix core (splitk_x6.hip) — a forced TILE_SPLITK
-    // (tests, tuning) stays on the fp32 kernel
-    if (auto_sk && !L.pf.ptr && splitk_x6_supported(L)) return launch_splitk_x6(stream, L, variant_name);
     return launch_splitk(stream, L, max_cout_pad, variant_name);
   }
   if (L.ksplit != 1) return -1;                   // the LDS-tiled kernel never splits K across workgroups

@@ -283,7 +283,12 @@ __global__ void __launch_bounds__(64 * WN * KS) conv_f16_kernel(const HcLaunch L
         for (int r = 0; r < 16; ++r) red[((((kh - 1) * WN + wm) * NI + ni) * 16 + r) * 64 + lane] = acc[ni][r];
     }
     __syncthreads();
-    if (kh > 0) return;
+    if (kh > 0) {
+      // the kh == 0 waves go on to the LayerNorm epilogue's three barriers: the K-half waves keep the workgroup's barrier count whole
+      // (a wave that has ended is dropped from s_barrier on CDNA, but HIP leaves a barrier not reached by every thread undefined)
+      if constexpr (LN && OUT_CT) { __syncthreads(); __syncthreads(); __syncthreads(); }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < KS - 1; ++q)
 #pragma unroll

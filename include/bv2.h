@@ -286,13 +286,9 @@ void bv2_graph_destroy(bv2_graph* graph);
  *                     LayerNorm-1, the next layer's q/k/v projection behind LayerNorm-2), bit 1 — a split-K conv launch does (conv_2 behind
  *                     conv_1): 128 spare workgroups touch it line by line into the L2 of the XCD whose workgroups will read it
  *                     (bv2_kernels.h Prefetch).  0: every launch fetches its own weights from HBM / the Infinity Cache when it starts
- *   "xcd_affine"      1 (default): in the fp16 Encoder stacks at batch >= 16, batch item b runs on XCD b % 8 in EVERY kernel of a layer (q/k/v,
+ *   "xcd_affine"      1 (default): in the fp16 Encoder stacks at batch 8, 16, 24 and any batch >= 32 (B >= 8 && (B % 8 == 0 || B >= 32): the batch fills the eight XCDs about evenly), batch item b runs on XCD b % 8 in EVERY kernel of a layer (q/k/v,
  *                     attention, conv_o, LayerNorms, FFN convs), so a layer's tensors are handed on inside one XCD's L2 (the eight L2s are
  *                     not coherent with each other); 0: plain grids
- *   "resblock_sw"     default 0 (pair by pair, respair_cl_bf16.hip).  Bit 0 — the C = 64, bit 1 — the C = 32 bf16 stage as ONE whole-ResBlock launch
- *                     per stage on unpadded XOR-swizzled LDS rows (two tensor passes per branch instead of six: kernels/resblock_sw_bf16.hip).
- *                     Bit-identical to the pair kernels; measured SLOWER at B = 32 (C = 64: 2.58 against 2.17 ms per step, C = 32: 1.44
- *                     against 1.36) — kept as an option and as the record of the experiment
  *   "respair_form"    1 (default): 64-channel x 128-row wave tiles on the XOR-swizzled tile; 0: 32-channel waves on the padded tile
  *   "respair_mix"     1 (default): the k = 11 / 7 / 3 branches of a pair launch interleaved in dispatch order; 0: branch after branch
  *   "fused_dds"       one launch per DDSConv layer incl. the projection / spline that follows (0: 3 launches per layer)

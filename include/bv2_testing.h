@@ -50,8 +50,7 @@ int bv2_test_conv_cl_bf16(void* stream, const void* x0, const void* x1, const vo
 /* a WHOLE ResBlock1 (nd (dilated conv, conv) pairs with their residuals, reference modules.py:296-309) of a narrow Generator stage in one
  * launch, bf16 channels-last: x / out DEVICE bf16 [B][L][C] (out != x), w_host [nd][2][C][C][k] and bias_host [nd][2][C] HOST fp32 (index
  * [d][0] = convs1[d] with dilation dil[d], [d][1] = convs2[d]); variant 0 = kernels/resblock_cl_bf16.hip (v_mfma_f32_32x32x16_bf16, C = 16 /
- * 32), 1 = kernels/resblock_c16_bf16.hip (v_mfma_f32_16x16x32_bf16, C = 16), 2 = kernels/resblock_sw_bf16.hip (unpadded swizzled tile, C = 32 /
- * 64); lens: optional DEVICE int64 [B] valid rows per item;
+ * 32), 1 = kernels/resblock_c16_bf16.hip (v_mfma_f32_16x16x32_bf16, C = 16); lens: optional DEVICE int64 [B] valid rows per item;
  * wpack_dev needs bv2_test_resblock_cl_pack_bytes(C, k, nd) bytes.  Returns -2 for an unsupported shape. */
 int64_t bv2_test_resblock_cl_pack_bytes(int C, int k, int nd);
 int bv2_test_resblock_cl(void* stream, const void* x, void* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,

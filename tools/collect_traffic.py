@@ -26,8 +26,6 @@ def family(kname):
         return f"conv1d_x6<{a[0] * a[2] * 32}x{a[1] * a[3] * 32}{',ld' if len(a) > 6 and a[6] > 0 else ''}>"
     if "respair_x6_kernel<" in kname:           # <C, WNT> -> the name bv2_exec.cpp reports
         return f"respair_x6<{int(kname.split('respair_x6_kernel<')[1].split(',')[0])}>"
-    if "conv1d_splitk_x6_kernel" in kname:
-        return "conv1d_splitk_x6<32x32>"
     if "conv1d_splitk_kernel" in kname:
         return "conv1d_splitk<32x32>"
     if "conv_cl_bf16_kernel" in kname:
@@ -43,8 +41,6 @@ def family(kname):
         return f"respair_cl_bf16<{16 * a[2]},64x128>"
     if "resblock_c16_bf16_kernel" in kname:     # round 5: the C = 16 whole-ResBlock kernel on v_mfma_f32_16x16x32_bf16
         return "resblock_c16_bf16"
-    if "resblock_sw_bf16_kernel<" in kname:
-        return f"resblock_sw_bf16<{int(kname.split('resblock_sw_bf16_kernel<')[1].split('>')[0])}>"
     if "resblock_cl_bf16_kernel" in kname:
         return "resblock_cl_bf16<C32>" if "<32," in kname else "resblock_cl_bf16<C16>"
     if "conv_f16_kernel" in kname:
