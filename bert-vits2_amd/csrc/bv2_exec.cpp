@@ -1085,6 +1085,15 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
     // on a half-empty MFMA block: 1.49 -> 1.72 ms, not kept.)
     if (whole && U.cout == 32 && !c.h->no_respair_c32 && !c.h->no_fused_respair) whole = false;
     const bool narrow_layerwise = c.h->no_fused_resblock && U.cout <= 32;    // "fused_resblock" = 0: one conv per launch on the narrow stages
+    // Stage hand-over (round 6): the kernel that finishes a stage's branches runs them tile by tile in one workgroup and writes ONE tensor, the
+    // branch mean (cl_bf16.h stage_mean) — the next ConvTranspose1d / conv_post reads 1 tensor instead of n.  Off ("stage_sum" = 0, a branch tap
+    // set, a kernel without the form): n tensors and the consumer forms the same mean with the same rounding points — bit-identical results.
+    bool want_sum = !c.h->no_stage_sum && nb > 1 && nb <= 3;
+    if (want_sum)
+      for (const auto& kv : c.h->taps)
+        if (kv.first.compare(0, 7, "dec.rb.") == 0) want_sum = false;
+    bool summed = false;
+    uint16_t* const sum_t = U16(S[1]);              // branch 0's final buffer: no launch of the stage's last step reads it
     if (whole) {
       // narrow stages: every branch's whole ResBlock (all dilation pairs) in ONE launch, intermediates in LDS
       RbClLaunch F;
@@ -1106,6 +1115,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
           const int j = nb - 1 - jj;
           F.p[jj].w = reinterpret_cast<const uint16_t*>(c.W(m.rb16_w_off[i][j])); F.p[jj].bias = c.W(m.rb16_b_off[i][j]);
         }
+      if (c16 && want_sum) { F.sum_out = sum_t; summed = true; }
       if (!c.rc) {
         const int pi = c.prof_begin("dec.resblock.whole");
         if (pi >= 0 && c.h->prof_mode >= 3)
@@ -1130,6 +1140,7 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
       F.mix = c.h->respair_problem_major ? 0 : 1;
       F.form = c.h->respair_form;
       const bool to_cur = ((m.n_rbd - 1 - d) & 1) == 0;
+      if (want_sum && d + 1 == m.n_rbd) { F.sum_out = sum_t; summed = true; }     // the stage's last pair launch leaves the branch mean
       for (int jj = 0; jj < nb; ++jj) {
         const int j = nb - 1 - jj;                                // widest kernel first
         uint16_t* cur = U16(S[1 + j]);
@@ -1187,9 +1198,10 @@ static void gen_core_bf16(Ctx& c, const PlanB& P, const float* z, int z_rstride,
       launch(c1, "dec.resblock.convs1", flops_of(c1));
       launch(c2, "dec.resblock.convs2", flops_of(c2));
     }
-    for (int j = 0; j < 3; ++j) src[j] = j < nb ? U16(S[1 + j]) : nullptr;
-    for (int j = 0; j < nb; ++j) tap_cl("dec.rb." + std::to_string(i) + "." + std::to_string(j), src[j], U.cout, Lo);
-    nsrc = nb;
+    for (int j = 0; j < 3; ++j) src[j] = j < nb && (j == 0 || !summed) ? U16(S[1 + j]) : nullptr;
+    if (summed) tap_cl("dec.stage." + std::to_string(i), src[0], U.cout, Lo);
+    else for (int j = 0; j < nb; ++j) tap_cl("dec.rb." + std::to_string(i) + "." + std::to_string(j), src[j], U.cout, Lo);
+    nsrc = summed ? 1 : nb;
     Lc = Lo;
     up *= U.u;
   }

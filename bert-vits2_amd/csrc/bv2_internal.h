@@ -137,6 +137,7 @@ struct bv2_handle {
   bool no_f16_ksplit = false;        // "f16_ksplit" = 0: the fp16 FFN conv_2 (768 -> 192 rows, 64-column tiles) as 6 waves over three staged chunks instead of 12 waves on K halves of one tile
   bool no_conv_post_rows = false;    // "conv_post_rows" = 0: the bf16 path's conv_post + tanh on the any-width kernel also at C = 16 (default: the row-wise kernel, gen_bf16.hip)
   bool no_ups_phase_taps = false;    // "ups_phase_taps" = 0: the bf16 ConvTranspose1d launches multiply through the zero taps of the union window (A/B and bit-identity tests)
+  bool no_stage_sum = false;         // "stage_sum" = 0: every bf16 Generator stage hands its n branch tensors to the next launch, which forms the mean (default: the stage's last ResBlock launch writes ONE tensor, the mean)
   bool no_resblock_c16 = false;      // "resblock_c16" = 0: the C = 16 bf16 stage on the 32x32x16 whole-ResBlock kernel (resblock_cl_bf16.hip) instead of resblock_c16_bf16.hip
   bool no_respair_c32 = false;       // "respair_c32" = 0: the C = 32 bf16 stage as whole-ResBlock launches (resblock_cl_bf16.hip) instead of pair by pair
   int respair_form = 1;              // "respair_form": 1 = 64 x 128 wave tiles (respair2_cl_bf16_kernel), 0 = 32-channel waves

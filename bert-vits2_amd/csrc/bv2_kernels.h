@@ -270,7 +270,11 @@ double conv_cl_bytes(const ClLaunch& L);
 #define BV2_RBCL_MAX_D 4
 constexpr int RBCL_PD = 8;        // weight ring depth = unit padding of the stream
 struct RbClProb { const uint16_t* x; uint16_t* out; const uint16_t* w; const float* bias; int k; int dil[BV2_RBCL_MAX_D]; int halo; };
-struct RbClLaunch { RbClProb p[3]; int nprob, B, C, L, nd; float slope; const int64_t* lens = nullptr; int len_mul = 1; };
+struct RbClLaunch { RbClProb p[3]; int nprob, B, C, L, nd; float slope; const int64_t* lens = nullptr; int len_mul = 1;
+                    // stage hand-over (round 6, resblock_c16_bf16.hip only): non-null = ONE workgroup runs the nprob branches of its tile one after
+                    // the other and the stage's output tensor — the branch mean with the rounding points of cl_bf16.h stage_mean — is written
+                    // here instead of one tensor per branch into p[i].out
+                    uint16_t* sum_out = nullptr; int halo_max = 0; float sum_scale = 1.f; };
 bool resblock_cl_bf16_supported(int C, int k, const int* dil, int nd);
 int resblock_cl_bf16_units(int C, int k);
 int launch_resblock_cl_bf16(hipStream_t stream, const RbClLaunch& L);
@@ -296,6 +300,10 @@ struct RpClProb { const uint16_t* x; uint16_t* out; const uint16_t* w1; const ui
 struct RpClLaunch { RpClProb p[3]; int nprob, B, C, L; float slope; const int64_t* lens = nullptr; int len_mul = 1;
                     int form = 1;    // 1: 64-channel x 128-row wave tiles on the swizzled tile, 0: 32-channel waves on the padded tile
                     int mix = 1;     // 1: the problems interleaved in dispatch order (every CU holds tiles of all branches), 0: problem-major
+                    // stage hand-over (round 6): non-null on a stage's LAST pair launch = one workgroup runs the nprob branches of its tile one
+                    // after the other (p[0] first) and accumulates their outputs into ONE tensor here (read-modify-write of its own rows,
+                    // which stay in L2) — the branch mean with the rounding points of cl_bf16.h stage_mean; p[i].out is not written
+                    uint16_t* sum_out = nullptr; int kmax = 0; float sum_scale = 1.f;
                     unsigned long long* dbg = nullptr; };
 bool respair_cl_bf16_supported(int C, int k, int dil);
 int launch_respair_cl_bf16(hipStream_t stream, const RpClLaunch& L, const char** variant_name);

@@ -22,10 +22,33 @@ __device__ __forceinline__ unsigned bf_pack(float a, float b) {     // round-to-
   return __builtin_bit_cast(unsigned, r);
 }
 
+__device__ __forceinline__ float bf_round(float v) { return (float)(__bf16)v; }     // round-to-nearest-even to a bf16 value
+
+// The stage hand-over's rounding points (oracle generator_bf16; reference models.py:545-552 `xs / self.num_kernels`): a stage's n <= 3 branch
+// outputs r_j (each already bf16) are summed widest kernel first — branch n-1, n-2, ... 0 — with the running sum rounded to bf16 wherever the
+// summed-output kernels store it, and the mean is bf16((running sum + r_0) * fp32(1/n)).  Both forms of the hand-over compute exactly this:
+// the producer that writes one tensor (RpClLaunch / RbClLaunch sum_out) and the consumer that reads the n branch tensors (x0 = branch 0).
+__device__ __forceinline__ float stage_mean(float x0, float x1, float x2, int nsrc, float scale) {
+  if (nsrc <= 1) return x0;
+  const float s = nsrc > 2 ? bf_round(x2 + x1) + x0 : x1 + x0;
+  return bf_round(s * scale);
+}
+// the producer side of the same sum, one 16-byte piece (8 bf16) at a time: prev = the running sum, r = this branch's output
+__device__ __forceinline__ u32x4 stage_accum(u32x4 r, u32x4 prev, bool last, float scale) {
+  u32x4 o;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    float lo = bf_lo(prev[w]) + bf_lo(r[w]), hi = bf_hi(prev[w]) + bf_hi(r[w]);
+    if (last) { lo *= scale; hi *= scale; }
+    o[w] = bf_pack(lo, hi);
+  }
+  return o;
+}
+
 constexpr int CL_PD = 8;          // weight prefetch ring depth (units of 4 MFMAs)
 
 // Stage rows [tb, tb + rows) x cin channels of up to 3 sources into LDS (pitch in elements), applying
-// pre(v) = bf16(lrelu(in_scale * sum)).  Rows outside [0, Lin) are zero (the conv's padding).
+// pre(v) = bf16(lrelu(stage_mean(sources))).  Rows outside [0, Lin) are zero (the conv's padding).
 // Every load of a batch is issued before the first one is used (QB pieces of 16 B per thread in flight): tools/timeline.py showed
 // the staging at three SERIAL global round trips of ~4.6k cycles each with batches of 4 — as long as the k = 11 GEMM it feeds.
 template <int NT, int QB, bool MULTI>
@@ -66,10 +89,9 @@ __device__ __forceinline__ void cl_stage_impl(unsigned short* xs, int pitch, con
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           float a = bf_lo(v[q][0][w]), b = bf_hi(v[q][0][w]);
-          if (MULTI) {
-            if (nsrc > 1) { a += bf_lo(v[q][1][w]); b += bf_hi(v[q][1][w]); }
-            if (nsrc > 2) { a += bf_lo(v[q][2][w]); b += bf_hi(v[q][2][w]); }
-            if (nsrc > 1) { a *= in_scale; b *= in_scale; }
+          if (MULTI) {                            // the branch mean, rounded where the summed-output producers round it (stage_mean)
+            a = stage_mean(a, nsrc > 1 ? bf_lo(v[q][1][w]) : 0.f, nsrc > 2 ? bf_lo(v[q][2][w]) : 0.f, nsrc, in_scale);
+            b = stage_mean(b, nsrc > 1 ? bf_hi(v[q][1][w]) : 0.f, nsrc > 2 ? bf_hi(v[q][2][w]) : 0.f, nsrc, in_scale);
           }
           if (lrelu) { a = a < 0.f ? a * slope : a; b = b < 0.f ? b * slope : b; }
           o[w] = bf_pack(a, b);

@@ -446,17 +446,13 @@ __global__ void __launch_bounds__(CP_TS) conv_post_cl_kernel(const ConvPostClArg
     if (!inq[q]) continue;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (s < A.nsrc) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { v[2 * w] += bf_lo(u[q][s][w]); v[2 * w + 1] += bf_hi(u[q][s][w]); }
-      }
+    for (int w = 0; w < 4; ++w) {                 // the last stage's branch mean with the hand-over's rounding points (cl_bf16.h stage_mean)
+      v[2 * w] = stage_mean(bf_lo(u[q][0][w]), bf_lo(u[q][1][w]), bf_lo(u[q][2][w]), A.nsrc, A.in_scale);
+      v[2 * w + 1] = stage_mean(bf_hi(u[q][0][w]), bf_hi(u[q][1][w]), bf_hi(u[q][2][w]), A.nsrc, A.in_scale);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float a = v[e] * A.in_scale;
+      float a = v[e];
       a = a < 0.f ? a * A.slope : a;
       v[e] = okq[q] ? a : 0.f;
     }
@@ -495,22 +491,18 @@ __global__ void __launch_bounds__(CP_TS) conv_post_cl16_kernel(const ConvPostClA
   const int64_t off = ((int64_t)b * A.L + tc) * C;
   u32x4 u[3][2];
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
-    if (s < A.nsrc) {
-      u[s][0] = *reinterpret_cast<const u32x4*>(A.x[s] + off);
-      u[s][1] = *reinterpret_cast<const u32x4*>(A.x[s] + off + 8);
-    }
+  for (int s = 0; s < 3; ++s) {
+    u[s][0] = *reinterpret_cast<const u32x4*>(A.x[s < A.nsrc ? s : 0] + off);
+    u[s][1] = *reinterpret_cast<const u32x4*>(A.x[s < A.nsrc ? s : 0] + off + 8);
+  }
   if (tid < K * C) ws[(tid % K) * C + tid / K] = A.w[tid];          // A.w is [c][k]
   float x[C];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      float lo = 0.f, hi = 0.f;
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-        if (s < A.nsrc) { lo += bf_lo(u[s][h][w]); hi += bf_hi(u[s][h][w]); }
-      lo *= A.in_scale; hi *= A.in_scale;
+      float lo = stage_mean(bf_lo(u[0][h][w]), bf_lo(u[1][h][w]), bf_lo(u[2][h][w]), A.nsrc, A.in_scale);
+      float hi = stage_mean(bf_hi(u[0][h][w]), bf_hi(u[1][h][w]), bf_hi(u[2][h][w]), A.nsrc, A.in_scale);
       lo = lo < 0.f ? lo * A.slope : lo; hi = hi < 0.f ? hi * A.slope : hi;
       x[8 * h + 2 * w] = ok ? lo : 0.f; x[8 * h + 2 * w + 1] = ok ? hi : 0.f;
     }

@@ -79,6 +79,8 @@ struct R16Ctx {
   int q4;                            // 4 * q: first of this lane's 4 output channels
   float slope;
   unsigned wl;                       // lane * 16: byte offset of this lane's fragment inside a 1 KB weight unit
+  int sum_mode;                      // stage hand-over: 0 = plain store, 1 = first branch (plain store into the sum tensor), 2 = add to the
+  float sum_scale;                   // running sum, 3 = last branch (add, scale by 1/n): cl_bf16.h stage_mean's rounding points
 };
 
 // One conv of the block: acc = bias + sum_u W(u) x B(u) over the KU tap pairs, for the wave's 8 blocks in R16_NB / R16_HB passes.
@@ -148,7 +150,18 @@ __device__ __forceinline__ void r16_conv(R16Ctx c, bf16x8 (&W)[KU], const uint16
         xr[ni][0] = x.x; xr[ni][1] = x.y;
         if (last) {
           // 32-bit element offset inside the batch item (L * 16 < 2^31 is checked by the launcher)
-          if (tg >= c.t0 && tg < c.tend) *reinterpret_cast<u32x2*>(outg + (unsigned)(tg * 16 + c.q4)) = x;
+          if (tg >= c.t0 && tg < c.tend) {
+            u32x2* og = reinterpret_cast<u32x2*>(outg + (unsigned)(tg * 16 + c.q4));
+            if (c.sum_mode >= 2) {
+              // hand-over: the running sum of the earlier branches — this LANE's own store of the previous iteration (same tile origin for
+              // every branch), read back from L2 — plus this branch's output
+              const u32x2 pv = *og;
+              float s0 = r16_lo(pv.x) + r16_lo(x.x), s1 = r16_hi(pv.x) + r16_hi(x.x), s2 = r16_lo(pv.y) + r16_lo(x.y), s3 = r16_hi(pv.y) + r16_hi(x.y);
+              if (c.sum_mode == 3) { s0 *= c.sum_scale; s1 *= c.sum_scale; s2 *= c.sum_scale; s3 *= c.sum_scale; }
+              x.x = r16_pack(s0, s1); x.y = r16_pack(s2, s3);
+            }
+            *og = x;
+          }
         } else {
           u32x2 o;
           o.x = r16_act(x.x, c.slope); o.y = r16_act(x.y, c.slope);
@@ -160,21 +173,22 @@ __device__ __forceinline__ void r16_conv(R16Ctx c, bf16x8 (&W)[KU], const uint16
 }
 
 template <int KU>
-__device__ __forceinline__ void r16_block(const RbClLaunch& L, const RbClProb& P, int b, int t0, int TT, int Lseq) {
+__device__ __forceinline__ void r16_block(const RbClLaunch& L, const RbClProb& P, int b, int t0, int TT, int Lseq, int halo, int sum_mode) {
   constexpr int NT = 64 * R16_NW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4, row0 = wid * 16 * R16_NB;
   R16Ctx c;
-  c.tg0 = t0 - P.halo + row0 + t;
+  c.tg0 = t0 - halo + row0 + t;
   c.t0 = t0; c.tend = t0 + TT < Lseq ? t0 + TT : Lseq; c.Lseq = Lseq;
   c.own = (unsigned)(((R16_G + row0 + t) * R16_P + 4 * q) * 2);
   c.rd = (unsigned)(((R16_G + row0 + t) * R16_P + (q & 1) * 8) * 2);
   c.qt = q >> 1; c.q4 = 4 * q;
   c.slope = L.slope; c.wl = (unsigned)lane * 16u;
+  c.sum_mode = sum_mode; c.sum_scale = L.sum_scale;
   const int Lrow = L.L, nd = L.nd, halfk = (P.k - 1) / 2;
   const uint16_t* xg = P.x + (int64_t)b * Lrow * 16;
-  uint16_t* outg = P.out + (int64_t)b * Lrow * 16;
+  uint16_t* outg = (L.sum_out ? L.sum_out : P.out) + (int64_t)b * Lrow * 16;
 
   // the first conv's weights go in flight before anything else
   bf16x8 W[KU];
@@ -227,23 +241,32 @@ __device__ __forceinline__ void r16_block(const RbClLaunch& L, const RbClProb& P
 }  // namespace
 
 __global__ void __launch_bounds__(64 * R16_NW, 4) resblock_c16_bf16_kernel(const RbClLaunch L) {
-  const RbClProb& P = L.p[blockIdx.z];
-  const int TT = R16_R - 2 * P.halo;              // output rows per tile
-  const int t0 = blockIdx.x * TT;
-  if (t0 >= L.L) return;                          // branches with a smaller halo need fewer tiles
-  const int b = blockIdx.y;
-  int Lseq = L.L;
-  if (L.lens) {
-    const int64_t lv = L.lens[b] * L.len_mul;
-    Lseq = lv < L.L ? (int)lv : L.L;
-    if (t0 >= Lseq) return;                       // a tile wholly past the utterance: nobody reads its outputs
-  }
-  switch (P.k) {                                  // wave-uniform: KU = (k + 1) / 2 tap pairs per conv
-    case 3: r16_block<2>(L, P, b, t0, TT, Lseq); break;
-    case 5: r16_block<3>(L, P, b, t0, TT, Lseq); break;
-    case 7: r16_block<4>(L, P, b, t0, TT, Lseq); break;
-    case 9: r16_block<5>(L, P, b, t0, TT, Lseq); break;
-    default: r16_block<6>(L, P, b, t0, TT, Lseq); break;
+  // stage hand-over (L.sum_out): one workgroup runs the nprob branches of its tile one after the other — same tile origin (the widest halo) for
+  // every branch, so a lane owns the same output elements in each — and leaves ONE tensor: x is read from HBM once (the later branches find it
+  // in L2) and one output is written instead of one per branch
+  const int nit = L.sum_out ? L.nprob : 1;
+  for (int it = 0; it < nit; ++it) {
+    const RbClProb& P = L.p[__builtin_amdgcn_readfirstlane(L.sum_out ? it : (int)blockIdx.z)];
+    const int halo = L.sum_out ? L.halo_max : P.halo;
+    const int TT = R16_R - 2 * halo;              // output rows per tile
+    const int t0 = blockIdx.x * TT;
+    if (t0 >= L.L) return;                        // branches with a smaller halo need fewer tiles
+    const int b = blockIdx.y;
+    int Lseq = L.L;
+    if (L.lens) {
+      const int64_t lv = L.lens[b] * L.len_mul;
+      Lseq = __builtin_amdgcn_readfirstlane(lv < L.L ? (int)lv : L.L);
+      if (t0 >= Lseq) return;                     // a tile wholly past the utterance: nobody reads its outputs
+    }
+    const int sm = !L.sum_out ? 0 : (it == 0 ? 1 : (it + 1 == nit ? 3 : 2));
+    switch (P.k) {                                // wave-uniform: KU = (k + 1) / 2 tap pairs per conv
+      case 3: r16_block<2>(L, P, b, t0, TT, Lseq, halo, sm); break;
+      case 5: r16_block<3>(L, P, b, t0, TT, Lseq, halo, sm); break;
+      case 7: r16_block<4>(L, P, b, t0, TT, Lseq, halo, sm); break;
+      case 9: r16_block<5>(L, P, b, t0, TT, Lseq, halo, sm); break;
+      default: r16_block<6>(L, P, b, t0, TT, Lseq, halo, sm); break;
+    }
+    if (it + 1 < nit) __syncthreads();            // the next branch re-stages x over the tiles
   }
 }
 
@@ -265,16 +288,21 @@ int launch_resblock_c16_bf16(hipStream_t stream, const RbClLaunch& L0) {
   RbClLaunch L = L0;
   if (L.nprob < 1 || L.nprob > 3 || L.B < 1 || L.L < 1 || L.C != 16 || (int64_t)L.L * 16 >= (1ll << 31)) return -1;
   int max_tiles = 0;
+  L.halo_max = 0;
   for (int i = 0; i < L.nprob; ++i) {
     if (!resblock_c16_bf16_supported(L.C, L.p[i].k, L.p[i].dil, L.nd)) return -1;
     L.p[i].halo = r16_halo(L.p[i].k, L.p[i].dil, L.nd);
-    const int TT = R16_R - 2 * L.p[i].halo;
+    if (L.p[i].halo > L.halo_max) L.halo_max = L.p[i].halo;
+  }
+  L.sum_scale = 1.f / (float)L.nprob;
+  for (int i = 0; i < L.nprob; ++i) {
+    const int TT = R16_R - 2 * (L.sum_out ? L.halo_max : L.p[i].halo);
     const int nt = (L.L + TT - 1) / TT;
     if (nt > max_tiles) max_tiles = nt;
   }
   const size_t lds = (size_t)2 * R16_ROWS * R16_P * 2;
   ensure_dyn_lds((const void*)resblock_c16_bf16_kernel, lds);
-  hipLaunchKernelGGL(resblock_c16_bf16_kernel, dim3(max_tiles, L.B, L.nprob), dim3(64 * R16_NW), lds, stream, L);
+  hipLaunchKernelGGL(resblock_c16_bf16_kernel, dim3(max_tiles, L.B, L.sum_out ? 1 : L.nprob), dim3(64 * R16_NW), lds, stream, L);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

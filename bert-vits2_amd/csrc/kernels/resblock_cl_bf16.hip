@@ -317,9 +317,10 @@ double resblock_cl_bf16_flops(const RbClLaunch& L) {
   return f;
 }
 
-double resblock_cl_bf16_bytes(const RbClLaunch& L) {   // x read once, out written once, weights once
+double resblock_cl_bf16_bytes(const RbClLaunch& L) {   // x read once, out written once, weights once (hand-over: x and ONE output for all branches)
   double by = 0;
-  for (int i = 0; i < L.nprob; ++i) by += 2.0 * (2.0 * L.C * (double)L.L * L.B + 2.0 * L.nd * L.C * L.C * L.p[i].k);
+  for (int i = 0; i < L.nprob; ++i)
+    by += 2.0 * ((L.sum_out && i ? 0.0 : 2.0) * L.C * (double)L.L * L.B + 2.0 * L.nd * L.C * L.C * L.p[i].k);
   return by;
 }
 

@@ -46,15 +46,25 @@ respair_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
     pz = q % mix;
     bx = ((q / mix) << 3) | (bx & 7);
   }
-  const RpClProb P = L.p[pz];                     // by value: one kernarg round trip
-  const int tid = threadIdx.x, lane = tid & 63;
+  // stage hand-over (L.sum_out): this workgroup runs ALL branches of its tile, p[0] first, and accumulates them into one tensor
+  const int nit = L.sum_out ? L.nprob : 1;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;         // timeline stamps (tools/timeline.py; L.dbg is null in the product)
+  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
+  int kdbg = 0;
+  for (int it = 0; it < nit; ++it) {
+  // everything per-lane is re-derived from an opaque copy of the thread index inside the loop: hoisted out of it, the staging / epilogue
+  // addresses of all phases stayed alive across the whole body and the kernel spilled
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid % WN, wm = wid / WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;         // timeline stamps (tools/timeline.py; L.dbg is null in the product)
-  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
+  // (readfirstlane: a `return` under a loaded length makes the loop divergent to the compiler, and a divergent index turns P into 14 VGPRs)
+  const RpClProb P = L.p[__builtin_amdgcn_readfirstlane(L.sum_out ? it : pz)];    // by value: one kernarg round trip
   const int k = P.k, dil = P.dil;
-  const int BT = HT - (k - 1);                    // output rows per tile
+  kdbg = k;
+  const int BT = HT - ((L.sum_out ? L.kmax : k) - 1);   // output rows per tile (hand-over: the widest branch's, so every branch has the same tiles)
   // consecutive time tiles share (k-1)(d+1) halo rows: each XCD gets a contiguous range of them, so the re-read hits ITS L2
   const int vt = per_xcd ? (bx & 7) * per_xcd + (bx >> 3) : bx;
   const int t0 = vt * BT;
@@ -63,7 +73,7 @@ respair_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   int Lin = L.L;
   if (L.lens) {                                   // exact lengths: this batch item ends at lens[b]*len_mul
     const int64_t lv = L.lens[b] * L.len_mul;
-    Lin = lv < Lin ? (int)lv : Lin;
+    Lin = __builtin_amdgcn_readfirstlane(lv < Lin ? (int)lv : Lin);
     if (t0 >= Lin) return;                        // a tile wholly past the utterance: nobody reads its outputs
   }
   const int p2 = (k - 1) / 2, p1 = p2 * dil;
@@ -170,7 +180,7 @@ respair_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   }
   __syncthreads();
   {
-    uint16_t* og = P.out + (int64_t)b * bstride + (int64_t)t0 * C;
+    uint16_t* og = (L.sum_out ? L.sum_out : P.out) + (int64_t)b * bstride + (int64_t)t0 * C;
     u32x4 ov[EPI_PIECES];
 #pragma unroll
     for (int i = 0; i < EPI_PIECES; ++i) {        // all LDS reads first, then all stores
@@ -179,19 +189,41 @@ respair_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
       const int r = p / PPR, c = p - r * PPR;
       ov[i] = *reinterpret_cast<const u32x4*>(xs + r * OP + c * 8);
     }
+    if (it > 0) {
+      // hand-over: the running sum of the branches before this one — the very pieces THIS thread stored an iteration ago (same piece ->
+      // same thread in every iteration), read back from L2 — plus this branch, rounded as cl_bf16.h stage_mean says.  Four pieces at a time:
+      // with all of them in flight next to ov[] the kernel spilled
+      const bool lastb = it + 1 == nit;
+      const float sc = L.sum_scale;
+#pragma unroll
+      for (int i0 = 0; i0 < EPI_PIECES; i0 += 4) {
+        u32x4 pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int p = tid + (i0 + i) * NT;
+          p = p < npc ? p : npc - 1;
+          if (i0 + i < EPI_PIECES) pv[i] = *reinterpret_cast<const u32x4*>(og + p * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i0 + i < EPI_PIECES) ov[i0 + i] = stage_accum(ov[i0 + i], pv[i], lastb, sc);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < EPI_PIECES; ++i) {
       const int p = tid + i * NT;
       if (p < npc) *reinterpret_cast<u32x4*>(og + p * 8) = ov[i];
     }
   }
-  if (L.dbg && tid == 0) {
+  if (it + 1 < nit) __syncthreads();              // the next branch stages its x tile over this output tile
+  }
+  if (L.dbg && threadIdx.x == 0) {
     __builtin_amdgcn_s_waitcnt(0);
     unsigned long long* d = L.dbg + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
     d[0] = ts0; d[1] = ts1; d[2] = ts3; d[3] = __builtin_amdgcn_s_memtime();
     d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
     d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    d[6] = (unsigned long long)k | ((ts2 - ts1) << 16);           // taps | ticks of conv1's GEMM
+    d[6] = (unsigned long long)kdbg | ((ts2 - ts1) << 16);        // taps | ticks of conv1's GEMM
     d[7] = 1;
   }
 }
@@ -356,7 +388,7 @@ __device__ __forceinline__ void rp2_run(f32x16 (&acc)[2][4], bf16x8 (&ar)[RP2_RS
 
 }  // namespace
 
-template <int WN, int WM, int G>
+template <int WN, int WM, int G, bool SUM>         // SUM: the stage hand-over form (L.sum_out), a kernel of its own so that the plain form keeps its registers
 __global__ void __launch_bounds__(64 * WN * WM, WN * WM <= 4 ? 2 : 1)
 respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   constexpr int NT = 64 * WN * WM;
@@ -368,20 +400,27 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   static_assert(WN * 64 == C, "the workgroup owns every channel");
   extern __shared__ __attribute__((aligned(16))) unsigned char xsb[];
   int bx = blockIdx.x, pz = blockIdx.z;
-  if (mix) {
+  if (!SUM && mix) {
     const int q = bx >> 3;
     pz = q % mix;
     bx = ((q / mix) << 3) | (bx & 7);
   }
-  const RpClProb P = L.p[pz];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int nit = SUM ? L.nprob : 1;             // stage hand-over: see the first form
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+  const bool dbg = !SUM && L.dbg != nullptr;     // (no timeline in the hand-over form: its stamps cost the scalar registers the loop needs)
+  if (dbg) ts0 = __builtin_amdgcn_s_memtime();
+  int kdbg = 0;
+  for (int it = 0; it < nit; ++it) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));                   // per-lane values re-derived inside the loop (see the first form)
+  const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid % WN, wm = wid / WN;
   const unsigned l31 = lane & 31, lh = lane >> 5;
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-  if (L.dbg) ts0 = __builtin_amdgcn_s_memtime();
+  const RpClProb P = L.p[__builtin_amdgcn_readfirstlane(SUM ? it : pz)];
   const int k = P.k, dil = P.dil;
-  const int BT = HT - (k - 1);
+  kdbg = k;
+  const int BT = HT - ((SUM ? L.kmax : k) - 1);
   const int vt = per_xcd ? (bx & 7) * per_xcd + (bx >> 3) : bx;
   const int t0 = vt * BT;
   if (t0 >= L.L) return;
@@ -389,7 +428,7 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   int Lin = L.L;
   if (L.lens) {
     const int64_t lv = L.lens[b] * L.len_mul;
-    Lin = lv < Lin ? (int)lv : Lin;
+    Lin = __builtin_amdgcn_readfirstlane(lv < Lin ? (int)lv : Lin);
     if (t0 >= Lin) return;
   }
   const int p2 = (k - 1) / 2, p1 = p2 * dil;
@@ -403,7 +442,7 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   rp2_prime<NP>(ar, wq, P.w1 + (2 * wn) * mstream, P.w1 + (2 * wn + 1) * mstream, wlane, k);
   rp2_stage<C, NT, 20>(xsb, xg, L.slope, t0 - p2 - p1, HT + (k - 1) * dil, Lin, tid);
   __syncthreads();
-  if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
+  if (dbg) ts1 = __builtin_amdgcn_s_memtime();
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -414,7 +453,7 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
   const unsigned row0 = (unsigned)wm * 128u + l31;
   rp2_run<C>(acc, ar, wq, wlane, k, xsb, row0, dil, lh);
-  if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
+  if (dbg) ts2 = __builtin_amdgcn_s_memtime();
 
   __syncthreads();                                // every wave is done reading the x tile
   {
@@ -452,7 +491,7 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   rp2_prime<NP>(ar, wq, P.w2 + (2 * wn) * mstream, P.w2 + (2 * wn + 1) * mstream, wlane, k);
   __syncthreads();
   rp2_run<C>(acc, ar, wq, wlane, k, xsb, row0, 1, lh);
-  if (L.dbg) ts3 = __builtin_amdgcn_s_memtime();
+  if (dbg) ts3 = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: out = bf16(acc + b2 + x): residual rows L2 -> registers -> LDS (swizzled), fragment add in place, rows back out.
   // The residual goes through in two halves — the first in flight across the barrier, the second behind it — so that at most
@@ -526,28 +565,58 @@ respair2_cl_bf16_kernel(const RpClLaunch L, const int per_xcd, const int mix) {
   }
   __syncthreads();
   {
-    uint16_t* og = P.out + (int64_t)b * bstride + (int64_t)t0 * C;
-    u32x4 ov[EPI_PIECES];
+    // (another opaque copy of the thread index: the residual loads above use the same piece offsets, and kept alive for re-use here — 64-bit
+    // each — they spilled in the hand-over form)
+    int tids = threadIdx.x;
+    asm volatile("" : "+v"(tids));
+    uint16_t* og = (SUM ? L.sum_out : P.out) + (int64_t)b * bstride + (int64_t)t0 * C;
+    if (SUM && it > 0) {
+      // hand-over: running sum (this THREAD's own stores of the previous iteration: same piece -> same thread every iteration, read back
+      // from L2) + this branch, rounded as cl_bf16.h stage_mean says.  Four pieces at a time: all sixteen in flight spilled
+      const bool lastb = it + 1 == nit;
+      const float sc = L.sum_scale;
 #pragma unroll
-    for (int i = 0; i < EPI_PIECES; ++i) {
-      int p = tide + i * NT;
-      p = p < npc ? p : npc - 1;
-      const int r = p / PPR, c = p - r * PPR;
-      ov[i] = *reinterpret_cast<const u32x4*>(xsb + rp2_addr<C>((unsigned)r, (unsigned)c));
-    }
+      for (int i0 = 0; i0 < EPI_PIECES; i0 += 4) {
+        u32x4 pv[4], o4[4];
 #pragma unroll
-    for (int i = 0; i < EPI_PIECES; ++i) {
-      const int p = tide + i * NT;
-      if (p < npc) *reinterpret_cast<u32x4*>(og + p * 8) = ov[i];
+        for (int i = 0; i < 4; ++i) {
+          int p = tids + (i0 + i) * NT;
+          p = p < npc ? p : npc - 1;
+          pv[i] = *reinterpret_cast<const u32x4*>(og + p * 8);
+          const int r = p / PPR, c = p - r * PPR;
+          o4[i] = *reinterpret_cast<const u32x4*>(xsb + rp2_addr<C>((unsigned)r, (unsigned)c));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = tids + (i0 + i) * NT;
+          if (p < npc) *reinterpret_cast<u32x4*>(og + p * 8) = stage_accum(o4[i], pv[i], lastb, sc);
+        }
+      }
+    } else {
+      u32x4 ov[EPI_PIECES];
+#pragma unroll
+      for (int i = 0; i < EPI_PIECES; ++i) {
+        int p = tids + i * NT;
+        p = p < npc ? p : npc - 1;
+        const int r = p / PPR, c = p - r * PPR;
+        ov[i] = *reinterpret_cast<const u32x4*>(xsb + rp2_addr<C>((unsigned)r, (unsigned)c));
+      }
+#pragma unroll
+      for (int i = 0; i < EPI_PIECES; ++i) {
+        const int p = tids + i * NT;
+        if (p < npc) *reinterpret_cast<u32x4*>(og + p * 8) = ov[i];
+      }
     }
   }
-  if (L.dbg && tid == 0) {
+  if (SUM && it + 1 < nit) __syncthreads();              // the next branch stages its x tile over this output tile
+  }
+  if (dbg && threadIdx.x == 0) {
     __builtin_amdgcn_s_waitcnt(0);
     unsigned long long* d = L.dbg + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
     d[0] = ts0; d[1] = ts1; d[2] = ts3; d[3] = __builtin_amdgcn_s_memtime();
     d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
     d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    d[6] = (unsigned long long)k | ((ts2 - ts1) << 16);
+    d[6] = (unsigned long long)kdbg | ((ts2 - ts1) << 16);
     d[7] = 1;
   }
 }
@@ -566,8 +635,10 @@ template <int WN, int WM, int NI, int G>
 static int launch_rp(hipStream_t stream, const RpClLaunch& L0) {
   constexpr int HT = WM * NI * 32, C = 16 * G;
   int ntx = 0, extra = 0;
+  int kmax = 0;
+  for (int i = 0; i < L0.nprob; ++i) kmax = L0.p[i].k > kmax ? L0.p[i].k : kmax;
   for (int i = 0; i < L0.nprob; ++i) {
-    const int BT = HT - (L0.p[i].k - 1);
+    const int BT = HT - ((L0.sum_out ? kmax : L0.p[i].k) - 1);
     const int n = (L0.L + BT - 1) / BT;
     ntx = n > ntx ? n : ntx;
     const int e = (L0.p[i].k - 1) * L0.p[i].dil;
@@ -575,12 +646,13 @@ static int launch_rp(hipStream_t stream, const RpClLaunch& L0) {
   }
   const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
   const size_t lds = (size_t)(HT + extra) * (C + 8) * 2;
-  const int mix = (per_xcd && L0.nprob > 1 && L0.mix) ? L0.nprob : 0;
-  dim3 grid(per_xcd ? per_xcd * 8 : ntx, L0.B, L0.nprob);
+  const int mix = (per_xcd && L0.nprob > 1 && L0.mix && !L0.sum_out) ? L0.nprob : 0;
+  dim3 grid(per_xcd ? per_xcd * 8 : ntx, L0.B, L0.sum_out ? 1 : L0.nprob);
   if (mix) grid = dim3(per_xcd * 8 * L0.nprob, L0.B, 1);
   auto kern = respair_cl_bf16_kernel<WN, WM, NI, G>;
   ensure_dyn_lds((const void*)kern, lds);
   RpClLaunch Lt = L0;
+  Lt.kmax = kmax; Lt.sum_scale = 1.f / (float)L0.nprob;
   if (Lt.dbg == nullptr) {
     int ks = 0;
     for (int i = 0; i < L0.nprob && i < 3; ++i) ks |= (L0.p[i].k & 255) << (8 * i);
@@ -594,8 +666,10 @@ template <int WN, int WM, int G>
 static int launch_rp2(hipStream_t stream, const RpClLaunch& L0) {
   constexpr int HT = WM * 128, C = 16 * G;
   int ntx = 0, extra = 0;
+  int kmax = 0;
+  for (int i = 0; i < L0.nprob; ++i) kmax = L0.p[i].k > kmax ? L0.p[i].k : kmax;
   for (int i = 0; i < L0.nprob; ++i) {
-    const int BT = HT - (L0.p[i].k - 1);
+    const int BT = HT - ((L0.sum_out ? kmax : L0.p[i].k) - 1);
     const int n = (L0.L + BT - 1) / BT;
     ntx = n > ntx ? n : ntx;
     const int e = (L0.p[i].k - 1) * L0.p[i].dil;
@@ -603,12 +677,13 @@ static int launch_rp2(hipStream_t stream, const RpClLaunch& L0) {
   }
   const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
   const size_t lds = (size_t)(HT + extra) * C * 2;
-  const int mix = (per_xcd && L0.nprob > 1 && L0.mix) ? L0.nprob : 0;
-  dim3 grid(per_xcd ? per_xcd * 8 : ntx, L0.B, L0.nprob);
+  const int mix = (per_xcd && L0.nprob > 1 && L0.mix && !L0.sum_out) ? L0.nprob : 0;
+  dim3 grid(per_xcd ? per_xcd * 8 : ntx, L0.B, L0.sum_out ? 1 : L0.nprob);
   if (mix) grid = dim3(per_xcd * 8 * L0.nprob, L0.B, 1);
-  auto kern = respair2_cl_bf16_kernel<WN, WM, G>;
+  auto kern = L0.sum_out ? respair2_cl_bf16_kernel<WN, WM, G, true> : respair2_cl_bf16_kernel<WN, WM, G, false>;
   ensure_dyn_lds((const void*)kern, lds);
   RpClLaunch Lt = L0;
+  Lt.kmax = kmax; Lt.sum_scale = 1.f / (float)L0.nprob;
   if (Lt.dbg == nullptr) {
     int ks = 0;
     for (int i = 0; i < L0.nprob && i < 3; ++i) ks |= (L0.p[i].k & 255) << (8 * i);
@@ -622,7 +697,8 @@ int launch_respair_cl_bf16(hipStream_t stream, const RpClLaunch& L, const char**
   if (L.nprob < 1 || L.nprob > 3 || L.B < 1 || L.L < 1) return -1;
   for (int i = 0; i < L.nprob; ++i) {
     const RpClProb& p = L.p[i];
-    if (!respair_cl_bf16_supported(L.C, p.k, p.dil) || !p.x || !p.out || p.x == p.out || !p.w1 || !p.w2 || !p.b1 || !p.b2) return -1;
+    if (!respair_cl_bf16_supported(L.C, p.k, p.dil) || !p.x || !p.w1 || !p.w2 || !p.b1 || !p.b2) return -1;
+    if (L.sum_out ? p.x == L.sum_out : (!p.out || p.x == p.out)) return -1;
   }
   if (L.form >= 1 && L.C >= 64) {
     switch (L.C) {
@@ -661,9 +737,10 @@ double respair_cl_bf16_flops(const RpClLaunch& L) {   // both convs, no halo rec
   return f;
 }
 
-double respair_cl_bf16_bytes(const RpClLaunch& L) {   // x read once, out written once, both weight sets once
+double respair_cl_bf16_bytes(const RpClLaunch& L) {   // x read once, out written once (hand-over: ONE output for all branches), both weight sets once
   double by = 0;
-  for (int i = 0; i < L.nprob; ++i) by += 2.0 * (2.0 * L.C * (double)L.L * L.B + 2.0 * L.C * L.C * L.p[i].k);
+  for (int i = 0; i < L.nprob; ++i)
+    by += 2.0 * ((L.sum_out && i ? 1.0 : 2.0) * L.C * (double)L.L * L.B + 2.0 * L.C * L.C * L.p[i].k);
   return by;
 }
 

@@ -403,8 +403,9 @@ def generator(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
 # Generator with bf16 storage / fp32 accumulation (BASELINE config 3).  The reference's counterpart is running `dec`
 # under torch.autocast(bfloat16); this restatement pins the rounding points of the bf16 product path so parity can be
 # held tightly: weights, (z*mask) and every stored activation are rounded to bf16 (round-to-nearest-even), each conv
-# input is bf16(leaky_relu(.)) (for the upsampling convs: bf16(leaky_relu(mean of the branches)), mean = fp32 sum of the
-# bf16 branch outputs times fp32(1/n)), accumulation + bias + residual are fp32, conv_post/tanh are fp32 on bf16 inputs.
+# input is bf16(leaky_relu(.)), accumulation + bias + residual are fp32, conv_post/tanh are fp32 on bf16 inputs.  A stage's output — the
+# mean of its n branch outputs r_j (models.py:545-552) — is ONE bf16 tensor since round 6 (the stage hand-over, kernels/cl_bf16.h stage_mean):
+# the branches are summed widest kernel first with the running sum stored as bf16, mean = bf16((bf16(r_{n-1} + r_{n-2}) + ... + r_0) * fp32(1/n)).
 
 def _bf(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
@@ -428,6 +429,17 @@ def resblock2_bf16(sd, p, x, k, dilations, fold_cache=None):
     return x
 
 
+def stage_mean_bf16(rs, inv):
+    """The stage hand-over's rounding points (kernels/cl_bf16.h stage_mean / stage_accum): branches summed last (widest kernel) first, the
+    running sum stored as bf16 between branches, the mean rounded once more."""
+    if len(rs) == 1:
+        return rs[0]
+    s = rs[-1]
+    for r in rs[-2:0:-1]:
+        s = _bf(s + r)
+    return _bf((s + rs[0]) * inv)
+
+
 def generator_bf16(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
     x = _bf(F.conv1d(_bf(z), _bf(sd["dec.conv_pre.weight"]), sd["dec.conv_pre.bias"], padding=3) + conv1x1(sd, "dec.cond", g))
     nk = len(hp.resblock_kernel_sizes)
@@ -438,12 +450,11 @@ def generator_bf16(sd, hp, z, g, fold_cache=None, taps: Optional[dict] = None):
                                    stride=u, padding=(k - u) // 2))
         if taps is not None:
             taps[f"dec.ups.{i}"] = x
-        xs = None
+        rs = []
         for j in range(nk):
             rb = resblock2_bf16 if str(getattr(hp, "resblock", "1")) == "2" else resblock1_bf16
-            r = rb(sd, f"dec.resblocks.{i * nk + j}", x, hp.resblock_kernel_sizes[j], hp.resblock_dilation_sizes[j], fold_cache)
-            xs = r if xs is None else xs + r
-        x = xs * inv if nk > 1 else xs
+            rs.append(rb(sd, f"dec.resblocks.{i * nk + j}", x, hp.resblock_kernel_sizes[j], hp.resblock_dilation_sizes[j], fold_cache))
+        x = stage_mean_bf16(rs, inv)
         if taps is not None:
             taps[f"dec.stage.{i}"] = x
     x = F.leaky_relu(x)                                                 # default slope 0.01 (models.py:553), fp32

@@ -66,11 +66,11 @@ def test_conv_cl_bf16_kernel(B, cin, cout, k, dil, L, nsrc, lrelu, res, bias2, p
     r = bf(torch.randn(B, cout, L, generator=g)) if res else None
     # reference with the kernel's rounding points (bv2_kernels.h ClProb)
     xin = xs[0]
-    if nsrc > 1:
-        acc = xs[0].clone()
-        for t in xs[1:]:
-            acc = acc + t
-        xin = acc * torch.tensor(1.0 / nsrc, dtype=torch.float32)
+    if nsrc > 1:                                   # the stage hand-over's rounding points (kernels/cl_bf16.h stage_mean): widest branch first, running sum in bf16
+        acc = xs[-1]
+        for t in xs[-2:0:-1]:
+            acc = bf(acc + t)
+        xin = bf((acc + xs[0]) * torch.tensor(1.0 / nsrc, dtype=torch.float32))
     if lrelu:
         xin = torch.where(xin < 0, xin * torch.tensor(0.1, dtype=torch.float32), xin)
     if lrelu or nsrc > 1:
