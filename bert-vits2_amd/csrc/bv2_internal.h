@@ -137,7 +137,11 @@ struct bv2_handle {
   bool no_f16_ksplit = false;        // "f16_ksplit" = 0: the fp16 FFN conv_2 (768 -> 192 rows, 64-column tiles) as 6 waves over three staged chunks instead of 12 waves on K halves of one tile
   bool no_conv_post_rows = false;    // "conv_post_rows" = 0: the bf16 path's conv_post + tanh on the any-width kernel also at C = 16 (default: the row-wise kernel, gen_bf16.hip)
   bool no_ups_phase_taps = false;    // "ups_phase_taps" = 0: the bf16 ConvTranspose1d launches multiply through the zero taps of the union window (A/B and bit-identity tests)
-  bool no_stage_sum = false;         // "stage_sum" = 0: every bf16 Generator stage hands its n branch tensors to the next launch, which forms the mean (default: the stage's last ResBlock launch writes ONE tensor, the mean)
+  bool no_stage_sum = true;          // "stage_sum" = 1: the launch that finishes a bf16 Generator stage writes ONE tensor, the branch mean (default 0: the n branch tensors are handed over and
+  // the next launch forms the mean).  Measured round 6 (profiles/r06_ab_stage_sum.txt, r06_fam_stage_sum.txt, B = 32): the consumers gain 228 us per step (four
+  // ConvTranspose1d launches read 1/3 of the bytes), the producers lose 346 us — a workgroup that runs three branches back to back lives 3x as long (tail rounds of
+  // a 416-workgroup grid, no k = 11 / k = 3 tiles side by side on a CU any more), every branch pays the widest branch's halo, the running sum is re-read through L2:
+  // 14.65 vs 14.66-14.72 ms at config 3, 15.7-15.9 vs 15.6 at config 5.  Bit-identical either way (tests/test_stage_sum_gpu.py).
   bool no_resblock_c16 = false;      // "resblock_c16" = 0: the C = 16 bf16 stage on the 32x32x16 whole-ResBlock kernel (resblock_cl_bf16.hip) instead of resblock_c16_bf16.hip
   bool no_respair_c32 = false;       // "respair_c32" = 0: the C = 32 bf16 stage as whole-ResBlock launches (resblock_cl_bf16.hip) instead of pair by pair
   int respair_form = 1;              // "respair_form": 1 = 64 x 128 wave tiles (respair2_cl_bf16_kernel), 0 = 32-channel waves

@@ -267,7 +267,7 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "fused_respair"   the wide bf16 Generator stages (C = 64 / 128 / 256) one (dilated conv, conv) ResBlock pair per launch, the
  *                     intermediate in LDS (kernels/respair_cl_bf16.hip; bit-identical to the layer-wise path); 0: one conv per launch
  *   "respair_c32"     1 (default): also the C = 32 stage pair by pair (one wave owns all channels); 0: whole-ResBlock launches
- *   "stage_sum"       1 (default): the launch that finishes a bf16 Generator stage's ResBlocks (the last pair launch of the wide stages, the whole-ResBlock
+ *   "stage_sum"       0 (default, measured: no gain — what the consumers save the producers lose, see bv2_internal.h); 1: the launch that finishes a bf16 Generator stage's ResBlocks (the last pair launch of the wide stages, the whole-ResBlock
  *                     launch at C = 16) runs the stage's n branches tile by tile in one workgroup and writes ONE tensor — the branch mean of reference
  *                     models.py:545-552 (`xs / self.num_kernels`) — so the next ConvTranspose1d / conv_post reads one tensor instead of n; 0: n
  *                     tensors, the consumer forms the mean.  Same rounding points either way (kernels/cl_bf16.h stage_mean): bit-identical results

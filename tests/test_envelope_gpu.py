@@ -114,7 +114,8 @@ def test_envelope_graph_replay_is_bit_identical_to_eager(name, reduced):
 # the same models where B*T and B*T_y are past the split-K regime (every encoder / flow convolution on the LDS-tiled kernels, attention and
 # LayerNorm with B > 1, the Generator's wide tiles): no golden (a fixture of that size is MBs) — the oracle, which the goldens above pin for
 # exactly these hyper-parameters, is the checker
-@pytest.mark.parametrize("name", ENV)
+# (six of the twelve: hidden 128 / 192 / 256, both flows, odd and even coupling counts, ResBlock1 / 2, 3-5 stages — the GPU suite has a time limit)
+@pytest.mark.parametrize("name", ["hp01_tf3_h128x4", "hp03_tf2_h256x8_rb2", "hp04_tf5_h192x6", "hp06_wn3_h128x2", "hp07_wn4_h256x4_rb2", "hp09_wn5_h256x2"])
 def test_envelope_at_a_tiled_batch_vs_oracle(name):
     from bert_vits2_amd import synth
     hp, seed, *_ = cases.build_case(name)
