@@ -133,6 +133,7 @@ struct Ctx {
     if (rc) return;
     HcLaunch hl;
     hl.p[0] = p; hl.nprob = 1; hl.B = B; hl.L = L; hl.xcd_b = xcd ? 1 : 0; hl.no_ksplit = h->no_f16_ksplit ? 1 : 0;
+    hl.wn_pref = h->f16_wn; hl.ni_pref = h->f16_ni;
     if (p2) { hl.p[1] = *p2; hl.nprob = 2; }
     const char* vn = "conv_f16";
     const int pi = prof_begin(tag);

@@ -367,6 +367,8 @@ bool conv_f16_ln_supported(int cout);
 // coherent: a tile produced on another XCD comes back through the fabric).  Same switch in LnArgs / AttnArgs; see xcd_decode.
 struct HcLaunch { HcProb p[2]; int nprob = 1; int B, L; unsigned long long* dbg = nullptr;   // dbg: tools/timeline.py only
                   int no_ksplit = 0;                 // 1: the FFN conv_2 shape without the in-workgroup K split ("f16_ksplit" = 0)
+                  int wn_pref = 0;                   // tuning ("f16_wn"): 4 / 6 / 8 = that many waves per workgroup when it wastes no more wave slots than the default choice
+                  int ni_pref = 0;                   // tuning ("f16_ni"): 2 / 4 = 64 / 128 time steps per workgroup
                   int xcd_b = 0; int xcd_gx = 0, xcd_per = 0; };    // xcd_gx / xcd_per: filled by the launcher
 int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_name);
 void conv_f16_set_tuning(int generic);                       // tests / tuning only (bv2_test_set_variants)

@@ -639,11 +639,12 @@ int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_
   const int cand[3] = {8, 6, 4};
   for (int c : cand) {
     const int waste = (nt + c - 1) / c * c - nt;
-    if (waste < best) { best = waste; wn = c; }
+    if (waste < best || (waste == best && c == L.wn_pref)) { best = waste; wn = c; }
   }
   // time steps per workgroup: 128 when that still gives every CU a workgroup, else 64
   const long wg128 = (long)((L.L + 127) / 128) * L.B * ((nt + wn - 1) / wn);
   int ni = wg128 >= 256 ? 4 : 2;
+  if (L.ni_pref == 2 || L.ni_pref == 4) ni = L.ni_pref;
   {
     const int ck = p.cin < HC_CK ? p.cin : HC_CK;
     if ((int64_t)(128 + (p.k - 1) * p.dil) * (ck + 8) * 2 > 160 * 1024) ni = 2;
