@@ -458,7 +458,7 @@ def encoder_gemms_block(rows, psteps, config):
     fam = {}
     for r in rows:
         site, _, rest = r["name"].partition("|")
-        if not site.startswith("enc.") or not r["launches"]:
+        if not (site.startswith("enc.") or site == "attention") or not r["launches"]:      # the attention core sits between q/k/v and conv_o
             continue
         name = rest.split(" n")[0]
         f = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
@@ -474,7 +474,7 @@ def encoder_gemms_block(rows, psteps, config):
             continue
     out = []
     for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
-        peak = PEAK_BF16_MFMA_TFLOPS if "f16" in name else PEAK_FP32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if ("f16" in name or (name.startswith("attention") and config != 2)) else PEAK_FP32_MFMA_TFLOPS
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
         key = "conv1d_splitk<32x32>" if name.startswith("conv1d_splitk") else name.split("<")[0] if name.startswith("conv_f16") else name
         pk = pmc.get(name) or pmc.get(key) or next((v for k, v in pmc.items() if k.startswith(key)), None)

@@ -414,6 +414,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "respair_c32") h->no_respair_c32 = value == 0;
   else if (k == "f16_wn") h->f16_wn = value;
   else if (k == "f16_ni") h->f16_ni = value;
+  else if (k == "f16_kv") h->no_f16_kv = !value;
   else if (k == "stage_sum") h->no_stage_sum = !value;
   else if (k == "resblock_c16") h->no_resblock_c16 = value == 0;
   else if (k == "f16_fused_ln") h->no_f16_fused_ln = value == 0;

@@ -160,7 +160,7 @@ struct Ctx {
 //   f   = relu(conv_k(x*mask))            (MFMA, input mask + ReLU fused)
 //   s   = conv_k(f*mask)*mask + x         (MFMA, masks + residual fused)
 //   x   = LN2(s) [ + spk, *mask when the NEXT layer is the conditioning layer; *mask after the last layer ]
-struct EncBufs { float *x, *s, *att, *qkv, *f1, *ml; int64_t slab; };   // s holds kSlabs slabs of `slab` floats; ml: key-split (max, sum) pairs
+struct EncBufs { float *x, *s, *att, *qkv, *f1, *ml; int64_t slab; uint16_t *k16 = nullptr, *v16 = nullptr; };   // k16 / v16: fp16 K / V of the fp16 stacks (attention.hip KV16)   // s holds kSlabs slabs of `slab` floats; ml: key-split (max, sum) pairs
 
 constexpr int kSlabs = BV2_MAX_KSPLIT;
 inline int attn_ld(int T) { return (T + 31) / 32 * 32; }
@@ -180,9 +180,11 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     bool ln2_in_conv = false;
     ConvProb p = c.prob(L.qkv, b.x, b.qkv, T);
     p.out_rstride = ld; p.out_bstride = (int64_t)R * ld;      // rows padded to 32 columns: aligned tile loads
+    const bool kv16 = f16 && b.k16 && b.v16 && !c.h->no_f16_kv && H % 32 == 0;
     if (f16) {
       HcProb q = c.hprob(L.qkv, b.x, true, b.qkv, true, T);
       q.out_rstride = ld; q.out_bstride = (int64_t)R * ld;
+      if (kv16) { q.k16 = b.k16; q.v16 = b.v16; q.kv_row0 = H; q.kv_rows = H; q.k16_ld = ld; }   // K / V rows as fp16 in the attention kernel's layouts
       c.conv_h(q, B, T, "enc.qkv", nullptr, xcd);
     } else {
       c.conv1(p, B, T, "enc.qkv");
@@ -190,6 +192,7 @@ void run_encoder(Ctx& c, const EncoderW& e, const EncBufs& b, const float* mask,
     AttnArgs a;
     a.qkv = b.qkv; a.ld = ld; a.mask = mask; a.erv = c.W(L.erv.off); a.out = b.att;
     a.B = B; a.H = e.heads; a.D = H / e.heads; a.T = T; a.W = kAttnWindow; a.f16 = f16 ? 1 : 0; a.xcd_b = xcd ? 1 : 0;
+    if (kv16) { a.kh = b.k16; a.vh = b.v16; }
     // small-N regime (the one where `s` holds partial slabs): conv_o runs inside the attention kernel, head h -> slab h
     const bool fuse_o = !f16 && !c.h->no_fused_attn_o && n_slabs(B, T) >= e.heads && L.o.k == 1 && L.o.cin == H;
     // key split (batch 1, long sequences): the key tiles of a (head, query tile) go to `ks` workgroups, each writing its own partial
@@ -429,6 +432,8 @@ PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
     p.enc.qkv = A.get<float>((int64_t)B * qkv_rows(m.coupling[0].enc) * attn_ld(Ty));
     p.enc.f1 = A.get<float>(BT * c.filter_channels);
     p.enc.ml = n_slabs(B, Ty) > 1 ? A.get<float>((int64_t)B * kSlabs * 2 * Ty) : nullptr;
+    p.enc.k16 = A.get<uint16_t>((int64_t)B * attn_ld(Ty) * H);
+    p.enc.v16 = A.get<uint16_t>((int64_t)B * attn_ld(Ty) * H);
   } else {
     p.acts = A.get<float>(BT * H);
     p.outacc = A.get<float>(BT * H);

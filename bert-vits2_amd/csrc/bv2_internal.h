@@ -135,6 +135,7 @@ struct bv2_handle {
   bool no_xcd_affine = false;        // "xcd_affine" = 0: plain grids for the fp16 Encoder stacks (default: batch item b on XCD b % 8 when B >= 8 && (B % 8 == 0 || B >= 32), Ctx::xcd_affine)
   bool no_f16_fused_ln = false;      // "f16_fused_ln" = 0: LayerNorm-1 / the plain LayerNorm-2s of the fp16 Encoder stacks as launches of their own instead of in conv_o's / conv_2's epilogue
   int f16_wn = 0, f16_ni = 0;        // "f16_wn" / "f16_ni": tile tuning of the fp16 Encoder convs (HcLaunch wn_pref / ni_pref); 0 = the launcher's choice
+  bool no_f16_kv = false;            // "f16_kv" = 0: the fp16 Encoder stacks' q/k/v projection writes K and V as fp32 rows and the attention kernel rounds them in registers
   bool no_f16_ksplit = false;        // "f16_ksplit" = 0: the fp16 FFN conv_2 (768 -> 192 rows, 64-column tiles) as 6 waves over three staged chunks instead of 12 waves on K halves of one tile
   bool no_conv_post_rows = false;    // "conv_post_rows" = 0: the bf16 path's conv_post + tanh on the any-width kernel also at C = 16 (default: the row-wise kernel, gen_bf16.hip)
   bool no_ups_phase_taps = false;    // "ups_phase_taps" = 0: the bf16 ConvTranspose1d launches multiply through the zero taps of the union window (A/B and bit-identity tests)

@@ -355,6 +355,10 @@ struct HcProb {
   // ln_vec [B][ln_vec_bstride] / ln_mask [B][out_mask_bstride] (each may be null): out = (LayerNorm(...) + ln_vec[b][c]) * ln_mask[b][t]
   const float* ln_gamma; const float* ln_beta; float ln_eps;
   const float* ln_vec; int ln_vec_bstride; const float* ln_mask;
+  // out_ct, no LayerNorm (round 6, the fused q/k/v projection): output rows [kv_row0, kv_row0 + kv_rows) go to k16 as fp16 channels-last
+  // [B][k16_ld][kv_rows] and rows [kv_row0 + kv_rows, kv_row0 + 2 kv_rows) to v16 as fp16 [B][kv_rows][k16_ld] — what attention.hip's KV16 form
+  // reads — instead of `out`; kv_row0 and kv_rows are multiples of 32 (a wave's 32-row tile goes one way or the other).  null = everything to `out`
+  uint16_t* k16; uint16_t* v16; int kv_row0, kv_rows, k16_ld;
 };
 bool conv_f16_ln_supported(int cout);
 // act == ACT_GATE (out_ct = 0 only; WN, reference commons.py:98-105): the weight rows come in gate order (bv2_model.cpp wn_gate_row:
@@ -481,6 +485,9 @@ struct AttnArgs {
   float* out;               // [B][H*D][T]
   int B, H, D, T, W;
   int f16;                  // 1: QK^T and PV on the fp16 matrix core (operands rounded in registers, everything else fp32)
+  // f16 only (round 6): K and V handed over as fp16 by the q/k/v projection (HcProb::k16 / v16) — kh [B][ld][H*D] channels-last, vh [B][H*D][ld];
+  // both or neither.  The k / v rows of `qkv` are then not read (q and the relative-key rows still are).
+  const uint16_t* kh = nullptr; const uint16_t* vh = nullptr;
   // fused output projection (fp32 form only; wo == nullptr: plain attention output in `out`): each head's workgroup multiplies its
   // tile by its K-slice of the packed 1x1 weight `wo` (conv_w_index order, wo_groups = cin_pad / 8) and writes partial slab h of
   // o_out [B][Co][T] (slab h at o_out + h * o_slab_stride; head 0 adds bias `bo` and residual `res` [B][Co][T])

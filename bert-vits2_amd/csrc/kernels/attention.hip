@@ -36,6 +36,8 @@ namespace bv2 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // wave-uniform base (SGPR pair) + 32-bit per-lane BYTE offset: one VGPR per address instead of a 64-bit pair
 __device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
@@ -59,8 +61,14 @@ constexpr int ANS = 4;          // merge slots
 //                             staging loop stores in LDS as fp16 in exactly that order (one ds_read_b128 per step);
 //   O^T step s (16 keys):     B = the lane's S registers 8s .. 8s+7 (its own D-layout rows), A = vreg[m][2s], vreg[m][2s+1]
 //                             (the float4s that hold exactly those keys).
-template <int DT, int NW, bool F16, bool ONE>   // D = 32*DT head channels, NW waves; ONE: at most one key tile per wave (no loop)
+// KV16 = true (F16 only, round 6; A.kh / A.vh): K and V arrive as fp16 from the q/k/v projection's epilogue (enc_f16.hip HcProb::k16 / v16) instead of
+// as fp32 rows of `qkv` — K channels-last [B][ld][HD] so that the 8 K-indices of lane (key, lh) at step t are the 16 bytes [16t + 8lh, +8) of the
+// key's row (6 loads of 16 B per key tile at D = 96 instead of 48 dword loads + 48 conversions), V channel-major [B][HD][ld] (the two groups of
+// four consecutive keys a step needs are two 8-byte loads: half the bytes of the fp32 float4s).  The values are the same fp16 numbers (the
+// rounding moved from this kernel's registers to the projection's epilogue); only the K-index <-> channel assignment of the S^T MFMAs differs.
+template <int DT, int NW, bool F16, bool ONE, bool KV16 = false>   // D = 32*DT head channels, NW waves; ONE: at most one key tile per wave (no loop)
 __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
+  static_assert(!KV16 || F16, "fp16 K / V only feed the fp16 matrix products");
   constexpr int D = 32 * DT;
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -105,22 +113,44 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 
   // ---- everything this wave's first key tile needs goes in flight at once (one memory round trip):
   //      K tile -> D/2 registers + key mask now; the V tile (D/8 float4) is issued as soon as the K registers are consumed
-  float kreg[D / 2];
-  f32x4 vreg[DT][4];
+  float kreg[KV16 ? 1 : D / 2];
+  f32x4 vreg[KV16 ? 1 : DT][4];
+  u32x4 kq[KV16 ? D / 16 : 1];                      // KV16: step t's 8 K-indices of this lane's key, packed fp16
+  u32x2 vq[KV16 ? DT : 1][2][2];                    // KV16: [m][step][keys ja.. / ja+8..] of channel m*32 + l31, packed fp16
+  const uint16_t* const khp = KV16 ? A.kh + (int64_t)b * ld * HD + h * D : nullptr;
+  const uint16_t* const vhp = KV16 ? A.vh + ((int64_t)b * HD + h * D) * ld : nullptr;
   float mkey = 0.f;
   const unsigned koff = 4u * (unsigned)(lh * ld + l31);         // per-lane byte offsets, shared by every load of a tile
   const unsigned voff = 4u * (unsigned)(l31 * ld + 4 * lh);
   auto issue_k = [&](int j0) __attribute__((always_inline)) {
+    if constexpr (KV16) {
+      const uint16_t* kr_ = khp + (int64_t)(j0 + l31) * HD + 8 * lh;     // rows up to ld exist (ld = T rounded up to 32)
+#pragma unroll
+      for (int t = 0; t < D / 16; ++t) kq[t] = *reinterpret_cast<const u32x4*>(kr_ + 16 * t);
+    } else {
 #pragma unroll
     for (int s = 0; s < D / 2; ++s) kreg[s] = ld_off(kp, koff + 4u * (unsigned)(j0 + 2 * s * ld));
+    }
     const int jm = j0 + l31;
     mkey = mp[jm < T ? jm : T - 1];
   };
   auto issue_v = [&](int j0) __attribute__((always_inline)) {
+    if constexpr (KV16) {
+#pragma unroll
+      for (int m = 0; m < DT; ++m) {
+        const uint16_t* vr_ = vhp + (int64_t)(m * 32 + l31) * ld + j0 + 4 * lh;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          vq[m][s2][0] = *reinterpret_cast<const u32x2*>(vr_ + 16 * s2);
+          vq[m][s2][1] = *reinterpret_cast<const u32x2*>(vr_ + 16 * s2 + 8);
+        }
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < DT; ++m)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) vreg[m][g4] = ld_off4(vp, voff + 4u * (unsigned)((m * 32) * ld + j0 + 8 * g4));
+    }
   };
   const bool have_tile = wid < ntiles;
   if (have_tile) {
@@ -176,7 +206,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       const int e = tid + q * NT;
       if (e >= D * AQ) continue;
       const int c = e >> 5, i = e & 31;
-      if (F16) {
+      if (F16 && KV16) {
+        Qh[i * QP + c] = (_Float16)((i0 + i < T) ? qv[q] : 0.f);       // natural order: K-index 16t + 8lh + e is channel 16t + 8lh + e
+      } else if (F16) {
         const int h2 = c & 1, u = c >> 1;           // c = 2u + lh, u = 8t + e
         Qh[i * QP + (u >> 3) * 16 + h2 * 8 + (u & 7)] = (_Float16)((i0 + i < T) ? qv[q] : 0.f);
       } else {
@@ -210,8 +242,12 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
 #pragma unroll
       for (int t = 0; t < D / 16; ++t) {
         f16x8 ka;
+        if constexpr (KV16) {
+          ka = __builtin_bit_cast(f16x8, kq[t]);
+        } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) ka[e] = (_Float16)kreg[8 * t + e];
+        }
         const f16x8 qf = *reinterpret_cast<const f16x8*>(Qh + l31 * QP + t * 16 + lh * 8);
         S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf, S, 0, 0, 0);
       }
@@ -285,8 +321,18 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
       for (int m = 0; m < DT; ++m) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          f32x4 va = vreg[m][2 * s2], vb = vreg[m][2 * s2 + 1];
           const int ja = j0 + 16 * s2 + 4 * lh, jb2 = ja + 8;
+          if constexpr (KV16) {
+            f16x8 vf = __builtin_bit_cast(f16x8, u32x4{vq[m][s2][0].x, vq[m][s2][0].y, vq[m][s2][1].x, vq[m][s2][1].y});
+            if (jb2 + 3 >= T) {                               // tile tail: keys that do not exist contribute exactly 0 (their slots hold garbage)
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if ((e < 4 ? ja + e : jb2 + e - 4) >= T) vf[e] = (_Float16)0.f;
+            }
+            O[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], O[m], 0, 0, 0);
+            continue;
+          }
+          f32x4 va = vreg[m][2 * s2], vb = vreg[m][2 * s2 + 1];
           if (jb2 + 3 >= T) {                                 // tile tail: keys that do not exist contribute exactly 0
             va.x = ja + 0 < T ? va.x : 0.f; va.y = ja + 1 < T ? va.y : 0.f; va.z = ja + 2 < T ? va.z : 0.f; va.w = ja + 3 < T ? va.w : 0.f;
             vb.x = jb2 + 0 < T ? vb.x : 0.f; vb.y = jb2 + 1 < T ? vb.y : 0.f; vb.z = jb2 + 2 < T ? vb.z : 0.f; vb.w = jb2 + 3 < T ? vb.w : 0.f;
@@ -508,10 +554,10 @@ static size_t attn_lds_bytes(int D, int NW) {
   return sizeof(float) * (size_t)(ANS * D * AQ + D * AQ + (2 * AMAXW + 1) * D + 2 * (2 * AMAXW + 1) * AQ + 2 * NW * AQ);
 }
 
-template <int DT, int NW, bool F16, bool ONE>
+template <int DT, int NW, bool F16, bool ONE, bool KV16 = false>
 static int launch_attn_variant2(hipStream_t stream, const AttnArgs& a, dim3 grid) {
   const size_t lds = attn_lds_bytes(32 * DT, NW);
-  auto kern = attention_kernel<DT, NW, F16, ONE>;
+  auto kern = attention_kernel<DT, NW, F16, ONE, KV16>;
   ensure_dyn_lds((const void*)kern, lds);
   AttnArgs at = a;
   if (a.xcd_b) {
@@ -525,6 +571,7 @@ static int launch_attn_variant2(hipStream_t stream, const AttnArgs& a, dim3 grid
 
 template <int DT, int NW, bool ONE>
 static int launch_attn_variant(hipStream_t stream, const AttnArgs& a, dim3 grid) {
+  if (a.f16 && a.kh && a.vh) return launch_attn_variant2<DT, NW, true, ONE, true>(stream, a, grid);
   return a.f16 ? launch_attn_variant2<DT, NW, true, ONE>(stream, a, grid) : launch_attn_variant2<DT, NW, false, ONE>(stream, a, grid);
 }
 
@@ -543,6 +590,7 @@ static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int n
 
 int launch_attention(hipStream_t stream, const AttnArgs& a) {
   if (a.W > AMAXW || a.W < 0 || a.T < 1 || a.B < 1 || a.H < 1 || a.ld % 32 || a.ld < a.T) return -1;
+  if ((a.kh != nullptr) != (a.vh != nullptr) || (a.kh && !a.f16)) return -1;                  // fp16 K / V: both, and only for the fp16 products
   if (a.wo && (a.f16 || !a.o_out || a.Co < 1 || a.wo_groups * 8 < a.H * a.D)) return -1;   // fused conv_o: fp32 form only
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   const int ntiles_all = (a.T + AK - 1) / AK;

@@ -437,6 +437,39 @@ __global__ void __launch_bounds__(64 * WN * KS) conv_f16_kernel(const HcLaunch L
           outp[(unsigned)co * o_rs + (unsigned)t] = ((acc[ni][r] - mean[ni]) * rstd[ni] * g16[r] + b16[r]) * lm;
         }
       }
+    } else if (P.k16 && mt * 32 >= P.kv_row0 && mt * 32 < P.kv_row0 + 2 * P.kv_rows) {
+      // K / V rows of the fused q/k/v projection: fp16 for attention.hip's KV16 form (wave-uniform branch: a 32-row tile is K or V as a whole).
+      // No activation / residual / mask on these rows (attentions.py:263-266: k = conv_k(c), v = conv_v(c)).
+      const int kr = P.kv_rows, ldk = P.k16_ld;
+      const bool is_k = mt * 32 < P.kv_row0 + kr;
+      const int c0 = mt * 32 - P.kv_row0 - (is_k ? 0 : kr);          // first channel of this tile inside K (or V)
+      if (is_k) {
+        uint16_t* const kp = P.k16 + (int64_t)b * ldk * kr;           // [ld][kv_rows]: this lane's 4 consecutive channels are one 8-byte store
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int t = t0 + ni * 32 + l31;
+          if (t >= Lout) continue;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            u32x2 o;
+            o.x = h_pack(acc[ni][4 * g] + bs[4 * g], acc[ni][4 * g + 1] + bs[4 * g + 1]);
+            o.y = h_pack(acc[ni][4 * g + 2] + bs[4 * g + 2], acc[ni][4 * g + 3] + bs[4 * g + 3]);
+            *reinterpret_cast<u32x2*>(kp + (int64_t)t * kr + c0 + 8 * g + 4 * lh) = o;
+          }
+        }
+      } else {
+        _Float16* const vp = reinterpret_cast<_Float16*>(P.v16) + (int64_t)b * kr * ldk;   // [kv_rows][ld]: 32 lanes = 64 contiguous bytes of a row
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int t = t0 + ni * 32 + l31;
+          if (t >= Lout) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            vp[(unsigned)c * (unsigned)ldk + (unsigned)t] = (_Float16)(acc[ni][r] + bs[r]);
+          }
+        }
+      }
     } else {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -631,6 +664,8 @@ int launch_conv_f16(hipStream_t stream, const HcLaunch& L, const char** variant_
     if (!q.out_ct && (q.res_mode != RES_NONE)) return -1;          // the residual add lives in the fp32 [C][T] epilogue
     if (q.act == ACT_GATE && (q.out_ct || q.cout % 32)) return -1; // the gate writes fp16 channels-last, whole (tanh, sigmoid) tiles
     if (q.bias2 && q.act != ACT_GATE) return -1;                   // the per-batch bias only exists in the gate epilogue
+    if (q.k16 && (!q.v16 || !q.out_ct || q.ln_gamma || q.kv_row0 % 32 || q.kv_rows % 32 || q.kv_rows < 32 || q.k16_ld < L.L ||
+                  q.kv_row0 + 2 * q.kv_rows > q.cout || q.res_mode != RES_NONE || q.act != ACT_NONE || q.out_mask)) return -1;
     if (q.ln_gamma && (!conv_f16_ln_supported(q.cout) || !q.out_ct || !q.ln_beta || q.cout_pad != q.cout || L.nprob != 1)) return -1;
   }
   const int nt = p.cout_pad / 32;

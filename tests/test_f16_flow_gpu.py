@@ -277,3 +277,36 @@ def test_f16_layernorm_in_conv_epilogue_on_and_off(name):
     assert torch.isfinite(zs[1]).all()
     assert e1 < 2e-3 and e0 < 2e-3 and e10 < 2e-3
     assert not torch.equal(zs[1], zs[0])               # the switch really changed the path
+
+
+@pytest.mark.parametrize("name", ["mix_b2_ragged", "narrow_b2_t18", "hp04_tf5_h192x6", "hp03_tf2_h256x8_rb2"])
+def test_f16_kv_handover_on_and_off(name):
+    """Round 6: the fp16 stacks' q/k/v projection writes K (channels-last) and V (channel-major) as fp16 for the attention kernel
+    ("f16_kv", default 1) instead of fp32 rows that the attention kernel rounds in registers.  The SAME fp16 values reach the matrix
+    core; only the K-index <-> channel assignment of the QK^T products differs (fp32 summation order) — z must agree to fp32 round-off
+    of an fp16-operand product, far inside the distance to the fp16 oracle.  Head dims 96 / 64 / 32 x 2-8 heads, ragged lengths, T_y not a
+    multiple of 32 (the K / V tails past T_y hold garbage that must never reach a sum)."""
+    hp, seed, batch, nw, nz, kw = cases.build_case(name)
+    meta, gold = load_golden(name)
+    sd = cached_state_dict(hp, seed)
+    g = torch.nn.functional.embedding(batch["sid"], sd["emb_g.weight"])[:, :, None]
+    m = _gpu_model(hp, seed)
+    m.set_flow_dtype(torch.float16)
+    ym = gold["y_mask"]
+    zs = {}
+    for v in (1, 0):
+        m.set_option("f16_kv", v)
+        # poison the workspace between the runs: stale K / V rows must not be what makes them agree
+        zs[v] = m.stage_flow(gold["z_p"], gold["y_lengths"], g).cpu() * ym
+        torch.cuda.synchronize()
+    m.set_option("f16_kv", 1)
+    with torch.no_grad():
+        z16 = O.flow_reverse(sd, hp, gold["z_p"], ym, g, None, "fp16") * ym
+    d = _relrms(zs[1], zs[0])
+    e1, e0 = _relrms(zs[1], z16), _relrms(zs[0], z16)
+    print(f"\n[{name}] fp16 K/V hand-over on vs off: rel RMS {d:.3e}; vs fp16 oracle {e1:.3e} / {e0:.3e}")
+    assert torch.isfinite(zs[1]).all()
+    # (not 1e-7: an fp32-ulp change of a logit now and then flips the fp16 rounding of a probability or of a conv input downstream, and each flip
+    # is a 5e-4 relative step — the two forms sit ~1e-4 apart, a third of their common distance to the oracle)
+    assert d < 3e-4, d
+    assert e1 < 2e-3 and e0 < 2e-3 and abs(e1 - e0) < 2e-4
