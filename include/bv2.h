@@ -267,6 +267,14 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "fused_respair"   the wide bf16 Generator stages (C = 64 / 128 / 256) one (dilated conv, conv) ResBlock pair per launch, the
  *                     intermediate in LDS (kernels/respair_cl_bf16.hip; bit-identical to the layer-wise path); 0: one conv per launch
  *   "respair_c32"     1 (default): also the C = 32 stage pair by pair (one wave owns all channels); 0: whole-ResBlock launches
+ *   "f16_kv"          1 (default): in the fp16 Encoder stacks the fused q/k/v projection writes K (channels-last) and V (channel-major) as fp16 in the
+ *                     layouts the attention kernel's matrix products consume (kernels/attention.hip KV16: 6 loads of 16 B per key tile instead of 48
+ *                     dword loads + conversions, 80 fewer registers); 0: fp32 rows, rounded to fp16 in the attention kernel's registers.  Same fp16
+ *                     values either way; measured -0.6 us per attention launch at B = 32 and nothing on the projection (profiles/r06_fam_f16_kv.txt)
+ *   "f16_wn"          tile tuning of the fp16 Encoder convs (0 = the launcher's choice): waves per workgroup (4 / 6 / 8, taken when it wastes no more wave
+ *                     slots than the default).  Measured round 6 (profiles/r06_ab_f16_tiles.txt): four-wave workgroups for the FFN conv_1 at B = 32
+ *                     give 14.56 vs 14.62 ms — inside the spread, default unchanged
+ *   "f16_ni"          the same for the time steps per workgroup (2 = 64, 4 = 128; 0 = the launcher's choice)
  *   "stage_sum"       0 (default, measured: no gain — what the consumers save the producers lose, see bv2_internal.h); 1: the launch that finishes a bf16 Generator stage's ResBlocks (the last pair launch of the wide stages, the whole-ResBlock
  *                     launch at C = 16) runs the stage's n branches tile by tile in one workgroup and writes ONE tensor — the branch mean of reference
  *                     models.py:545-552 (`xs / self.num_kernels`) — so the next ConvTranspose1d / conv_post reads one tensor instead of n; 0: n
