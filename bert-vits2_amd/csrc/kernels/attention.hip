@@ -585,7 +585,10 @@ static int launch_attn_d(hipStream_t stream, const AttnArgs& a, dim3 grid, int n
   // in one round even if only 4 have a key tile
   if (ntiles <= 4 && !(a.wo && a.Co > 128)) return launch_attn_variant<DT, 4, true>(stream, a, grid);
   if (ntiles <= 8) return launch_attn_variant<DT, 8, true>(stream, a, grid);
-  return launch_attn_variant<DT, 8, false>(stream, a, grid);
+  // head dim 128 with more than 8 key tiles: four waves walking the tiles (one wave per SIMD: 512 registers each) — the eight-wave loop form
+  // spilled 29 registers there (K tile 64 + V 64 + O 64 + S 16 per wave against 256), and a scratch segment is not allowed on any path
+  if constexpr (DT == 4) return launch_attn_variant<DT, 4, false>(stream, a, grid);
+  else return launch_attn_variant<DT, 8, false>(stream, a, grid);
 }
 
 int launch_attention(hipStream_t stream, const AttnArgs& a) {

@@ -65,8 +65,10 @@ __global__ void __launch_bounds__(64 * NU) dds_layer_kernel(const DdsArgs A) {
   const int T = A.T;
 
   // ---- weights of this wave's 16-row tile: in flight before any activation is touched
+  // (C = 256: 64 weight registers next to the elementwise phase's 60 do not fit the 128 a 16-wave workgroup leaves each lane — 10 spilled; there
+  // the weights are requested after phase 1 instead, at the price of an exposed L2 round trip.  No scratch segment on any accepted model's path.)
   f32x4 wr[NU];
-  load_tile_weights<NU>(A.w, wv, lane, wr);
+  if constexpr (NU <= 12) load_tile_weights<NU>(A.w, wv, lane, wr);
 
   // ---- phase 1: depthwise conv + LN1 + GELU on thread (tl = time step, cg = channel group)
   const int tl = tid & 15, cg = tid >> 4;
@@ -162,6 +164,7 @@ __global__ void __launch_bounds__(64 * NU) dds_layer_kernel(const DdsArgs A) {
   __syncthreads();
 
   // ---- phase 2: 1x1 conv, wave wv -> output rows [16 wv, 16 wv + 16)
+  if constexpr (NU > 12) load_tile_weights<NU>(A.w, wv, lane, wr);
   f32x4 acc = tile_gemm<NU>(wr, ys, lane);
 
   // weights of the optional post projection: loaded now (wr is dead), they land under the LN2 arithmetic

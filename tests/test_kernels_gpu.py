@@ -201,9 +201,22 @@ def _ref_attention(qkv, mask, erk, erv, H, W):
                                       (1, 384, [384]), (2, 250, [250, 129]), (1, 600, [600])])
 @pytest.mark.parametrize("f16", [0, 1])
 def test_attention_relpos(B, T, lens, f16):
+    _attention_case(B, T, lens, f16, 2, 96)
+
+
+# every head dim the envelope accepts (32 / 64 / 96 / 128) with head counts off the released two (round 6: until then only H = 2, D = 96 / 64 ever
+# ran); D = 128 at T > 256 is the four-wave loop form (the eight-wave one spilled), T = 600 the 19-tile loop of every width
+@pytest.mark.parametrize("H,D", [(4, 32), (8, 32), (3, 64), (1, 96), (2, 128), (1, 128)])
+@pytest.mark.parametrize("B,T,lens", [(2, 100, [100, 37]), (1, 300, [300]), (2, 600, [600, 257]), (1, 5, [5])])
+@pytest.mark.parametrize("f16", [0, 1])
+def test_attention_relpos_every_head_dim(H, D, B, T, lens, f16):
+    _attention_case(B, T, lens, f16, H, D)
+
+
+def _attention_case(B, T, lens, f16, H, D):
     lib = _lib()
-    H, D, W = 2, 96, 4
-    g = torch.Generator().manual_seed(T)
+    W = 4
+    g = torch.Generator().manual_seed(T + 7 * H + D)
     qkv = torch.randn(B, 3 * H * D, T, generator=g)
     qkv[:, : H * D] *= 3.0                      # sharpen the softmax a little
     erk, erv = torch.randn(2 * W + 1, D, generator=g) * D ** -0.5, torch.randn(2 * W + 1, D, generator=g) * D ** -0.5

@@ -11,7 +11,7 @@ python tools/collect_pmc.py gpurun_out/${TAG}_pmc_c2.json --lds --traffic profil
 python tools/collect_pmc.py gpurun_out/${TAG}_pmc_c3.json --lds --traffic profiles/${TAG}_traffic_c3.json --config 3 > /dev/null 2> gpurun_out/${TAG}_pmc_c3.err
 python tools/collect_traffic_bert.py profiles/${TAG}_traffic_bert.json > /dev/null 2> gpurun_out/${TAG}_traffic_bert.err
 cp profiles/${TAG}_traffic_c2.json profiles/${TAG}_traffic_c3.json profiles/${TAG}_traffic_bert.json gpurun_out/ 2>/dev/null
-( time python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
+( time python bench.py --details-out gpurun_out/${TAG}_bench_details.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
 for C in 2 3; do
   rm -rf /tmp/prof_c$C
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c$C -o c$C -- python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-secondary --no-cpu-baseline $( [ $C = 3 ] && echo "--config 3" ) > /tmp/b$C.json 2> /tmp/b$C.err )
@@ -20,7 +20,7 @@ for C in 2 3; do
 done
 python - <<PY
 import json
-d = json.load(open("gpurun_out/${TAG}_bench.json"))
+d = json.load(open("gpurun_out/${TAG}_bench_details.json"))
 print("C2", d["value"], d["ms_per_step"], "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "parity", (d.get("parity") or {}).get("wave_rms"))
 for k, v in d["secondary"].items():
     if isinstance(v, dict):

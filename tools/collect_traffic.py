@@ -37,7 +37,7 @@ def family(kname):
         a = [int(v) for v in kname.split("respair_cl_bf16_kernel<")[1].split(">")[0].split(",")]
         return f"respair_cl_bf16<{16 * a[3]}>"
     if "respair2_cl_bf16_kernel<" in kname:     # <WN, WM, G>: the 64 x 128 wave-tile form
-        a = [int(v) for v in kname.split("respair2_cl_bf16_kernel<")[1].split(">")[0].split(",")]
+        a = [int(v) for v in kname.split("respair2_cl_bf16_kernel<")[1].split(">")[0].split(",")[:3]]   # (+ a bool since round 6: the hand-over form)
         return f"respair_cl_bf16<{16 * a[2]},64x128>"
     if "resblock_c16_bf16_kernel" in kname:     # round 5: the C = 16 whole-ResBlock kernel on v_mfma_f32_16x16x32_bf16
         return "resblock_c16_bf16"
