@@ -183,3 +183,26 @@ def test_ty_bucket_keeps_the_seeded_rng_contract_and_reduced_precision():
         m.enable_graphs(False)
         m.set_generator_dtype(torch.float32)
         m.set_flow_dtype(torch.float32)
+
+
+def test_ty_bucket_with_max_len_and_without_attn():
+    """`max_len` (reference models.py:1073: dec sees z[:, :, :max_len]) cuts the Generator below T_y: under a bucket the flow still runs bucket-wide while
+    the Generator keeps the exact cut; `want_attn=False` (serving) leaves the path out of the outputs in both forms."""
+    hp, seed, batch, nw, nz, kw = cases.build_case("mix_b2_ragged")
+    m = _model(hp, seed)
+    args = [batch[k].cuda() for k in ("x", "x_lengths", "sid", "tone", "language", "bert", "ja_bert", "en_bert")]
+    full = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), **kw)
+    Ty = full[2].shape[2]
+    ml = Ty - 7
+    e = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), max_len=ml, want_attn=False, **kw)
+    assert e[0].shape[2] == ml * hp.total_upsample and e[1] is None
+    assert torch.equal(e[0][..., : (ml - 16) * hp.total_upsample], full[0][..., : (ml - 16) * hp.total_upsample]) or \
+        _relrms(e[0][..., : (ml - 16) * hp.total_upsample], full[0][..., : (ml - 16) * hp.total_upsample]) < 1e-4
+    m.enable_graphs(True)
+    try:
+        for _ in range(2):
+            r = m.infer(*args, noise_w=nw, noise_z=nz.cuda(), max_len=ml, want_attn=False, **kw)
+        assert r[1] is None and r[0].shape == e[0].shape and r[2].shape == e[2].shape and r[3][0].shape == e[3][0].shape
+        assert _relrms(r[0], e[0]) < 1e-4 and torch.equal(r[2], e[2])
+    finally:
+        m.enable_graphs(False)
