@@ -389,20 +389,14 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AttnArgs A) {
   const float il = 1.0f / l_tot;                    // per lane: query l31 (== tid & 31 below since AQ == 32)
   const float fac = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_tot);
   // band logits -> band probabilities p[i][i+r] (each (r, i) once)
+  // (element e = tid + n NT belongs to query e & 31 == tid & 31 == l31 — NT is a multiple of 64 — so the query's totals are the m_tot / l_tot this
+  // lane has just formed: re-deriving them per element was 16 LDS reads and 8 exponentials each)
   for (int e = tid; e < NR * AQ; e += NT) {
-    const int r = e >> 5, i = e & 31;
-    const int j = i0 + i + r - W;
-    float mt = -INFINITY, lt = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) mt = fmaxf(mt, Mw[w * AQ + i]);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float mw = Mw[w * AQ + i];
-      lt += (mw == -INFINITY) ? 0.f : Lw[w * AQ + i] * __expf(mw - mt);
-    }
+    const int r = e >> 5;
+    const int j = iq + r - W;
     // key split: a band key outside [kt0, kt1) belongs to another workgroup (its Sb slot was never written here)
     const bool mine = j >= kt0 * AK && j < kt1 * AK;
-    Sb[e] = (j >= 0 && j < T && i0 + i < T && mine) ? __expf(Sb[e] - mt) / lt : 0.f;
+    Sb[e] = (j >= 0 && j < T && iok && mine) ? __expf(Sb[e] - m_tot) / l_tot : 0.f;
   }
   if (KS > 1 && tid < AQ && i0 + tid < T) {
     // (m_r, l_r) of this key range for the merge in the LayerNorm: [b][h][kr][2][T]
