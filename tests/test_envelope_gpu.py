@@ -114,8 +114,8 @@ def test_envelope_graph_replay_is_bit_identical_to_eager(name, reduced):
 # the same models where B*T and B*T_y are past the split-K regime (every encoder / flow convolution on the LDS-tiled kernels, attention and
 # LayerNorm with B > 1, the Generator's wide tiles): no golden (a fixture of that size is MBs) — the oracle, which the goldens above pin for
 # exactly these hyper-parameters, is the checker
-# (six of the twelve: hidden 128 / 192 / 256, both flows, odd and even coupling counts, ResBlock1 / 2, 3-5 stages — the GPU suite has a time limit)
-@pytest.mark.parametrize("name", ["hp01_tf3_h128x4", "hp03_tf2_h256x8_rb2", "hp04_tf5_h192x6", "hp06_wn3_h128x2", "hp07_wn4_h256x4_rb2", "hp09_wn5_h256x2"])
+# (four of the twelve: hidden 128 / 192 / 256, both flows, odd and even coupling counts, ResBlock1 / 2, 3-5 stages — the GPU suite has a time limit)
+@pytest.mark.parametrize("name", ["hp03_tf2_h256x8_rb2", "hp04_tf5_h192x6", "hp06_wn3_h128x2", "hp09_wn5_h256x2"])
 def test_envelope_at_a_tiled_batch_vs_oracle(name):
     from bert_vits2_amd import synth
     hp, seed, *_ = cases.build_case(name)
@@ -165,7 +165,9 @@ def test_envelope_at_a_tiled_batch_vs_oracle(name):
 
 # the interior of the envelope: seeded random models (cases.random_hparams draws from hparams.ENVELOPE = validate()'s ranges) against the oracle,
 # which tests/test_envelope_cpu.py holds to the LIVE reference on these very draws in the build container
-@pytest.mark.parametrize("i", range(cases.N_RANDOM_HPARAMS))
+# (every other draw on the GPU — the suite has a time limit and each draw costs a model build plus three CPU oracle runs; tests/test_envelope_cpu.py holds
+# the oracle to the live reference on ALL draws, and the twelve ENVELOPE models above cover the corners)
+@pytest.mark.parametrize("i", range(0, cases.N_RANDOM_HPARAMS, 2))
 def test_random_hparams_vs_oracle(i):
     from bert_vits2_amd import models, synth
     hp, lens, langs, sids, seed = cases.random_hparams(i)
@@ -195,8 +197,6 @@ def test_random_hparams_vs_oracle(i):
     vm = valid_wave_mask(ref["y_lengths"], hp.total_upsample, o.shape[2]).expand_as(ref["o"])
     err = rms((o.cpu() - ref["o"])[vm])
     assert err <= 5e-5, err
-    if i % 2:            # the reduced-precision forms on every other draw (their oracles are CPU time of a suite with a time limit); fp32 on all
-        return
     m.set_generator_dtype(torch.bfloat16)
     m.set_flow_dtype(torch.float16)
     with torch.no_grad():
