@@ -25,6 +25,7 @@ import argparse
 import glob
 import hashlib
 import json
+import re
 import os
 import sys
 import time
@@ -931,14 +932,12 @@ def _leg(v):
                     "replay_over_eager", "padded_value"))
     rp = v.get("repeats")
     if isinstance(rp, dict):
-        out["min_max"] = [rp.get("min"), rp.get("max")]
-        if rp.get("unstable"):
+        if rp.get("unstable"):                                    # min / max of the repeats live in the details file
+            out["min_max"] = [rp.get("min"), rp.get("max")]
             out["unstable"] = True
     r = v.get("roofline")
     if isinstance(r, dict) and "frac" in r:
         out["frac"], out["bound"] = r["frac"], r.get("bound")
-        if r.get("kernel"):
-            out["kernel"] = r["kernel"]
     rd = v.get("roofline_dominant_kernel")
     if isinstance(rd, dict) and "frac" in rd:
         out["mfma_frac"] = rd["frac"]
@@ -952,10 +951,9 @@ def headline(line, details_path=None):
     h = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                   "vs_baseline", "dtype", "data")}
     cfg = line.get("config") or {}
-    h["config"] = _pick(cfg, ("workload", "utterances_per_gpu", "symbols", "frames", "parallelism", "rtf", "x_realtime_per_gpu", "hipgraph",
-                              "weight_broadcast_ms", "hip_force_dev_kernarg"))
-    if isinstance(h["config"].get("workload"), str):
-        h["config"]["workload"] = h["config"]["workload"][:260]
+    h["config"] = _pick(cfg, ("workload", "utterances_per_gpu", "symbols", "frames", "parallelism", "hipgraph", "hip_force_dev_kernarg"))
+    if isinstance(h["config"].get("workload"), str):                 # the long description stays in the details file
+        h["config"]["workload"] = re.sub(r" \(wide-stage[^)]*\)", " (split-bf16 MFMA)", h["config"]["workload"]).split(", T_y=")[0][:200]
     if isinstance(cfg.get("pcie_inclusive"), dict):
         h["config"]["pcie_inclusive"] = _pick(cfg["pcie_inclusive"], ("value", "ms_per_step"))
     if isinstance(line.get("repeats"), dict):
@@ -972,10 +970,9 @@ def headline(line, details_path=None):
     c = line.get("cpu_baseline")
     if isinstance(c, dict):
         h["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "ms_per_step"))
-        h["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:170]
+        h["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:120]
         if isinstance(c.get("reference_container"), dict):
-            h["cpu_baseline"]["reference_container"] = _pick(c["reference_container"], ("ms", "audio_s_per_s", "threads", "port_ms_same_box",
-                                                                                         "reference_over_port", "reference_over_port_range"))
+            h["cpu_baseline"]["reference_container"] = _pick(c["reference_container"], ("threads", "reference_over_port", "reference_over_port_range"))
         if isinstance(c.get("reference_estimate_this_box"), dict):
             h["cpu_baseline"]["reference_estimate_this_box"] = c["reference_estimate_this_box"].get("value")
             h["cpu_baseline"]["reference_estimate_range"] = c["reference_estimate_this_box"].get("range")
@@ -1003,14 +1000,15 @@ def headline(line, details_path=None):
         if not isinstance(e, dict) or "families" not in e:
             return None
         return dict(ms_per_step=e.get("ms_per_step"), tflops=e.get("tflops"),
-                    families=[_pick(f, ("kernel", "us_per_launch", "tflops", "peak", "frac", "pmc_mfma_util")) for f in e["families"][:3]])
+                    families=[_pick(f, ("kernel", "us_per_launch", "peak", "frac", "pmc_mfma_util")) for f in e["families"][:2]])
     sec = line.get("secondary")
     eg = {k: v for k, v in (("config2", _eg(line.get("encoder_gemms"))),
                             ("config3", _eg((sec or {}).get("config3", {}).get("encoder_gemms") if isinstance(sec, dict) else None))) if v}
     if eg:
         h["encoder_gemms"] = eg
     if isinstance(sec, dict):
-        h["secondary"] = {k: _leg(v) for k, v in sec.items()}
+        h["secondary"] = {k: _leg(v) for k, v in sec.items()              # the other in-flight depths are in the details file
+                          if k not in ("config2_2_requests_in_flight", "text_features_plus_config2_4_in_flight")}
         ctl = sec.get("config2_fp32_mfma")
         if isinstance(ctl, dict) and ctl.get("value"):
             # the same step with the round-2 kernel on the SAME box: box-to-box spread cancels in the ratio
