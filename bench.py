@@ -54,7 +54,7 @@ CONFIGS = {
 }
 WN_FLOW_B32 = "f16"               # flow arithmetic of secondary.config3_residual_flow: the WN convolutions on the fp16 matrix core
 KW = dict(noise_scale=0.6, noise_scale_w=0.9, sdp_ratio=0.0, length_scale=1.0)
-KERNEL_SOURCES = {"conv1d_x6": "conv_x6.hip", "respair_x6": "respair_x6.hip", "conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
+KERNEL_SOURCES = {"conv1d_x6": "conv_x6.hip", "conv1d_x3": "conv_x6.hip", "respair_x6": "respair_x6.hip", "respair_x3": "respair_x6.hip", "conv1d_mfma": "conv_mfma.hip", "conv1d_splitk": "conv_mfma.hip", "resblock_fused": "resblock_fused.hip",
                   "conv_cl_bf16": "gen_bf16.hip", "respair_cl_bf16": "respair_cl_bf16.hip", "resblock_cl_bf16": "resblock_cl_bf16.hip", "resblock_c16_bf16": "resblock_c16_bf16.hip", "conv_f16": "enc_f16.hip",
                   "attention": "attention.hip"}
 
@@ -409,6 +409,15 @@ def roofline_block(prof, psteps, config=2):
                                         "(profiles/r03_mfma_bf16_probe.txt; round 4, full-range random operands: 0.68-0.73 in registers, "
                                         "0.57-0.64 with this operand traffic, profiles/r04_mfma_bf16_probe.txt)")
         ach, peak = 6.0 * ach, PEAK_BF16_MFMA_TFLOPS
+    elif (dom["name"].startswith("conv1d_x3") or dom["name"].startswith("respair_x3")) and bound == "mfma":
+        # the same kernel's two-plane fp16 form (bv2_kernels.h "x3"): THREE fp16 MFMA products per multiply-add (the operands scaled by
+        # powers of two into fp16's range and split into two fp16 halves; dropped term <= 2^-24 of a product).  Same accounting: issued
+        # fp16 FLOPs against the 2.5 PF fp16 / bf16 matrix peak.
+        x6 = dict(math="fp32 operands / fp32 results; every product formed on the fp16 matrix core from 2-way fp16 splits of the scaled "
+                       "operands, 3 of the 4 cross terms (dropped term <= 2^-24 of a product): 3 issued fp16 MFMA FLOPs per algorithmic FLOP",
+                  issued_flops_per_alg_flop=3, fp32_equivalent_tflops=round(ach, 3),
+                  frac_of_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4))
+        ach, peak = 3.0 * ach, PEAK_BF16_MFMA_TFLOPS
     return dict(bound=bound, kernel=dom["name"], achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 4), **x6,
                 arithmetic_intensity_flop_per_byte=round(ai, 1), traffic=tr.get("bytes_per_launch"), traffic_detail=tr,
                 alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]), launches_per_step=dom["launches"] / psteps,

@@ -424,6 +424,7 @@ int bv2_set_option(bv2_handle* h, const char* key, int value) {
   else if (k == "xcd_affine") h->no_xcd_affine = value == 0;
   else if (k == "prefetch") h->prefetch = value & 3;
   else if (k == "conv_x6") h->no_conv_x6 = value == 0;
+  else if (k == "conv_x3") h->no_conv_x3 = value == 0;
   else if (k == "conv_x6_c32") h->x6_narrow = value != 0;
   else if (k == "fused_dds") h->no_fused_dds = value == 0;
   else if (k == "fused_attn_o") h->no_fused_attn_o = value == 0;
@@ -506,7 +507,9 @@ int64_t bv2_test_conv_pack_floats(int cin, int cout, int k) {
   // + 2048 floats: the register-ring conv kernel prefetches up to 4 units (4 KB) past the last weight unit
   // + the three split-bf16 planes of conv_x6.hip (tile >= TILE_X6), 6 bytes per weight of the 32-row padded matrix
   const int64_t base = (int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048;
-  return base + (cin % 32 == 0 ? (x6_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 : 0);
+  // + the x3 form's region (tile == TILE_X3): two 64-float slots (max |x| in, max |out| back), 1 / S_w, the two fp16 planes
+  return base + (cin % 32 == 0 ? (x6_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 +
+                                 128 + X3_HDR_FLOATS + (x3_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 : 0);
 }
 void bv2_test_x6_split(float v, uint16_t* h3) { x6_split(v, h3); }
 int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_floats, int max_regions) {
@@ -527,6 +530,11 @@ int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_flo
 static int64_t t_x6_off(int cin, int cout, int k) {
   return ((int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048 + 63) / 64 * 64;
 }
+
+static int64_t t_x3_off(int cin, int cout, int k) {                 // the x3 region: [slot in (64)] [slot out (64)] [1 / S_w (64)] [planes]
+  return (t_x6_off(cin, cout, k) + (x6_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 + 63) / 64 * 64;
+}
+int64_t bv2_test_x3_omax_off(int cin, int cout, int k) { return t_x3_off(cin, cout, k) + 64; }
 
 int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const float* bias_host, float* out, float* wpack_dev,
                     int B, int cin, int cout, int k, int dil, int pad_left, int L, int tile, float lrelu_slope, int relu,
@@ -555,10 +563,42 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
             for (int pl = 0; pl < 3; ++pl) wx[x6_w_index(j, ci, co, cin, k, pl)] = hh[pl];
           }
     }
+    const bool x3 = tile == TILE_X3 && x6;
+    if (w_host && x3) {
+      float wmax = 0.f;
+      for (size_t i = 0; i < (size_t)cout * cin * k; ++i) wmax = std::max(wmax, std::fabs(w_host[i]));
+      uint32_t mb;
+      std::memcpy(&mb, &wmax, 4);
+      const unsigned e = x3_scale_exp(mb);
+      float* reg = pk.data() + t_x3_off(cin, cout, k);
+      reg[128] = x3_scale_inv(e);
+      uint16_t* wy = reinterpret_cast<uint16_t*>(reg + 128 + X3_HDR_FLOATS);
+      for (int j = 0; j < k; ++j)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) {
+            const float v = w_host[((size_t)co * cin + ci) * k + j] * x3_scale(e);
+            const _Float16 g0 = (_Float16)v;
+            const _Float16 g1 = (_Float16)(v - (float)g0);
+            std::memcpy(&wy[x3_w_index(j, ci, co, cin, k, 0)], &g0, 2);
+            std::memcpy(&wy[x3_w_index(j, ci, co, cin, k, 1)], &g1, 2);
+          }
+    }
     if (w_host && hipMemcpy(wpack_dev, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice) != hipSuccess) return -6;
     ConvLaunch cl;
     std::memset(&cl, 0, sizeof(cl));
     ConvProb& p = cl.p[0];
+    if (cin % 32 == 0 && ksplit <= 1) {
+      // every kernel's max |out| lands in the region's second slot (bv2_test_x3_omax_off); the x3 form reads max |x| from the first: the
+      // product's producers publish it from their epilogues, here a reduction launch fills the (zeroed) slot
+      float* reg = wpack_dev + t_x3_off(cin, cout, k);
+      if (hipMemsetAsync(reg, 0, sizeof(float) * 128, static_cast<hipStream_t>(stream)) != hipSuccess) return -6;
+      p.omax = reinterpret_cast<unsigned*>(reg + 64);
+      if (x3) {
+        if (nsrc != 1 || launch_absmax(static_cast<hipStream_t>(stream), x, (int64_t)B * cin * L, reinterpret_cast<unsigned*>(reg))) return -2;
+        p.xmax = reinterpret_cast<const unsigned*>(reg);
+        p.w3inv = reg + 128; p.w3 = reinterpret_cast<const uint16_t*>(reg + 128 + X3_HDR_FLOATS);
+      }
+    }
     p.x[0] = x; p.x[1] = x1; p.x[2] = x2; p.nsrc = nsrc; p.in_scale = in_scale;
     p.x_bstride = (int64_t)cin * L; p.x_rstride = L; p.Lin = L;
     p.in_mask = in_mask; p.in_mask_bstride = L; p.out_mask = out_mask; p.out_mask_bstride = L;
@@ -689,7 +729,58 @@ int bv2_test_respair_cl(void* stream, const void* x, void* out, const float* w_h
 }
 int64_t bv2_test_respair_cl_pack_bytes(int C, int k) { return cl_w_elems(C, C, k) * 4 + 8192 + 256 + (int64_t)2 * C * 4; }
 
-int64_t bv2_test_respair_x6_pack_bytes(int C, int k) { return x6_w_elems(C, (C + 31) / 32 * 32, k) * 4 + 16384 + 256 + (int64_t)2 * 32 * 4 + (int64_t)2 * C * 4; }
+int64_t bv2_test_respair_x6_pack_bytes(int C, int k) { return x6_w_elems(C, (C + 31) / 32 * 32, k) * 4 + 16384 + 256 + (int64_t)2 * 32 * 4 + (int64_t)2 * C * 4 + 1024; }
+static int t_respair_x3(void* stream, const float* x, float* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                        int C, int k, int dil, int L, float slope, const int64_t* lens) {
+  try {
+    if (!respair_x6_supported(C, k, dil)) return -2;
+    const int cout_pad = t_round_up(C, 32);
+    const int64_t ne = x3_w_elems(C, cout_pad, k);
+    std::vector<uint16_t> pk((size_t)2 * ne, 0);
+    float inv[2];
+    for (int e = 0; e < 2; ++e) {
+      float wmax = 0.f;
+      for (size_t i = 0; i < (size_t)C * C * k; ++i) wmax = std::max(wmax, std::fabs(w_host[(size_t)e * C * C * k + i]));
+      uint32_t mb;
+      std::memcpy(&mb, &wmax, 4);
+      const unsigned ex = x3_scale_exp(mb);
+      inv[e] = x3_scale_inv(ex);
+      for (int co = 0; co < C; ++co)
+        for (int ci = 0; ci < C; ++ci)
+          for (int j = 0; j < k; ++j) {
+            const float v = w_host[(((size_t)e * C + co) * C + ci) * k + j] * x3_scale(ex);
+            const _Float16 g0 = (_Float16)v;
+            const _Float16 g1 = (_Float16)(v - (float)g0);
+            std::memcpy(&pk[(size_t)e * ne + (size_t)x3_w_index(j, ci, co, C, k, 0)], &g0, 2);
+            std::memcpy(&pk[(size_t)e * ne + (size_t)x3_w_index(j, ci, co, C, k, 1)], &g1, 2);
+          }
+    }
+    std::vector<float> pb((size_t)2 * cout_pad + 128, 0.f);
+    for (int e = 0; e < 2; ++e)
+      for (int co = 0; co < C; ++co) pb[(size_t)e * cout_pad + co] = bias_host[(size_t)e * C + co];
+    pb[(size_t)2 * cout_pad] = inv[0]; pb[(size_t)2 * cout_pad + 64] = inv[1];
+    char* base = static_cast<char*>(wpack_dev);
+    const size_t wbytes = pk.size() * 2 + 16384, boff = (wbytes + 255) / 256 * 256;
+    if (hipMemset(base, 0, boff + pb.size() * 4) != hipSuccess) return -6;
+    if (hipMemcpy(base, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    if (hipMemcpy(base + boff, pb.data(), pb.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -6;
+    FusedLaunch F;
+    std::memset(&F, 0, sizeof(F));
+    F.nprob = 1; F.B = B; F.C = C; F.L = L; F.slope = slope; F.lens = lens; F.len_mul = 1;
+    FusedProb& q = F.p[0];
+    q.x = x; q.out = out; q.k = k; q.dil = dil;
+    q.w31 = reinterpret_cast<const uint16_t*>(base); q.w32 = q.w31 + ne;
+    q.w61 = q.w31; q.w62 = q.w32;                    // (the launcher insists on them; not read by the x3 form)
+    q.b1 = reinterpret_cast<const float*>(base + boff); q.b2 = q.b1 + cout_pad;
+    q.w3inv1 = q.b1 + 2 * cout_pad; q.w3inv2 = q.w3inv1 + 64;
+    q.w1 = q.b1; q.w2 = q.b1;
+    return launch_respair_x6(static_cast<hipStream_t>(stream), F);
+  } catch (...) { return -100; }
+}
+int bv2_test_respair_x3(void* stream, const float* x, float* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                        int C, int k, int dil, int L, float slope, const int64_t* lens) {
+  return t_respair_x3(stream, x, out, w_host, bias_host, wpack_dev, B, C, k, dil, L, slope, lens);
+}
 int bv2_test_respair_x6(void* stream, const float* x, float* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
                         int C, int k, int dil, int L, float slope, const int64_t* lens) {
   try {

@@ -393,9 +393,11 @@ PlanA plan_a(Arena& A, const Model& m, int B, int T) {
   return p;
 }
 
+constexpr int kX3Slots = 512;          // >= BV2_MAX_UPS * (1 + 2 * BV2_MAX_RESBLOCK_KERNELS * BV2_MAX_RESBLOCK_DILATIONS) = 264
 struct PlanB {
   float *gv, *zp, *z, *h, *acts, *outacc, *pre, *ymask;
   int* fidx;
+  unsigned* xslots;                  // kX3Slots max |x| slots of the fp32 Generator's x3 convs (conv_x6.hip), zeroed at the start of every decode
   int64_t* len_cap;                  // [B] the batch's longest y_length, broadcast (exact_lengths == 2)
   EncBufs enc;
   float* set[2][7];
@@ -419,6 +421,7 @@ PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
                 (c.use_transformer_flow ? m.n_coupling * (int)H : m.n_coupling * 2 * (int)H * c.n_flow_layer);
   p.gv = A.get<float>((int64_t)B * p.gv_stride);
   p.fidx = A.get<int>(BT);
+  p.xslots = A.get<unsigned>(kX3Slots);
   p.ymask = A.get<float>(BT);
   p.len_cap = A.get<int64_t>(B);
   p.zp = A.get<float>(BT * c.inter_channels);
@@ -849,11 +852,23 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
   int nsrc = 1;
   int Lc = L;
   int up = 1;                                     // samples per latent frame at the current resolution
+  // x3 form of the wide-stage convs (conv_x6.hip, two scaled fp16 planes): every conv input needs the slot its producer's epilogue
+  // filled with max |x|; the slots of one decode are distinct and zeroed here
+  int next_slot = 0;
+  bool any_x3 = false;
+  for (int i = 0; i < m.n_ups && !c.h->no_conv_x3 && !c.h->no_conv_x6; ++i)
+    if (m.rb[i][0][0][0].wy_off >= 0) any_x3 = true;
+  if (any_x3 && !c.rc && hipMemsetAsync(P.xslots, 0, sizeof(unsigned) * kX3Slots, c.s) != hipSuccess) c.chk(-1, "dec.x3_slots");
   for (int i = 0; i < m.n_ups; ++i) {
     const UpW& U = m.ups[i];
     float* const* S = P.set[i & 1];
     float* x = S[0];
     const int Lo = Lc * U.u;
+    const int nb = m.n_rbk;
+    bool x3 = any_x3;                             // (a stage that takes a fused path below just leaves its slots unread)
+    for (int j = 0; j < nb && x3; ++j)
+      for (int d = 0; d < m.n_rbd && x3; ++d) x3 = m.rb[i][j][d][0].wy_off >= 0 && m.rb[i][j][d][1].wy_off >= 0;
+    unsigned* const slot_x = x3 ? P.xslots + next_slot++ : nullptr;
     {
       // x = ConvTranspose1d(leaky_relu(mean of the previous stage's branches)) as U.u polyphase stride-1 convs
       ConvLaunch cl;
@@ -864,6 +879,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
         p.pre_act = PRE_LRELU; p.slope = 0.1f;
         p.pad_left = U.pad_left[ph];
         p.out_bstride = (int64_t)U.cout * Lo; p.out_rstride = Lo; p.out_tstride = U.u; p.out_toff = ph;
+        p.omax = slot_x;
         cl.p[ph] = p;
       }
       c.conv(cl, "dec.ups");
@@ -873,7 +889,6 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
       c.tap(tn.c_str(), x, (int64_t)B * U.cout * Lo);
     }
     // the n_rbk ResBlock1 branches run side by side
-    const int nb = m.n_rbk;
     const bool rb2 = m.rb_type == 2;
     bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock && !rb2;
     // C = 32: two split-bf16 launches per pair (HBM-bound, 5 tensor passes) against one fused fp32-MFMA launch (MFMA-bound, 3 passes)
@@ -934,6 +949,11 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
           if (x6pair) {
             p.w61 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off));
             p.w62 = reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][1].wx_off));
+            if (!c.h->no_conv_x3 && m.rb[i][j][d][0].wy_off >= 0 && m.rb[i][j][d][1].wy_off >= 0) {   // the x3 form: scaled fp16 planes
+              p.w3inv1 = c.W(m.rb[i][j][d][0].wy_off); p.w3inv2 = c.W(m.rb[i][j][d][1].wy_off);
+              p.w31 = reinterpret_cast<const uint16_t*>(p.w3inv1 + X3_HDR_FLOATS);
+              p.w32 = reinterpret_cast<const uint16_t*>(p.w3inv2 + X3_HDR_FLOATS);
+            }
           }
           branch_out[j] = xout;
         }
@@ -943,12 +963,14 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
             c.cur_shape = " n" + std::to_string(nb) + " C" + std::to_string(U.cout) + " k" + std::to_string(F.p[0].k) + " L" +
                           std::to_string(Lo) + " B" + std::to_string(B);
           const int r = x6pair ? launch_respair_x6(c.s, F) : launch_resblock_fused(c.s, F);
-          c.prof_end(pi, x6pair ? (U.cout == 16 ? "respair_x6<16>" : U.cout == 32 ? "respair_x6<32>" : (U.cout == 64 ? "respair_x6<64>" : "respair_x6<128>")) : "resblock_fused", resblock_fused_flops(F), resblock_fused_bytes(F));
+          c.prof_end(pi, x6pair ? (F.p[0].w31 ? (U.cout == 16 ? "respair_x3<16>" : U.cout == 32 ? "respair_x3<32>" : (U.cout == 64 ? "respair_x3<64>" : "respair_x3<128>"))
+                                              : (U.cout == 16 ? "respair_x6<16>" : U.cout == 32 ? "respair_x6<32>" : (U.cout == 64 ? "respair_x6<64>" : "respair_x6<128>"))) : "resblock_fused", resblock_fused_flops(F), resblock_fused_bytes(F));
           if (r) c.fail("dec.resblock.fused", r);
         }
       }
     } else {
       // wide stages: 2 launches per dilation step, each carrying all branches
+      unsigned* slot_cur[BV2_MAX_RESBLOCK_KERNELS] = {nullptr, nullptr, nullptr, nullptr};   // max |cur_j| after the previous dilation step
       for (int d = 0; d < m.n_rbd; ++d) {
         ConvLaunch c1, c2;
         c1.nprob = c2.nprob = nb; c1.B = c2.B = B; c1.L = c2.L = Lo;
@@ -959,15 +981,26 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
           float* tmp = S[1 + nb + j];
           const float* xin = d == 0 ? x : cur;
           const bool x6 = !c.h->no_conv_x6;                       // the split-bf16 planes ride along: launch_conv1d picks conv_x6.hip
+          auto planes3 = [&](ConvProb& q, const ConvW& w, const unsigned* in_slot, unsigned* out_slot) {
+            if (!x3) return;
+            q.w3inv = c.W(w.wy_off);
+            q.w3 = reinterpret_cast<const uint16_t*>(c.W(w.wy_off) + X3_HDR_FLOATS);
+            q.xmax = in_slot; q.omax = out_slot;
+          };
+          unsigned* const slot_tmp = x3 ? P.xslots + next_slot++ : nullptr;
+          unsigned* const slot_out = (x3 && d + 1 < m.n_rbd) ? P.xslots + next_slot++ : nullptr;   // the last step's output feeds no x3 conv
           ConvProb p = c.prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
           p.pre_act = PRE_LRELU; p.slope = 0.1f;
           p.w6 = (x6 && m.rb[i][j][d][0].wx_off >= 0) ? reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off)) : nullptr;
+          planes3(p, m.rb[i][j][d][0], d == 0 ? slot_x : slot_cur[j], slot_tmp);
           c1.p[jj] = p;
           p = c.prob(m.rb[i][j][d][1], tmp, cur, Lo, 1);
           p.pre_act = PRE_LRELU; p.slope = 0.1f;
           p.res = xin; p.res_mode = RES_ADD;
           p.w6 = (x6 && m.rb[i][j][d][1].wx_off >= 0) ? reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][1].wx_off)) : nullptr;
+          planes3(p, m.rb[i][j][d][1], slot_tmp, slot_out);
           c2.p[jj] = p;
+          slot_cur[j] = slot_out;
         }
         c.conv(c1, "dec.resblock.convs1");
         c.conv(c2, "dec.resblock.convs2");

@@ -33,6 +33,7 @@ struct ConvW {
   int64_t wb_off = -1;               // Generator convs only: bf16 fragment stream (cl_w_index), offset in floats
   int64_t wh_off = -1;               // flow Encoder convs only: fp16 fragment stream (cl_w_index), offset in floats
   int64_t wx_off = -1;               // wide Generator ResBlock convs only: three bf16 planes (x6_w_index), offset in floats
+  int64_t wy_off = -1;               // fp32 Generator ResBlock convs with x6 planes: 1 / S_w, then (X3_HDR_FLOATS in) two fp16 planes (x3_w_index)
 };
 struct VecW { int64_t off = -1; int64_t n = 0; };
 struct GemvW { int cout = 0, cin = 0; int64_t w_off = -1, b_off = -1; };
@@ -129,6 +130,7 @@ struct bv2_handle {
   int flow_dtype = BV2_F32;          // transformer-flow Encoder convs: BV2_F32 (conv_mfma.hip) or BV2_F16 (enc_f16.hip)
   // bv2_set_option switches (tests compare the fused kernels with the layer-wise ones)
   bool no_conv_x6 = false;           // "conv_x6" = 0: wide Generator convs on the fp32 matrix core (conv_mfma.hip) instead of the bf16x6 form
+  bool no_conv_x3 = false;           // "conv_x3" = 0: the wide fp32 Generator convs on the three-plane bf16 form (six products) instead of the two-plane fp16 form
   bool x6_narrow = true;             // "conv_x6_c32" = 0: the C = 32 stage on the fused fp32 pair kernel instead of layer-wise on conv_x6.hip
   bool no_fused_resblock = false;    // "fused_resblock" = 0: narrow Generator stages layer by layer
   int prefetch = 0;                  // "prefetch": bit 0 LayerNorm launches, bit 1 split-K launches carry the next launch's weight stream (batch 1); measured: nothing at config 2 (profiles/r05_ab_prefetch_c2.txt), off

@@ -113,6 +113,13 @@ struct ConvProb {
   int mask_pre;             // multiply by out_mask before the residual op
   int res_mode;
   int mask_post;            // multiply by out_mask after the residual op
+  // conv_x6.hip's two-plane fp16 form ("x3", below): the weights as two fp16 planes (x3_w_index) scaled by a power of two, that
+  // scale's reciprocal, and the slot that holds max|x| of the INPUT tensor as fp32 bits (written by the launch that produced x).
+  // All three set: the x3 form; any null: the three-plane bf16 form (w6).
+  const uint16_t* w3;
+  const float* w3inv;
+  const unsigned* xmax;
+  unsigned* omax;           // any LDS-tiled conv (conv_mfma.hip, conv_x6.hip): atomicMax of |out| over everything this problem stores, or null
 };
 
 #define BV2_MAX_PROBS 8
@@ -141,7 +148,8 @@ unsigned long long* timeline_slice(unsigned gx, unsigned gy, unsigned gz, int ti
 // tile: 0 = auto; otherwise one of the TILE_* ids (tests force each variant)
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_32x256 = 5, TILE_SPLITK = 6, TILE_128x64 = 7,
        TILE_X6 = 8,            // the split-bf16 form of the LDS-tiled kernel (kernels/conv_x6.hip); TILE_AUTO picks it when every problem has w6
-       TILE_X6_128x64 = 9, TILE_X6_128x64_LD = 10, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12 };   // tests / tuning: one x6 tile forced
+       TILE_X6_128x64 = 9, TILE_X6_128x64_LD = 10, TILE_X6_64x128 = 11, TILE_X6_32x256 = 12,     // tests / tuning: one x6 tile forced
+       TILE_X3 = 14 };         // tests: the x6 choice with the two-plane fp16 form where the tile has one (the product takes it whenever w3 / w3inv / xmax are set)
 // (13 was TILE_SPLITK_X6, the split-K kernel's split-bf16 form: measured at +0.4 % on config 2 for +195 MB of blob and deleted in round 6 —
 //  DESIGN.md "measured and not kept", profiles/r05_ab_splitk_x6_not_kept.txt)
 int launch_conv1d(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
@@ -176,6 +184,36 @@ inline void x6_split(float v, uint16_t h[3]) {
     v -= f;
   }
 }
+// The two-plane fp16 form of the same kernel ("x3": three products instead of six).  v * S = g0 + g1 with g0 = fp16(v * S) and
+// g1 = fp16(v * S - g0), S a power of two that puts the tensor's largest magnitude just below 2^15: |v * S - g0 - g1| <= 2^-24 |v * S|
+// for every element within 2^15 of the largest (fp16 has 11 significand bits and subnormals down to 2^-24; smaller elements keep an
+// ABSOLUTE error <= 2^-25, i.e. 2^-40 of the largest), and of the four cross terms the three largest, w0x0 + (w0x1 + w1x0), leave out
+// |w1x1| <= 2^-24 |wx| — the same order as the six-product bf16 form, at half the matrix work.  fp16 has no exponent range to spare,
+// hence the scales: S_w per weight tensor at pack time (x3_scale_exp of its max |w|), S_x per INPUT tensor from the max |x| slot its
+// producer filled (ConvProb::omax -> ::xmax); the epilogue multiplies the accumulator by 1 / (S_w S_x), exact.
+//   plane layout: [m-tile = co/32][group s = ci/16][tap j][plane p < 2][lane = co%32 + 32*((ci%16)/8)][ci%8]   (x6's with two planes)
+inline int64_t x3_w_index(int j, int ci, int co, int cin, int k, int plane) {
+  const int64_t U = (int64_t)(cin / 16) * k, u = (int64_t)(ci / 16) * k + j;
+  const int lane = (co & 31) + 32 * ((ci % 16) / 8);
+  return ((((int64_t)(co >> 5) * U + u) * 2 + plane) * 64 + lane) * 8 + (ci % 8);
+}
+inline int64_t x3_w_elems(int cin, int cout_pad, int k) { return (int64_t)(cout_pad / 32) * (cin / 16) * k * 2 * 512; }
+constexpr int X3_HDR_FLOATS = 64;     // the packed region starts with 1 / S_w (one float, 256-byte slot), the planes follow
+// biased fp32 exponent e of the tensor's largest magnitude, clamped so that S = 2^(141 - e) and 1 / S = 2^(e - 141) are normal floats:
+// max < 2^(e - 126)  =>  max * S < 2^15
+#if defined(__HIPCC__)
+#define BV2_HD __host__ __device__
+#else
+#define BV2_HD
+#endif
+BV2_HD inline unsigned x3_scale_exp(unsigned max_bits) {
+  unsigned e = (max_bits >> 23) & 255u;
+  return e < 15u ? 15u : (e > 254u ? 254u : e);
+}
+BV2_HD inline float x3_scale(unsigned e) { const uint32_t u = (268u - e) << 23; float f; __builtin_memcpy(&f, &u, 4); return f; }
+BV2_HD inline float x3_scale_inv(unsigned e) { const uint32_t u = (e - 14u) << 23; float f; __builtin_memcpy(&f, &u, 4); return f; }
+// max |x| of a tensor into a slot (fp32 bits; the slot is zeroed by the caller): for inputs whose producer is not a conv launch
+int launch_absmax(hipStream_t stream, const float* x, int64_t n, unsigned* slot);
 bool conv_x6_supported(const ConvLaunch& L);        // every problem carries w6 and fits the staged tile
 int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 void conv_x6_occupancy(int out[4]);                              // workgroups per CU granted to {128x64, 128x64 + loaders, 64x128, 32x256}
@@ -202,6 +240,8 @@ struct FusedProb {
   const float* w2; const float* b2;               // ... of convs2[d]
   int k, dil;
   const uint16_t* w61; const uint16_t* w62;       // respair_x6.hip only: the two convs' split-bf16 weight planes (x6_w_index)
+  const uint16_t* w31; const uint16_t* w32;       // ... their scaled fp16 planes (x3_w_index) and 1 / S_w: all four set = the x3 form
+  const float* w3inv1; const float* w3inv2;
 };
 struct FusedLaunch { FusedProb p[3]; int nprob, B, C, L; float slope; const int64_t* lens = nullptr; int len_mul = 1;
                      unsigned long long* dbg = nullptr; };   // dbg: tools/timeline.py only

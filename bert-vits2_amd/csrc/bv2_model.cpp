@@ -41,6 +41,12 @@ static inline uint16_t f2h(float f) {
   return u;
 }
 
+static inline float h2f(uint16_t u) {
+  _Float16 h;
+  std::memcpy(&h, &u, 2);
+  return (float)h;
+}
+
 namespace {
 
 struct Packer {
@@ -123,6 +129,8 @@ struct Packer {
     if (emit_bf16 && cin % 16 == 0) c.wb_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (emit_f16 && cin % 16 == 0) c.wh_off = alloc((cl_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (emit_x6 && cin % 16 == 0) c.wx_off = alloc((x6_w_elems(cin, c.cout_pad, k) + 1) / 2);
+    // ... and the two scaled fp16 planes of the "x3" form of conv_x6.hip / respair_x6.hip (1 / S_w in front)
+    if (emit_x6 && cin % 16 == 0) c.wy_off = alloc(X3_HDR_FLOATS + (x3_w_elems(cin, c.cout_pad, k) + 1) / 2);
     if (fill() && ok) {
       for (int j = 0; j < k; ++j)
         for (int ci = 0; ci < cin; ++ci)
@@ -145,6 +153,27 @@ struct Packer {
               uint16_t h[3];
               x6_split(src(co, ci, j), h);
               for (int pl = 0; pl < 3; ++pl) wx[x6_w_index(j, ci, co, cin, k, pl)] = h[pl];
+            }
+      }
+      if (c.wy_off >= 0) {
+        // w * S_w = g0 + g1 (x3_w_index, bv2_kernels.h); S_w from the tensor's largest magnitude
+        float wmax = 0.f;
+        for (int j = 0; j < k; ++j)
+          for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) wmax = std::max(wmax, std::fabs(src(co, ci, j)));
+        uint32_t mb;
+        std::memcpy(&mb, &wmax, 4);
+        const unsigned e = x3_scale_exp(mb);
+        const float S = x3_scale(e);
+        blob[c.wy_off] = x3_scale_inv(e);
+        uint16_t* wy = reinterpret_cast<uint16_t*>(blob + c.wy_off + X3_HDR_FLOATS);
+        for (int j = 0; j < k; ++j)
+          for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) {
+              const float v = src(co, ci, j) * S;                    // exact: S is a power of two, |v| < 2^15
+              const uint16_t g0 = f2h(v);
+              wy[x3_w_index(j, ci, co, cin, k, 0)] = g0;
+              wy[x3_w_index(j, ci, co, cin, k, 1)] = f2h(v - h2f(g0));
             }
       }
       if (c.wh_off >= 0) {

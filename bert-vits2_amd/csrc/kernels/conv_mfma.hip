@@ -306,6 +306,8 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
     const float* const b1p = biasp ? biasp : P.w;
     const float* const b2p = bias2p ? bias2p : P.w;
     const unsigned m_b1 = biasp ? 0xffffffffu : 0u, m_b2 = bias2p ? 0xffffffffu : 0u;
+    unsigned* const omaxp = P.omax;                // max |v| of everything stored, for the x3 form of conv_x6.hip that reads this tensor
+    float vmx = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;       // this lane's rows: row0 + (r & 3) + 8 * (r >> 2)
@@ -358,9 +360,18 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
           if (res_mode == RES_ADD) v += rv[r];
           else if (res_mode == RES_RSUB) v = rv[r] - v;
           if (mask_post) v *= om;
-          if (colok && row0 + dr < cout) outb[off0 + (unsigned)dr * o_rs] = v;
+          if (colok && row0 + dr < cout) {
+            outb[off0 + (unsigned)dr * o_rs] = v;
+            vmx = fmaxf(vmx, fabsf(v));
+          }
         }
       }
+    }
+    if (omaxp) {                                   // one atomic per wave, only while the slot is below the wave's value (conv_x6.hip)
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, d));
+      const unsigned bits = __float_as_uint(vmx);
+      if (lane == 0 && bits > *reinterpret_cast<volatile unsigned*>(omaxp)) atomicMax(omaxp, bits);
     }
   }
   if (L.dbg && tid == 0) {
@@ -499,6 +510,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const float* const biasp = z == 0 ? P.bias : nullptr;
   const float* const bias2p = (z == 0 && P.bias2) ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
   const float om = (P.out_mask && colok) ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
+  unsigned* const omaxp = P.omax;
   const unsigned coff = (unsigned)(colok ? col : 0) * o_ts + o_to;
   constexpr int RPP = 2 * NWV;                      // rows per pass (one element per thread per pass)
   float rvv[32 / RPP], bsv[32 / RPP], b2v[32 / RPP];
@@ -608,6 +620,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   __syncthreads();
   // epilogue (its operands — ConvProb fields, bias, residual — were loaded before the main loop: "epilogue operands first" above)
   {
+    float vmx = 0.f;
     if (act == ACT_GATE) {                          // rows rl and rl + 16 are a (tanh, sigmoid) pair: passes i and i + 16/RPP of this thread
       if constexpr (RPP <= 16) {
         float vs[32 / RPP];
@@ -647,7 +660,16 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
         vv = -vv;
       }
       if (mask_post) vv *= om;
-      if (colok && row < cout) outb[(unsigned)row * o_rs + coff] = vv;
+      if (colok && row < cout) {
+        outb[(unsigned)row * o_rs + coff] = vv;
+        vmx = fmaxf(vmx, fabsf(vv));
+      }
+    }
+    if (omaxp) {                                    // ksplit == 1 only (host): max |v| of the stored tensor, see conv1d_mfma_kernel
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, d));
+      const unsigned bits = __float_as_uint(vmx);
+      if (lane == 0 && bits > *reinterpret_cast<volatile unsigned*>(omaxp)) atomicMax(omaxp, bits);
     }
   }
   if (L.dbg && tid == 0) {

@@ -40,6 +40,9 @@ namespace {
 
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 xf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 xf16x2 __attribute__((ext_vector_type(2)));
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
 typedef float xf32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
 // explicit global address space for the ring (see gen_bf16.hip: a FLAT load would also count on lgkmcnt)
@@ -57,7 +60,23 @@ __device__ __forceinline__ float x6_lo(unsigned u) { return __uint_as_float(u <<
 __device__ __forceinline__ float x6_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 constexpr float X6_BF16_MAX = 3.38953139e38f;   // 0x7f7f0000
-constexpr int X6_UNIT = 3 * 512;          // elements of one (group, tap) unit of one m-tile: 3 planes x 64 lanes x 8
+// ConvProb::omax: the wave's max |v| into the slot.  |v| >= 0, so the fp32 bit patterns order like the values; one atomic per wave, and
+// only while the slot is still below the wave's value (a stale read only costs a redundant atomic).
+__device__ __forceinline__ void x6_absmax_publish(unsigned* slot, float vmx, int lane) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, d));
+  const unsigned bits = __float_as_uint(vmx);
+  if (lane == 0 && bits > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, bits);
+}
+__device__ __forceinline__ xf32x16 x6_mfma(xbf16x8 a, xbf16x8 b, xf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ xf32x16 x6_mfma(xf16x8 a, xf16x8 b, xf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// NP = 2 (the x3 form, bv2_kernels.h): fp16 halves of the SCALED value, round-to-nearest-even (v_cvt_f16_f32 x 2 + pack)
+__device__ __forceinline__ unsigned x3_pack(float a, float b) {
+  xf32x2 v = {a, b};
+  const xf16x2 r = __builtin_convertvector(v, xf16x2);
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ xf32x2 x3_unpack(unsigned u) { return __builtin_convertvector(__builtin_bit_cast(xf16x2, u), xf32x2); }
 
 }  // namespace
 
@@ -66,9 +85,12 @@ constexpr int X6_UNIT = 3 * 512;          // elements of one (group, tap) unit o
 // waves stage themselves between two barriers with the matrix pipe idle: 2.5-4k cycles per chunk (tools/timeline.py), which the other
 // resident workgroups hide only partly and, in the one-workgroup-per-CU launches of the C = 256 stage, not at all.  Costs a second
 // 31 KB buffer (two workgroups per CU instead of three; with the loaders still 12 waves per CU).
-template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD>
+// NP = 3: three bf16 planes per operand, six products.  NP = 2: two scaled fp16 planes, three products (the "x3" form, bv2_kernels.h):
+// the same kernel with a third less LDS / ring registers and half the matrix instructions per unit.
+template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD, int NP = 3>
 __global__ void __launch_bounds__(64 * (WM * WN + NLD), WM * WN > 4 ? 2 : ((NLD > 0 || (MI * NI <= 2 && CK == 32 && XR <= 128)) ? 3 : 2))
 conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
+  constexpr int X6_UNIT = NP * 512;                // elements of one (group, tap) unit of one m-tile: NP planes x 64 lanes x 8
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
   constexpr int PITCH = CK + 8;                    // bf16 elements per LDS row: (CK/8 + 1) * 16 B, an odd multiple of 16 B
@@ -78,11 +100,11 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   constexpr int NCW = WM * WN;                     // MFMA waves: 4, or 8 (with loader waves only)
   constexpr int STW = NLD > 0 ? NLD : 4;           // waves that stage X
   constexpr int OPW = CK / 8 / STW;                // channel octets per staging wave per column group
-  constexpr int BUFSZ = 3 * PLANE;                 // elements of one X buffer (NLD > 0: two of them)
+  constexpr int BUFSZ = NP * PLANE;                // elements of one X buffer (NLD > 0: two of them)
   static_assert(NCW == 4 || (NCW == 8 && NLD > 0), "4 MFMA waves, or 8 staged by loader waves");
   static_assert((CK / 8) % STW == 0, "octets dealt evenly");
   static_assert(XR % 64 == 0 && XR >= BN && (CK == 32 || CK == 64), "staged tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [NP][XR][PITCH]
 
   // placement: identical to conv1d_mfma_kernel (grid (time tiles, m-tiles x batch, problems), or the cost-balanced snake)
   int pz = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
@@ -122,7 +144,14 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     Lin = lv < Lin ? (int)lv : Lin;
     if (t0 >= Lin) return;
   }
-  const float in_scale = P.in_scale, slope = P.slope;
+  float in_scale = P.in_scale;
+  const float slope = P.slope;
+  float acc_scale = 1.f;                           // NP = 2: 1 / (S_w S_x), applied to the accumulators in the epilogue
+  if constexpr (NP == 2) {
+    const unsigned ex = x3_scale_exp(*P.xmax);     // S_x from the input tensor's max |x| (wave-uniform: scalar loads)
+    in_scale *= x3_scale(ex);
+    acc_scale = x3_scale_inv(ex) * *P.w3inv;
+  }
   const bool lrelu = P.pre_act == PRE_LRELU;
   const float* const x0p = P.x[0] + (int64_t)b * P.x_bstride;
   const float* const maskp = P.in_mask ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
@@ -144,7 +173,9 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   // The ring holds TWO taps per group — slot [g][(j + par) & 1] for tap j, par = parity of the taps consumed before this chunk — so a
   // unit is requested 2*GR - 1 units (>= 1150 MFMA cycles) before its first MFMA: with one slot per group (the fp32 kernel's ring, one
   // unit = 384 cycles ahead here) a workgroup alone on its CU (C = 256 at batch 1: 288 workgroups) spent 980 cycles per 384-cycle unit.
-  xbf16x8 ar[GR][2][MI][3];
+  typedef typename std::conditional<NP == 2, xf16x8, xbf16x8>::type frag_t;
+  typedef __attribute__((address_space(1))) frag_t GlobalFragT;
+  frag_t ar[GR][2][MI][NP];
   const uint16_t* wq[GR][MI];
   const unsigned wlane = 16u * (unsigned)lane;
 #pragma unroll
@@ -152,7 +183,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     int mt = (m0 >> 5) + wm * MI + mi;
     mt = mt * 32 < P.cout_pad ? mt : (m0 >> 5);   // rows beyond the problem: any valid tile (results are dropped)
 #pragma unroll
-    for (int g = 0; g < GR; ++g) wq[g][mi] = P.w6 + ((int64_t)mt * groups + g) * k * X6_UNIT;
+    for (int g = 0; g < GR; ++g) wq[g][mi] = (NP == 2 ? P.w3 : P.w6) + ((int64_t)mt * groups + g) * k * X6_UNIT;
   }
   const int last_step = ((GR - 1) * k + 1) * X6_UNIT;             // elements from (g, k-1) to (g, 0) of the next chunk
   const int wrap_step = -(((nchunks - 1) * GR * k + (k - 1)) * X6_UNIT);   // from (g, k-1) of the last chunk back to (g, 0) of the first
@@ -165,8 +196,8 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        ar[g][SL][mi][p] = *(const XGlobalFrag*)(reinterpret_cast<const char*>(wq[g][mi]) + wlane + 1024u * (unsigned)p);
+      for (int p = 0; p < NP; ++p)
+        ar[g][SL][mi][p] = *(const GlobalFragT*)(reinterpret_cast<const char*>(wq[g][mi]) + wlane + 1024u * (unsigned)p);
       wq[g][mi] += step;
     }
   };
@@ -216,6 +247,13 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
           a = (lrelu && a < 0.f) ? an : a;
           bq = (lrelu && bq < 0.f) ? bn : bq;
           a *= sc; bq *= sc;
+          if constexpr (NP == 2) {
+            // |a| < 2^15 (sc carries S_x): g0 = fp16(a), g1 = fp16(a - g0); the remainder is exact in fp32
+            const unsigned u1 = x3_pack(a, bq);
+            const xf32x2 f1 = x3_unpack(u1);
+            p1[w] = u1; p2[w] = x3_pack(a - f1[0], bq - f1[1]);
+            continue;
+          }
           // plane 1 saturates at the largest bf16 (x6_split, bv2_kernels.h): a finite value never rounds to +-inf, its remainder
           // a - h1 (< 2^120) is exact in planes 2 and 3; inf / NaN leave the clamp finite but their remainders are inf / NaN
           const unsigned u1 = x6_pack(__builtin_amdgcn_fmed3f(a, -X6_BF16_MAX, X6_BF16_MAX), __builtin_amdgcn_fmed3f(bq, -X6_BF16_MAX, X6_BF16_MAX));
@@ -227,7 +265,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
         unsigned short* dst = xs + buf * BUFSZ + (rg * 64 + lane) * PITCH + (sw + STW * o) * 8;
         *reinterpret_cast<xu32x4*>(dst) = p1;
         *reinterpret_cast<xu32x4*>(dst + PLANE) = p2;
-        *reinterpret_cast<xu32x4*>(dst + 2 * PLANE) = p3;
+        if constexpr (NP == 3) *reinterpret_cast<xu32x4*>(dst + 2 * PLANE) = p3;
       }
     }
   };
@@ -274,12 +312,12 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     if constexpr (NLD == 0) {
       if (next_chunk) issue_x(c + 1);             // in flight under this chunk's MFMAs
     }
-    xbf16x8 bb[2][NI][3];
+    frag_t bb[2][NI][NP];
     const unsigned short* xrow = xlane + (NLD > 0 ? (c & 1) * BUFSZ : 0);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bb[0][ni][p] = *reinterpret_cast<const xbf16x8*>(xrow + ni * 32 * PITCH + p * PLANE);
+      for (int p = 0; p < NP; ++p) bb[0][ni][p] = *reinterpret_cast<const frag_t*>(xrow + ni * 32 * PITCH + p * PLANE);
     // one tap: the GR units (g, j) from ring slots [g][SL]; each slot is refilled with the unit two taps further down its stream
     auto tap = [&](int j, int SL) __attribute__((always_inline)) {               // SL: a literal at every (inlined) call site
       const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;   // the chunk's last unit re-reads itself (unused)
@@ -296,21 +334,22 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-              bb[(g & 1) ^ 1][ni][p] = *reinterpret_cast<const xbf16x8*>(xn + ni * 32 * PITCH + p * PLANE);
+            for (int p = 0; p < NP; ++p)
+              bb[(g & 1) ^ 1][ni][p] = *reinterpret_cast<const frag_t*>(xn + ni * 32 * PITCH + p * PLANE);
         }
         // the six products, smallest first; consecutive MFMAs go to different accumulators
 #define X6_PROD(WP, XP)                                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                            \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                            \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[g][SL][mi][WP], bb[g & 1][ni][XP], acc[mi][ni], 0, 0, 0);
-        X6_PROD(2, 0) X6_PROD(1, 1) X6_PROD(0, 2) X6_PROD(1, 0) X6_PROD(0, 1) X6_PROD(0, 0)
+          acc[mi][ni] = x6_mfma(ar[g][SL][mi][WP], bb[g & 1][ni][XP], acc[mi][ni]);
+        if constexpr (NP == 3) { X6_PROD(2, 0) X6_PROD(1, 1) X6_PROD(0, 2) }
+        X6_PROD(1, 0) X6_PROD(0, 1) X6_PROD(0, 0)
 #undef X6_PROD
         load_unit(g, SL, step);
         // pin the emitted order: next unit's LDS reads first (they land under this unit's MFMAs), MFMAs, ring loads
         // emitted order: one LDS read (next unit's B) or one ring load behind every MFMA, so that they issue in the shadow of the
         // 32-cycle matrix op instead of in front of / behind the block of 12 (a lone wave per SIMD ran 530 ticks per 384-cycle unit)
-        constexpr int NM = MI * NI * 6, NDS = NI * 3, NVM = MI * 3;
+        constexpr int NM = MI * NI * (NP == 3 ? 6 : 3), NDS = NI * NP, NVM = MI * NP;
         static_assert(NM >= NDS + NVM, "one memory instruction per MFMA at most");
 #pragma unroll
         for (int q = 0; q < NDS; ++q) {
@@ -358,7 +397,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     const int cout = P.cout, Lout = L.L;
     const unsigned o_rs = (unsigned)P.out_rstride, o_ts = (unsigned)P.out_tstride, o_to = (unsigned)P.out_toff;
     float* const outb = P.out + (int64_t)b * P.out_bstride;
-    const float* const dummy = reinterpret_cast<const float*>(P.w6);
+    const float* const dummy = reinterpret_cast<const float*>(NP == 2 ? P.w3 : P.w6);
     const bool has_res = P.res_mode != RES_NONE;
     const float* const resb = has_res ? P.res + (int64_t)b * P.res_bstride : dummy;
     const float* const b1p = P.bias ? P.bias : dummy;
@@ -399,6 +438,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
         }
       }
     }
+    float vmx = 0.f;                                // max |v| over what this lane stores (ConvProb::omax)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;
@@ -411,14 +451,18 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
           const int dr = (r & 3) + 8 * (r >> 2);
           const float bsum = __uint_as_float(__float_as_uint(bs[mi][r]) & m_b1) + __uint_as_float(__float_as_uint(bs2[mi][r]) & m_b2);
           const float rr = __uint_as_float(__float_as_uint(rv[mi][ni][r]) & m_res);
-          const float pre = acc[mi][ni][r] + bsum;
+          const float pre = NP == 2 ? __builtin_fmaf(acc[mi][ni][r], acc_scale, bsum) : acc[mi][ni][r] + bsum;
           float v = ((relu && pre < 0.f) ? 0.f : pre) * fpre;        // a select, not v_max: a NaN accumulator stays NaN (as in conv_mfma.hip / torch.relu)
           v = rsub ? rr - v : v + rr;
           v *= fpost;
-          if (colok[ni] && row0 + dr < cout) outb[off0[mi][ni] + (unsigned)dr * o_rs] = v;
+          if (colok[ni] && row0 + dr < cout) {
+            outb[off0[mi][ni] + (unsigned)dr * o_rs] = v;
+            vmx = fmaxf(vmx, fabsf(v));
+          }
         }
       }
     }
+    if (P.omax) x6_absmax_publish(P.omax, vmx, lane);
   }
   if (L.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -432,7 +476,28 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   }
 }
 
+// max |x| of a tensor into a zeroed slot: for x3 inputs whose producer is not a conv launch (tests; the product's producers publish
+// from their epilogues)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, const int64_t n, unsigned* slot) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  x6_absmax_publish(slot, m, threadIdx.x & 63);
+}
+int launch_absmax(hipStream_t stream, const float* x, int64_t n, unsigned* slot) {
+  if (!x || !slot || n < 1) return -1;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream, x, n, slot);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
+// the two-plane fp16 form: every problem carries its planes, their scale and the slot with its input's max |x|
+static bool conv_x3_ready(const ConvLaunch& L) {
+  for (int i = 0; i < L.nprob; ++i)
+    if (!L.p[i].w3 || !L.p[i].w3inv || !L.p[i].xmax) return false;
+  return true;
+}
+
 bool conv_x6_supported(const ConvLaunch& L) {
   if (L.nprob < 1 || L.ksplit > 1) return false;
   for (int i = 0; i < L.nprob; ++i) {
@@ -445,9 +510,11 @@ bool conv_x6_supported(const ConvLaunch& L) {
 
 // tuning experiments (tools/tune_x6.py through bv2_test_set_x6_tuning): forced tile per C_out class and chunk size; 0 = shipped choice
 static int g_x6_tile[3] = {0, 0, 0};
+static bool g_x3_off = false;                     // A/B: the three-plane form although the x3 operands are there
+void conv_x3_set_off(bool off) { g_x3_off = off; }
 void conv_x6_set_tuning(int t256, int t128, int t64, int) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; }
 
-template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD = 0>
+template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD = 0, int NP = 3>
 static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_cout_pad) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   const int mtiles = (max_cout_pad + BM - 1) / BM;
@@ -475,8 +542,8 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
     for (int i = 0; i < Ls.nprob && i < 3; ++i) ks |= (Ls.p[i].k & 255) << (8 * i);
     Ls.dbg = timeline_slice(grid.x, grid.y, grid.z, 6000000 + BM * 1000 + BN, ks, Ls.p[0].cin, Ls.L);
   }
-  const size_t lds = (size_t)(NLD > 0 ? 2 : 1) * 3 * XR * (CK + 8) * 2;
-  auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR, NLD>;
+  const size_t lds = (size_t)(NLD > 0 ? 2 : 1) * NP * XR * (CK + 8) * 2;
+  auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR, NLD, NP>;
   ensure_dyn_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + NLD)), lds, stream, Ls, mtiles, per_xcd, snake_n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -504,6 +571,7 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
   int max_cout_pad = 0;
   for (int i = 0; i < L.nprob; ++i)
     if (L.p[i].cout_pad > max_cout_pad) max_cout_pad = L.p[i].cout_pad;
+  if (tile == TILE_X3) tile = TILE_X6;
   if (tile == TILE_X6) {
     const int cls = max_cout_pad % 256 == 0 ? 0 : (max_cout_pad % 128 == 0 ? 1 : 2);
     if (g_x6_tile[cls]) tile = g_x6_tile[cls];
@@ -519,12 +587,15 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
   // round 3 (tools/tune_x6.py, profiles/r03_tune_x6_*.txt): 64-channel chunks (229 registers, two workgroups per CU: Generator pass
   // 2.11 against 1.97 ms), wave tiles 64x64 as 128x128 / 256x64 / 64x256 workgroups and 32x128 (all within +-2 % at B = 8, slower at
   // B = 1), and an eight-wave form with K split over two wave sets for the 288-workgroup launches of the C = 256 stage (no change).
+  const bool x3 = !g_x3_off && conv_x3_ready(L);  // the two-plane fp16 form where the tile has one (the 128-row tiles)
   switch (tile) {
     case TILE_X6_128x64:                          // all four waves on the same 64 columns, one 32-row block each
-      if (variant_name) *variant_name = "conv1d_x6<128x64>";
+      if (variant_name) *variant_name = x3 ? "conv1d_x3<128x64>" : "conv1d_x6<128x64>";
+      if (x3) return launch_x6_variant<4, 1, 1, 2, 32, 128, 0, 2>(stream, L, max_cout_pad);
       return launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
     case TILE_X6_128x64_LD:                       // the same tile with two loader waves and two X buffers
-      if (variant_name) *variant_name = "conv1d_x6<128x64,ld>";
+      if (variant_name) *variant_name = x3 ? "conv1d_x3<128x64,ld>" : "conv1d_x6<128x64,ld>";
+      if (x3) return launch_x6_variant<4, 1, 1, 2, 32, 128, 2, 2>(stream, L, max_cout_pad);
       return launch_x6_variant<4, 1, 1, 2, 32, 128, 2>(stream, L, max_cout_pad);
     case TILE_X6_64x128:                          // 2 x 2 waves
       if (variant_name) *variant_name = "conv1d_x6<64x128>";

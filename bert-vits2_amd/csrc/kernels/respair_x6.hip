@@ -26,7 +26,24 @@ typedef __bf16 pxbf16x2 __attribute__((ext_vector_type(2)));
 typedef float pxf32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned pxu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned pxu32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) pxbf16x8 PxGlobalFrag;
+typedef _Float16 pxf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pxf16x2 __attribute__((ext_vector_type(2)));
+typedef float pxf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pxf32x16 px_mfma(pxbf16x8 a, pxbf16x8 b, pxf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ pxf32x16 px_mfma(pxf16x8 a, pxf16x8 b, pxf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// the x3 form (bv2_kernels.h): the two fp16 halves of a pair of SCALED values (|a|, |b| < 2^15), round-to-nearest-even
+__device__ __forceinline__ void px_split2h(float a, float b, unsigned& u1, unsigned& u2) {
+  const pxf16x2 g = __builtin_convertvector((pxf32x2){a, b}, pxf16x2);
+  const pxf32x2 f = __builtin_convertvector(g, pxf32x2);
+  u1 = __builtin_bit_cast(unsigned, g);
+  u2 = __builtin_bit_cast(unsigned, __builtin_convertvector((pxf32x2){a - f[0], b - f[1]}, pxf16x2));
+}
+// workgroup-wide max of a per-thread magnitude: wave butterflies, one float per wave through `red` (the caller's barrier in between)
+__device__ __forceinline__ void px_wave_max_to(float* red, int wid, int lane, float m) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if (lane == 0) red[wid] = m;
+}
 
 __device__ __forceinline__ float px_ld(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -48,7 +65,6 @@ __device__ __forceinline__ void px_split2(float a, float b, unsigned& u1, unsign
   u3 = px_pack(a, b);
 }
 
-constexpr int PX_UNIT = 3 * 512;          // elements of one (group, tap) unit: 3 planes x 64 lanes x 8
 
 }  // namespace
 
@@ -58,9 +74,15 @@ constexpr int PX_UNIT = 3 * 512;          // elements of one (group, tap) unit: 
 // The 16-channel groups run in passes of two (conv_x6's 32-channel chunks: the layer-wise kernel's fp32 summation order) through a
 // ring of 2 groups x 2 taps whose streams jump from one pass's groups to the next's — the registers do not grow with C.
 //   C = 16 : 1 x 4 waves, HT 256,  46 KB, three per CU: ONE 16-channel group (passes of one), the upper half of the 32-row block is padding
-template <int PX_C, int WNT>
+// NP = 2: the "x3" form (bv2_kernels.h) — two scaled fp16 planes per operand, three products.  The activation scales are the
+// WORKGROUP's own: S_x from the max |x| of the tile it staged, S_h from the max |h| of the tile it computed (one float per wave
+// through LDS; x costs one more barrier, h rides on the existing one), so a quiet stretch of audio keeps its own 2^15 of range.
+template <int PX_C, int WNT, int NP = 3>
 __global__ void __launch_bounds__((PX_C >= 32 ? PX_C / 32 : 1) * WNT * 64, PX_C <= 32 ? 2 : 1)
 respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
+  constexpr int PX_UNIT = NP * 512;               // elements of one (group, tap) unit: NP planes x 64 lanes x 8
+  typedef typename std::conditional<NP == 2, pxf16x8, pxbf16x8>::type frag_t;
+  typedef __attribute__((address_space(1))) frag_t GlobalFragT;
   constexpr int NI = 2, PX_HT = 64 * WNT, PX_XR = PX_HT + 64, NRG = PX_XR / 64;
   constexpr int MB = PX_C >= 32 ? PX_C / 32 : 1;  // 32-row blocks
   constexpr int NW = MB * WNT;                    // waves
@@ -74,7 +96,8 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
   constexpr int GPP = PX_C >= 32 ? 2 : 1;         // 16-channel groups per pass
   constexpr int NPASS = PX_C / 16 / GPP;          // passes
   constexpr int NJ = PX_C >= 32 ? 4 : PX_C / 8;   // 8-channel sub-blocks of a row block that exist
-  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [3][XR][PITCH]: x planes, then h planes
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [NP][XR][PITCH]: x planes, then h planes; NP = 2: + 2 x NW floats
+  float* const red = reinterpret_cast<float*>(xs + NP * PX_PLANE);       // NP = 2 only: the waves' max |x| (first NW), max |h| (next NW)
   const FusedProb P = L.p[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,12 +125,12 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
 
   // ---- weight ring (conv_x6.hip): ring group gl carries group 2 c + gl of pass c through its k taps (two slots: taps j, j + 1), then
   // jumps to the next pass's group; k is odd, so pass c starts at slot parity c & 1
-  pxbf16x8 ar[GPP][2][3];
+  frag_t ar[GPP][2][NP];
   const uint16_t* wq[GPP];
   auto load_unit = [&](int gl, int SL, int step) __attribute__((always_inline)) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      ar[gl][SL][p] = *(const PxGlobalFrag*)(reinterpret_cast<const char*>(wq[gl]) + wlane + 1024u * (unsigned)p);
+    for (int p = 0; p < NP; ++p)
+      ar[gl][SL][p] = *(const GlobalFragT*)(reinterpret_cast<const char*>(wq[gl]) + wlane + 1024u * (unsigned)p);
     wq[gl] += step;
   };
   const int last_step = ((GPP - 1) * k + 1) * PX_UNIT;                  // from (g, k-1) to (g + GPP, 0)
@@ -124,7 +147,8 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
 #pragma unroll
     for (int gl = 0; gl < GPP; ++gl) { load_unit(gl, 1, s1); __builtin_amdgcn_sched_barrier(0); }
   };
-  prime(P.w61);
+  prime(NP == 2 ? P.w31 : P.w61);
+  float s1 = 1.f;                                 // NP = 2: 1 / (S_w1 S_x), the scale of conv1's accumulators
 
   // ---- stage x: wave `wid` loads channel octet `wid` of every 64-column group (lane = column), lrelu, split, channels-last planes
   {
@@ -149,6 +173,26 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
         for (int e = 0; e < 8; ++e) xr[i][o][e] = px_ld(x0p, row0 + (unsigned)e * x_rs4 + tc);
       }
     }
+    if constexpr (NP == 2) {
+      // S_x: |lrelu(x)| <= |x|, so the tile's max |x| over the valid columns bounds every staged value
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < NRGW; ++i)
+#pragma unroll
+        for (int o = 0; o < OPW; ++o)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(xr[i][o][e]) * colsc[i]);
+      px_wave_max_to(red, wid, lane, mx);
+      __syncthreads();
+      float M = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
+      const unsigned ex = x3_scale_exp(__float_as_uint(M));
+      const float Sx = x3_scale(ex);
+      s1 = x3_scale_inv(ex) * *P.w3inv1;
+#pragma unroll
+      for (int i = 0; i < NRGW; ++i) colsc[i] *= Sx;
+    }
 #pragma unroll
     for (int i = 0; i < NRGW; ++i) {
       const int rg = rg0 + CGS * i;
@@ -162,15 +206,16 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
           a = a < 0.f ? an : a;
           bq = bq < 0.f ? bn : bq;
           a *= colsc[i]; bq *= colsc[i];
-          unsigned u1, u2, u3;
-          px_split2(a, bq, u1, u2, u3);
+          unsigned u1, u2, u3 = 0;
+          if constexpr (NP == 2) px_split2h(a, bq, u1, u2);
+          else px_split2(a, bq, u1, u2, u3);
           q1[w] = u1; q2[w] = u2; q3[w] = u3;
         }
         if (CGS == 1 || rg < NRG) {
           unsigned short* dst = xs + (rg * 64 + lane) * PX_PITCH + (oct0 + NW * o) * 8;
           *reinterpret_cast<pxu32x4*>(dst) = q1;
           *reinterpret_cast<pxu32x4*>(dst + PX_PLANE) = q2;
-          *reinterpret_cast<pxu32x4*>(dst + 2 * PX_PLANE) = q3;
+          if constexpr (NP == 3) *reinterpret_cast<pxu32x4*>(dst + 2 * PX_PLANE) = q3;
         }
       }
     }
@@ -186,15 +231,15 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
 
   // one GEMM over the tile in LDS: acc[ni] += sum over (pass c, tap j, group gl of the pass) of the six cross products (conv_x6.hip's unit)
   auto gemm = [&](int tap_step) __attribute__((always_inline)) {
-    pxbf16x8 bb[2][NI][3];
+    frag_t bb[2][NI][NP];
     auto pass = [&](int c, int PAR) __attribute__((always_inline)) {              // PAR: a literal at every (inlined) call site
       const unsigned short* xrow = xlane + c * (16 * GPP);
       // B double buffer: alternates with the group inside a tap (two groups per pass) or with the tap's ring slot (one group per pass)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          bb[GPP == 2 ? 0 : PAR][ni][p] = *reinterpret_cast<const pxbf16x8*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
+        for (int p = 0; p < NP; ++p)
+          bb[GPP == 2 ? 0 : PAR][ni][p] = *reinterpret_cast<const frag_t*>(xrow + ni * 32 * PX_PITCH + p * PX_PLANE);
       auto tap = [&](int j, int SL) __attribute__((always_inline)) {
         const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;
         int jl = j + 2, cl = c;                     // the unit loaded during this tap: tap jl of pass cl (branch-free wrap)
@@ -209,16 +254,17 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-              for (int p = 0; p < 3; ++p)
-                bb[cur ^ 1][ni][p] = *reinterpret_cast<const pxbf16x8*>(xn + ni * 32 * PX_PITCH + p * PX_PLANE);
+              for (int p = 0; p < NP; ++p)
+                bb[cur ^ 1][ni][p] = *reinterpret_cast<const frag_t*>(xn + ni * 32 * PX_PITCH + p * PX_PLANE);
           }
 #define PX_PROD(WP, XP)                                                                                              \
           _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                          \
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[gl][SL][WP], bb[cur][ni][XP], acc[ni], 0, 0, 0);
-          PX_PROD(2, 0) PX_PROD(1, 1) PX_PROD(0, 2) PX_PROD(1, 0) PX_PROD(0, 1) PX_PROD(0, 0)
+            acc[ni] = px_mfma(ar[gl][SL][WP], bb[cur][ni][XP], acc[ni]);
+          if constexpr (NP == 3) { PX_PROD(2, 0) PX_PROD(1, 1) PX_PROD(0, 2) }
+          PX_PROD(1, 0) PX_PROD(0, 1) PX_PROD(0, 0)
 #undef PX_PROD
           load_unit(gl, SL, step);
-          constexpr int NM = NI * 6, NDS = NI * 3, NVM = 3;
+          constexpr int NM = NI * (NP == 3 ? 6 : 3), NDS = NI * NP, NVM = NP;
 #pragma unroll
           for (int q = 0; q < NDS; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -244,11 +290,38 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
   gemm(dil * PX_PITCH);
 
   // ---- h = lrelu(conv1 + b1), zero outside [0, L) (conv2's padding), split into its planes, written over the x planes
-  prime(P.w62);
+  prime(NP == 2 ? P.w32 : P.w62);
   float b1v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) b1v[r] = P.b1[wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
+  float s2 = 1.f, Sh = 1.f;                       // NP = 2: 1 / (S_w2 S_h) for conv2's accumulators, S_h for the h planes
+  if constexpr (NP == 2) {
+    // h in place of the accumulators (fp32), its max through LDS on the barrier that frees the x planes
+    float mh = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int th = t0 - p2 + wn * 64 + ni * 32 + l31;
+      const float ok = (th >= 0 && th < Lin) ? 1.f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4 * NJ; ++r) {
+        float t = __builtin_fmaf(acc[ni][r], s1, b1v[r]);
+        const float tn = t * slope;
+        t = t < 0.f ? tn : t;
+        acc[ni][r] = t * ok;
+        mh = fmaxf(mh, fabsf(acc[ni][r]));
+      }
+    }
+    px_wave_max_to(red + NW, wid, lane, mh);
+  }
   __syncthreads();                                // every wave is done reading the x planes
+  if constexpr (NP == 2) {
+    float M = red[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, red[NW + w]);
+    const unsigned eh = x3_scale_exp(__float_as_uint(M));
+    Sh = x3_scale(eh);
+    s2 = x3_scale_inv(eh) * *P.w3inv2;
+  }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int hc = wn * 64 + ni * 32 + l31;       // column of h: time t0 - p2 + hc
@@ -260,17 +333,18 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if constexpr (NP == 2) { v[i] = acc[ni][4 * j + i] * Sh; continue; }
         float t = acc[ni][4 * j + i] + b1v[4 * j + i];
         const float tn = t * slope;
         t = t < 0.f ? tn : t;
         v[i] = t * ok;
       }
-      unsigned a1, a2, a3, c1, c2, c3;
-      px_split2(v[0], v[1], a1, a2, a3);
-      px_split2(v[2], v[3], c1, c2, c3);
+      unsigned a1, a2, a3 = 0, c1, c2, c3 = 0;
+      if constexpr (NP == 2) { px_split2h(v[0], v[1], a1, a2); px_split2h(v[2], v[3], c1, c2); }
+      else { px_split2(v[0], v[1], a1, a2, a3); px_split2(v[2], v[3], c1, c2, c3); }
       *reinterpret_cast<pxu32x2*>(dst + 8 * j) = pxu32x2{a1, c1};
       *reinterpret_cast<pxu32x2*>(dst + 8 * j + PX_PLANE) = pxu32x2{a2, c2};
-      *reinterpret_cast<pxu32x2*>(dst + 8 * j + 2 * PX_PLANE) = pxu32x2{a3, c3};
+      if constexpr (NP == 3) *reinterpret_cast<pxu32x2*>(dst + 8 * j + 2 * PX_PLANE) = pxu32x2{a3, c3};
     }
   }
 #pragma unroll
@@ -304,11 +378,14 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 4 * NJ; ++r) {           // rows (r & 3) + 8 (r >> 2) + 4 lh < C
-        const float v = (acc[ni][r] + b2v[r]) + rv[ni][r];
+        const float v = (NP == 2 ? __builtin_fmaf(acc[ni][r], s2, b2v[r]) : acc[ni][r] + b2v[r]) + rv[ni][r];
         if (colok[ni]) outb[off0[ni] + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L.L] = v;
       }
   }
 }
+
+static bool g_pair_x3_off = false;                // A/B (tests): the three-plane form although the x3 planes are there
+void respair_x3_set_off(bool off) { g_pair_x3_off = off; }
 
 bool respair_x6_supported(int C, int k, int dil) {
   if ((C != 16 && C != 32 && C != 64 && C != 128) || k < 3 || k % 2 == 0 || dil < 1) return false;
@@ -329,8 +406,27 @@ int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
     ntx = n > ntx ? n : ntx;
   }
   const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
-  const size_t lds = (size_t)3 * (HT + 64) * (F.C + 8) * 2;
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, F.B, F.nprob);
+  bool x3 = !g_pair_x3_off;                       // the two-plane fp16 form: every problem carries its planes and their scales
+  for (int i = 0; i < F.nprob; ++i) x3 = x3 && F.p[i].w31 && F.p[i].w32 && F.p[i].w3inv1 && F.p[i].w3inv2;
+  if (x3) {
+    const size_t lds3 = (size_t)2 * (HT + 64) * (F.C + 8) * 2 + 256;
+    if (F.C == 16) {
+      ensure_dyn_lds((const void*)respair_x6_kernel<16, 4, 2>, lds3);
+      hipLaunchKernelGGL((respair_x6_kernel<16, 4, 2>), grid, dim3(256), lds3, stream, F, per_xcd);
+    } else if (F.C == 32) {
+      ensure_dyn_lds((const void*)respair_x6_kernel<32, 4, 2>, lds3);
+      hipLaunchKernelGGL((respair_x6_kernel<32, 4, 2>), grid, dim3(256), lds3, stream, F, per_xcd);
+    } else if (F.C == 64) {
+      ensure_dyn_lds((const void*)respair_x6_kernel<64, 4, 2>, lds3);
+      hipLaunchKernelGGL((respair_x6_kernel<64, 4, 2>), grid, dim3(512), lds3, stream, F, per_xcd);
+    } else {
+      ensure_dyn_lds((const void*)respair_x6_kernel<128, 2, 2>, lds3);
+      hipLaunchKernelGGL((respair_x6_kernel<128, 2, 2>), grid, dim3(512), lds3, stream, F, per_xcd);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  const size_t lds = (size_t)3 * (HT + 64) * (F.C + 8) * 2;
   if (F.C == 16) {
     ensure_dyn_lds((const void*)respair_x6_kernel<16, 4>, lds);
     hipLaunchKernelGGL((respair_x6_kernel<16, 4>), grid, dim3(256), lds, stream, F, per_xcd);

@@ -30,7 +30,7 @@ extern "C" {
 
 #define BV2_ABI_VERSION 3   /* 3: bv2_decode_in.nz_tstride, the six ONNX-seam stage calls, bv2_detach_weights,
                                pack-layout version in the blob header */
-#define BV2_PACK_LAYOUT 15   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
+#define BV2_PACK_LAYOUT 16   /* bumped whenever bv2_model.cpp changes the order / format of anything inside the packed blob:
                                a blob cached on disk by an older packer is rejected by bv2_attach_weights */
 #define BV2_MAX_UPS 8
 #define BV2_MAX_RESBLOCK_KERNELS 4
@@ -261,6 +261,13 @@ void bv2_graph_destroy(bv2_graph* graph);
  *   "conv_x6"         the ResBlock convs of the fp32 Generator stages with C >= 32 on the bf16 matrix core: operands split exactly
  *                     into three bf16 planes, six cross products accumulated in fp32 — fp32 accuracy (dropped terms < 2^-23 of a
  *                     product) at 6/16 of the fp32-MFMA time (kernels/conv_x6.hip).  0: v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
+ *   "conv_x3"         those convs (layer-wise at C % 128 == 0, and the pair kernel of the narrower stages) on the TWO-plane fp16 form:
+ *                     operands scaled by powers of two into fp16's range and split into two fp16 halves, three cross products — the
+ *                     same order of error (dropped term <= 2^-24 of a product) at half the matrix work.  The activation scale comes
+ *                     from the data: max |x| of the whole input tensor, published by the launch that wrote it (layer-wise form), or of
+ *                     the workgroup's own tile (pair kernel), so an element more than 2^15 below that maximum keeps an absolute, not a
+ *                     relative, error (2^-40 of the maximum), and a non-finite input leaves the whole tensor non-finite or zero.
+ *                     0: the three-plane bf16 form above (exact splits, fp32's exponent range)
  *   "conv_x6_c32"     also the C = 32 stage layer-wise on conv_x6.hip (two launches per ResBlock pair, 44.6 us each at batch 1) instead
  *                     of the fused fp32-MFMA pair kernel (one launch, 110 us); 0: resblock_fused.hip.  Only consulted when the C = 32
  *                     stage is NOT on the split-bf16 pair kernel, i.e. together with "x6_pair" = 0 (the default runs respair_x6.hip there)

@@ -27,6 +27,11 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
 /* tile 8 = the split-bf16 form of the LDS-tiled kernel with its own tile choice (kernels/conv_x6.hip; cin % 32 == 0, nsrc == 1),
  * 9 / 10 / 11 / 12 = its 128x64 / 128x64-with-loader-waves / 64x128 / 32x256 workgroup tiles forced. */
 
+/* tile 14 = the two-plane fp16 form of the same kernel ("x3", bv2_kernels.h): tile 8's choice with the scaled fp16 planes, max |x|
+ * reduced into a slot by a launch in front.  For cin % 32 == 0 and ksplit <= 1 EVERY tile also publishes max |out| (ConvProb::omax)
+ * as fp32 bits at float offset bv2_test_x3_omax_off(cin, cout, k) of wpack_dev. */
+int64_t bv2_test_x3_omax_off(int cin, int cout, int k);
+
 /* v = h[0] + h[1] + h[2] exactly as bf16 bit patterns: the host-side split the packer applies to the x6 weight planes (host only) */
 void bv2_test_x6_split(float v, uint16_t* h3);
 /* where the packed blob holds x6 weight planes: float offset / float count of every region ([unit][plane 3][64 lanes][8] uint16); returns
@@ -67,6 +72,9 @@ int bv2_test_respair_cl(void* stream, const void* x, void* out, const float* w_h
  * [B][C][L], C = 16 / 32 / 64 / 128; the packer splits w_host into its three bf16 planes (x6_split) */
 int64_t bv2_test_respair_x6_pack_bytes(int C, int k);
 int bv2_test_respair_x6(void* stream, const float* x, float* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
+                        int C, int k, int dil, int L, float slope, const int64_t* lens);
+/* the same pair on the two-plane fp16 form ("x3": scaled fp16 halves, three products, per-workgroup activation scales); same arguments */
+int bv2_test_respair_x3(void* stream, const float* x, float* out, const float* w_host, const float* bias_host, void* wpack_dev, int B,
                         int C, int k, int dil, int L, float slope, const int64_t* lens);
 /* the flow's coupling boundary in one launch (kernels/flow_boundary.hip): h = LayerNorm_C(sum of nslab slabs a [B][C][T]) * mask;
  * x1 [C/2 rows][T] (inside z, z_bstride floats per item) = (x1 - post(h) - post_b) * mask in place; pre_out [B][C][T] = (pre(x1) + pre_b) *

@@ -28,6 +28,8 @@ def _lib():
     lib.bv2_test_respair_x6_pack_bytes.argtypes = [C.c_int] * 2
     lib.bv2_test_respair_x6.restype = C.c_int
     lib.bv2_test_respair_x6.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]
+    lib.bv2_test_respair_x3.restype = C.c_int
+    lib.bv2_test_respair_x3.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]
     lib.bv2_test_flow_boundary_pack_floats.restype = C.c_int64
     lib.bv2_test_flow_boundary_pack_floats.argtypes = [C.c_int]
     lib.bv2_test_flow_boundary.restype = C.c_int
@@ -96,7 +98,8 @@ def test_respair_cl_bf16_vs_fp64_with_the_same_rounding_points(C_, k, dil, L, B,
     (64, 3, 5, 260, 2, [260, 7]),
     (128, 7, 1, 200, 1, None),
 ])
-def test_respair_x6_vs_fp64(C_, k, dil, L, B, lens):
+@pytest.mark.parametrize("form", ["x6", "x3"])          # six bf16 products / three scaled-fp16 products (bv2_kernels.h): the same bars
+def test_respair_x6_vs_fp64(C_, k, dil, L, B, lens, form):
     lib = _lib()
     g = torch.Generator().manual_seed(C_ * 31 + k * 5 + dil + L)
     # operands spanning e^+-3 in scale per channel: a split-bf16 kernel that dropped a plane would show here
@@ -120,7 +123,8 @@ def test_respair_x6_vs_fp64(C_, k, dil, L, B, lens):
     wp = torch.empty(lib.bv2_test_respair_x6_pack_bytes(C_, k), dtype=torch.uint8, device="cuda")
     ld = None if lens_t is None else lens_t.cuda()
     xdev = x.cuda()
-    rc = lib.bv2_test_respair_x6(None, P(xdev), P(out), P(w.contiguous()), P(b.contiguous()), P(wp), B, C_, k, dil, L, 0.1, P(ld))
+    fn = lib.bv2_test_respair_x6 if form == "x6" else lib.bv2_test_respair_x3
+    rc = fn(None, P(xdev), P(out), P(w.contiguous()), P(b.contiguous()), P(wp), B, C_, k, dil, L, 0.1, P(ld))
     assert rc == 0, rc
     torch.cuda.synchronize()
     got = out.cpu().double()
@@ -131,7 +135,7 @@ def test_respair_x6_vs_fp64(C_, k, dil, L, B, lens):
     e6 = torch.where(vm, (got - ref).abs(), zero).amax(dim=(0, 2))          # (rows past the utterance are never written: NaN there)
     e32 = torch.where(vm, (ref32 - ref).abs(), zero).amax(dim=(0, 2))
     rowscale = torch.where(vm, ref.abs(), zero).amax(dim=(0, 2))
-    print(f"\n[C={C_} k={k} d={dil} L={L}] x6 pair max err / row scale {float((e6 / rowscale).max()):.2e}, fp32 evaluation {float((e32 / rowscale).max()):.2e}")
+    print(f"\n[C={C_} k={k} d={dil} L={L}] {form} pair max err / row scale {float((e6 / rowscale).max()):.2e}, fp32 evaluation {float((e32 / rowscale).max()):.2e}")
     # 2x the fp32 evaluation's error + a few fp32 ulps of the row's scale (the per-row maximum over a few hundred columns is a noisy
     # statistic); a dropped split plane would show as 2^-16 = 1.5e-5 of the scale
     assert bool((e6 <= 2.0 * e32 + 1e-6 * rowscale).all()), (e6 / rowscale, e32 / rowscale)

@@ -206,6 +206,7 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
     up2 = up // hp.upsample_rates[3]
     up1 = up2 // hp.upsample_rates[2]
     res = {}
+    m.set_option("conv_x3", 0)                               # layer-wise on the SIX-product form: that is what the pair kernel computes
     m.set_option("x6_pair_c16", 0)                           # the C = 16 stage has no layer-wise x6 form to be identical to: own test below
     for pair in (1, 0):
         m.set_option("x6_pair", pair)
@@ -224,6 +225,7 @@ def test_x6_pair_kernel_equals_the_two_layer_wise_x6_launches(B, Ty, lens):
     m.set_option("x6_pair", 1)
     m.set_option("x6_pair_c128", 0)
     m.set_option("x6_pair_c16", 1)
+    m.set_option("conv_x3", 1)
     # a stage of <= 4096 columns runs its layer-wise convs on the split-K fp32-MFMA kernel (small-N regime), not on conv_x6: there the
     # two paths agree to fp32 round-off, not bit for bit
     exact = B * Ty * up1 > 4096
@@ -278,3 +280,98 @@ def test_x6_pair_kernel_on_the_c16_stage_matches_the_fp32_mfma_pair_kernel(B, Ty
         assert e <= 5e-6 * scale + 1e-7 and (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), (k, e, scale)
     assert not torch.equal(res[1][0], res[0][0])             # the switch really changed the kernel
     assert (res[1][0] - res[0][0]).abs().max().item() <= 2e-5
+
+
+# ---- the two-plane fp16 form ("x3": three products from scaled fp16 halves; bv2_kernels.h) -------------------------------------------
+X3_CASES = [
+    # B, cin, cout, k, dil, L          (cout % 128 == 0: the tiles that have the form)
+    (1, 128, 128, 11, 5, 517), (1, 256, 256, 3, 1, 129), (1, 128, 128, 1, 1, 200), (2, 128, 128, 7, 5, 1000), (1, 256, 256, 11, 1, 3072),
+    (1, 96, 128, 5, 2, 333), (3, 32, 256, 7, 1, 130), (6, 64, 256, 3, 3, 12000),                # the last: > 2048 workgroups = the form without loader waves
+]
+
+
+def _omax(lib, wp, cin, cout, k):
+    lib.bv2_test_x3_omax_off.restype = __import__("ctypes").c_int64
+    lib.bv2_test_x3_omax_off.argtypes = [__import__("ctypes").c_int] * 3
+    return wp[lib.bv2_test_x3_omax_off(cin, cout, k)].item()
+
+
+def _run_wp(lib, x, w, bias, tile, k, dil, **kw):
+    B, cin, L = x.shape
+    cout = w.shape[0]
+    out = torch.full((B, cout, L), float("nan"), device="cuda")
+    wp = torch.empty(lib.bv2_test_conv_pack_floats(cin, cout, k), device="cuda")
+    rc = lib.bv2_test_conv1d(None, P(x), P(w), P(bias), P(out), P(wp), B, cin, cout, k, dil, -1, L, tile, kw.get("lrelu", 0.0), kw.get("relu", 0),
+                             P(kw.get("res")), kw.get("res_mode", 0), P(kw.get("in_mask")), P(kw.get("out_mask")), kw.get("mask_pre", 0),
+                             kw.get("mask_post", 0), P(kw.get("bias2")), 1, None, None, 1.0, 1, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out, wp
+
+
+@pytest.mark.parametrize("B,cin,cout,k,dil,L", X3_CASES)
+def test_conv1d_x3_is_as_accurate_as_the_fp32_mfma_kernel(B, cin, cout, k, dil, L):
+    """Same claim, same inputs (rows / channels e^+-2..4 apart in scale) and same bars as the six-product form."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k + L)
+    x = torch.randn(B, cin, L, generator=g) * torch.exp(2.0 * torch.randn(B, cin, 1, generator=g))
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k) * torch.exp(torch.randn(cout, 1, 1, generator=g))
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv1d(x.double(), w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil)
+    xd = x.cuda()
+    y3, wp = _run_wp(lib, xd, w, bias, 14, k, dil)
+    y32 = _run(lib, xd, w, bias, 3, k, dil)
+    e3, e32 = rel_err(y3, ref), rel_err(y32, ref)
+    assert e3 < 2e-5
+    assert e3 <= 2.0 * e32 + 2e-7, (e3, e32)
+    scale = ref.abs().amax(dim=2, keepdim=True).clamp_min(1e-30)
+    r3 = ((y3.double().cpu() - ref).abs() / scale).max().item()
+    r32 = ((y32.double().cpu() - ref).abs() / scale).max().item()
+    assert r3 <= 2.0 * r32 + 3e-7, (r3, r32)
+    # the epilogue published max |out| for the next conv's scale: exactly the largest stored magnitude
+    assert _omax(lib, wp, cin, cout, k) == y3.abs().max().item()
+
+
+@pytest.mark.parametrize("tile", [3, 4, 6, 9, 10])
+def test_every_conv_kernel_publishes_max_abs_out(tile):
+    """ConvProb::omax on the producers of an x3 input: the LDS-tiled fp32 kernel, the split-K kernel (ksplit = 1) and the x6 tiles."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(tile)
+    B, cin, cout, k, dil, L = 2, 64, 128, 3, 2, 211
+    x, w, bias = torch.randn(B, cin, L, generator=g), torch.randn(cout, cin, k, generator=g), torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, L, generator=g).cuda()
+    out, wp = _run_wp(lib, x.cuda(), w, bias, tile, k, dil, lrelu=0.1, res=res, res_mode=1)
+    assert _omax(lib, wp, cin, cout, k) == out.abs().max().item()
+
+
+def test_conv1d_x3_fused_epilogues_and_small_elements():
+    """The x6 epilogue test on the x3 form, and the envelope of the per-tensor scale: elements 2^-20 of the tensor's largest keep full
+    relative accuracy in the result rows they dominate; a tensor of zeros gives exactly the bias."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(3)
+    B, cin, cout, k, dil, L = 2, 64, 128, 5, 2, 333
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias, bias2 = torch.randn(cout, generator=g), torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, L, generator=g)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, L - 57])[:, None]).float()
+    xin = F.leaky_relu(x.double(), 0.1) * mask[:, None].double()
+    y = F.conv1d(xin, w.double(), bias.double(), padding=(k - 1) // 2 * dil, dilation=dil) + bias2[:, :, None].double()
+    y = torch.relu(y) * mask[:, None].double()
+    xd, rd, md, b2 = x.cuda(), res.cuda(), mask.cuda(), bias2.cuda()
+    for res_mode, ref in ((1, (y + res.double()) * mask[:, None].double()), (2, (res.double() - y) * mask[:, None].double())):
+        out, _ = _run_wp(lib, xd, w, bias, 14, k, dil, lrelu=0.1, relu=1, res=rd, res_mode=res_mode, in_mask=md, out_mask=md, mask_pre=1,
+                         mask_post=1, bias2=b2)
+        assert rel_err(out, ref) < 2e-5
+    # one loud item, one quiet item (2^-20 of it) in the same tensor: the quiet item's outputs are still fp32-accurate relative to themselves
+    x2 = torch.randn(2, cin, L, generator=g)
+    x2[1] *= 2.0 ** -20
+    ref = F.conv1d(x2.double(), w.double(), None, padding=(k - 1) // 2 * dil, dilation=dil)
+    out, _ = _run_wp(lib, x2.cuda(), w, None, 14, k, dil)
+    y32 = _run(lib, x2.cuda(), w, None, 3, k, dil)
+    for b in range(2):
+        e3, e32 = rel_err(out[b], ref[b]), rel_err(y32[b], ref[b])
+        assert e3 <= 2.0 * e32 + (2e-7 if b == 0 else 4e-6), (b, e3, e32)          # quiet item: 2^-20 * 2^15 = 2^-5 after scaling -> ~18 bits
+    z = torch.zeros(B, cin, L)
+    outz, _ = _run_wp(lib, z.cuda(), w, bias, 14, k, dil)
+    assert torch.equal(outz.cpu(), bias[None, :, None].expand(B, cout, L))
