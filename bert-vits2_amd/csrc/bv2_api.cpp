@@ -509,7 +509,7 @@ int64_t bv2_test_conv_pack_floats(int cin, int cout, int k) {
   const int64_t base = (int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048;
   // + the x3 form's region (tile == TILE_X3): two 64-float slots (max |x| in, max |out| back), 1 / S_w, the two fp16 planes
   return base + (cin % 32 == 0 ? (x6_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 +
-                                 128 + X3_HDR_FLOATS + (x3_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 : 0);
+                                 2 * X3_SLOT_WORDS + X3_HDR_FLOATS + (x3_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 : 0);
 }
 void bv2_test_x6_split(float v, uint16_t* h3) { x6_split(v, h3); }
 int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_floats, int max_regions) {
@@ -531,10 +531,10 @@ static int64_t t_x6_off(int cin, int cout, int k) {
   return ((int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048 + 63) / 64 * 64;
 }
 
-static int64_t t_x3_off(int cin, int cout, int k) {                 // the x3 region: [slot in (64)] [slot out (64)] [1 / S_w (64)] [planes]
+static int64_t t_x3_off(int cin, int cout, int k) {                 // the x3 region: [slot in] [slot out] (X3_SLOT_WORDS each) [1 / S_w (64)] [planes]
   return (t_x6_off(cin, cout, k) + (x6_w_elems(cin, t_round_up(cout, 32), k) + 1) / 2 + 64 + 63) / 64 * 64;
 }
-int64_t bv2_test_x3_omax_off(int cin, int cout, int k) { return t_x3_off(cin, cout, k) + 64; }
+int64_t bv2_test_x3_omax_off(int cin, int cout, int k) { return t_x3_off(cin, cout, k) + X3_SLOT_WORDS; }
 
 int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const float* bias_host, float* out, float* wpack_dev,
                     int B, int cin, int cout, int k, int dil, int pad_left, int L, int tile, float lrelu_slope, int relu,
@@ -571,8 +571,8 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
       std::memcpy(&mb, &wmax, 4);
       const unsigned e = x3_scale_exp(mb);
       float* reg = pk.data() + t_x3_off(cin, cout, k);
-      reg[128] = x3_scale_inv(e);
-      uint16_t* wy = reinterpret_cast<uint16_t*>(reg + 128 + X3_HDR_FLOATS);
+      reg[2 * X3_SLOT_WORDS] = x3_scale_inv(e);
+      uint16_t* wy = reinterpret_cast<uint16_t*>(reg + 2 * X3_SLOT_WORDS + X3_HDR_FLOATS);
       for (int j = 0; j < k; ++j)
         for (int ci = 0; ci < cin; ++ci)
           for (int co = 0; co < cout; ++co) {
@@ -591,12 +591,12 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
       // every kernel's max |out| lands in the region's second slot (bv2_test_x3_omax_off); the x3 form reads max |x| from the first: the
       // product's producers publish it from their epilogues, here a reduction launch fills the (zeroed) slot
       float* reg = wpack_dev + t_x3_off(cin, cout, k);
-      if (hipMemsetAsync(reg, 0, sizeof(float) * 128, static_cast<hipStream_t>(stream)) != hipSuccess) return -6;
-      p.omax = reinterpret_cast<unsigned*>(reg + 64);
+      if (hipMemsetAsync(reg, 0, sizeof(float) * 2 * X3_SLOT_WORDS, static_cast<hipStream_t>(stream)) != hipSuccess) return -6;
+      p.omax = reinterpret_cast<unsigned*>(reg + X3_SLOT_WORDS);
       if (x3) {
         if (nsrc != 1 || launch_absmax(static_cast<hipStream_t>(stream), x, (int64_t)B * cin * L, reinterpret_cast<unsigned*>(reg))) return -2;
         p.xmax = reinterpret_cast<const unsigned*>(reg);
-        p.w3inv = reg + 128; p.w3 = reinterpret_cast<const uint16_t*>(reg + 128 + X3_HDR_FLOATS);
+        p.w3inv = reg + 2 * X3_SLOT_WORDS; p.w3 = reinterpret_cast<const uint16_t*>(reg + 2 * X3_SLOT_WORDS + X3_HDR_FLOATS);
       }
     }
     p.x[0] = x; p.x[1] = x1; p.x[2] = x2; p.nsrc = nsrc; p.in_scale = in_scale;

@@ -393,7 +393,7 @@ PlanA plan_a(Arena& A, const Model& m, int B, int T) {
   return p;
 }
 
-constexpr int kX3Slots = 512;          // >= BV2_MAX_UPS * (1 + 2 * BV2_MAX_RESBLOCK_KERNELS * BV2_MAX_RESBLOCK_DILATIONS) = 264
+constexpr int kX3Slots = 264;          // = BV2_MAX_UPS * (1 + 2 * BV2_MAX_RESBLOCK_KERNELS * BV2_MAX_RESBLOCK_DILATIONS), 1 KB each
 struct PlanB {
   float *gv, *zp, *z, *h, *acts, *outacc, *pre, *ymask;
   int* fidx;
@@ -421,7 +421,7 @@ PlanB plan_b(Arena& A, const Model& m, int B, int Ty) {
                 (c.use_transformer_flow ? m.n_coupling * (int)H : m.n_coupling * 2 * (int)H * c.n_flow_layer);
   p.gv = A.get<float>((int64_t)B * p.gv_stride);
   p.fidx = A.get<int>(BT);
-  p.xslots = A.get<unsigned>(kX3Slots);
+  p.xslots = A.get<unsigned>((int64_t)kX3Slots * X3_SLOT_WORDS);
   p.ymask = A.get<float>(BT);
   p.len_cap = A.get<int64_t>(B);
   p.zp = A.get<float>(BT * c.inter_channels);
@@ -855,20 +855,39 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
   // x3 form of the wide-stage convs (conv_x6.hip, two scaled fp16 planes): every conv input needs the slot its producer's epilogue
   // filled with max |x|; the slots of one decode are distinct and zeroed here
   int next_slot = 0;
-  bool any_x3 = false;
+  int n_slots = 0;                                // slots this decode can use: stages with 128-row tiles
   for (int i = 0; i < m.n_ups && !c.h->no_conv_x3 && !c.h->no_conv_x6; ++i)
-    if (m.rb[i][0][0][0].wy_off >= 0) any_x3 = true;
-  if (any_x3 && !c.rc && hipMemsetAsync(P.xslots, 0, sizeof(unsigned) * kX3Slots, c.s) != hipSuccess) c.chk(-1, "dec.x3_slots");
+    if (m.ups[i].cout % 128 == 0 && m.rb[i][0][0][0].wy_off >= 0) n_slots += 1 + 2 * m.n_rbk * m.n_rbd;
+  const bool any_x3 = n_slots > 0;
+  if (any_x3 && !c.rc && hipMemsetAsync(P.xslots, 0, sizeof(unsigned) * X3_SLOT_WORDS * n_slots, c.s) != hipSuccess) c.chk(-1, "dec.x3_slots");
   for (int i = 0; i < m.n_ups; ++i) {
     const UpW& U = m.ups[i];
     float* const* S = P.set[i & 1];
     float* x = S[0];
     const int Lo = Lc * U.u;
     const int nb = m.n_rbk;
-    bool x3 = any_x3;                             // (a stage that takes a fused path below just leaves its slots unread)
+    // the n_rbk ResBlock1 branches run side by side
+    const bool rb2 = m.rb_type == 2;
+    bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock && !rb2;
+    // C = 32: two split-bf16 launches per pair (HBM-bound, 5 tensor passes) against one fused fp32-MFMA launch (MFMA-bound, 3 passes)
+    // C = 32 with the planes packed: the pair in ONE launch on the bf16 matrix core (respair_x6.hip: two passes AND the fast pipe)
+    bool x6pair = !rb2 && nb <= 3 && !c.h->no_fused_resblock && !c.h->no_conv_x6 && !c.h->no_x6_pair &&
+                  (U.cout == 32 || (U.cout == 16 && !c.h->no_x6_pair_c16) || (U.cout == 64 && !c.h->no_x6_pair_c64) ||
+                   (U.cout == 128 && c.h->x6_pair_c128));
+    for (int j = 0; j < nb && x6pair; ++j)
+      for (int d = 0; d < m.n_rbd && x6pair; ++d)
+        x6pair = m.rb[i][j][d][0].wx_off >= 0 && m.rb[i][j][d][1].wx_off >= 0 && m.rb[i][j][d][0].k == m.rb[i][j][d][1].k &&
+                 respair_x6_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
+    if (x6pair) fused = true;
+    if (fused && !x6pair && c.h->x6_narrow && !c.h->no_conv_x6 && U.cout == 32 && m.rb[i][0][0][0].wx_off >= 0) fused = false;
+    for (int j = 0; j < nb && fused && !x6pair; ++j)
+      for (int d = 0; d < m.n_rbd; ++d)
+        fused = fused && resblock_fused_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
+    // x3 slots only for a stage that runs layer-wise on conv_x6.hip's 128-row tiles (the pair kernel scales per workgroup tile)
+    bool x3 = any_x3 && !rb2 && !fused && U.cout % 128 == 0;
     for (int j = 0; j < nb && x3; ++j)
       for (int d = 0; d < m.n_rbd && x3; ++d) x3 = m.rb[i][j][d][0].wy_off >= 0 && m.rb[i][j][d][1].wy_off >= 0;
-    unsigned* const slot_x = x3 ? P.xslots + next_slot++ : nullptr;
+    unsigned* const slot_x = x3 ? P.xslots + X3_SLOT_WORDS * next_slot++ : nullptr;
     {
       // x = ConvTranspose1d(leaky_relu(mean of the previous stage's branches)) as U.u polyphase stride-1 convs
       ConvLaunch cl;
@@ -888,23 +907,6 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
       const std::string tn = "dec.ups." + std::to_string(i);
       c.tap(tn.c_str(), x, (int64_t)B * U.cout * Lo);
     }
-    // the n_rbk ResBlock1 branches run side by side
-    const bool rb2 = m.rb_type == 2;
-    bool fused = U.cout <= 32 && nb <= 3 && !c.h->no_fused_resblock && !rb2;
-    // C = 32: two split-bf16 launches per pair (HBM-bound, 5 tensor passes) against one fused fp32-MFMA launch (MFMA-bound, 3 passes)
-    // C = 32 with the planes packed: the pair in ONE launch on the bf16 matrix core (respair_x6.hip: two passes AND the fast pipe)
-    bool x6pair = !rb2 && nb <= 3 && !c.h->no_fused_resblock && !c.h->no_conv_x6 && !c.h->no_x6_pair &&
-                  (U.cout == 32 || (U.cout == 16 && !c.h->no_x6_pair_c16) || (U.cout == 64 && !c.h->no_x6_pair_c64) ||
-                   (U.cout == 128 && c.h->x6_pair_c128));
-    for (int j = 0; j < nb && x6pair; ++j)
-      for (int d = 0; d < m.n_rbd && x6pair; ++d)
-        x6pair = m.rb[i][j][d][0].wx_off >= 0 && m.rb[i][j][d][1].wx_off >= 0 && m.rb[i][j][d][0].k == m.rb[i][j][d][1].k &&
-                 respair_x6_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
-    if (x6pair) fused = true;
-    if (fused && !x6pair && c.h->x6_narrow && !c.h->no_conv_x6 && U.cout == 32 && m.rb[i][0][0][0].wx_off >= 0) fused = false;
-    for (int j = 0; j < nb && fused && !x6pair; ++j)
-      for (int d = 0; d < m.n_rbd; ++d)
-        fused = fused && resblock_fused_supported(U.cout, cf.resblock_kernel_sizes[j], cf.resblock_dilation_sizes[j][d]);
     float* branch_out[BV2_MAX_RESBLOCK_KERNELS];
     if (rb2) {
       // modules.ResBlock2 (reference modules.py:348-357): for each of the two dilations x = x + conv_d(lrelu(x)) — one conv per launch
@@ -987,8 +989,8 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
             q.w3 = reinterpret_cast<const uint16_t*>(c.W(w.wy_off) + X3_HDR_FLOATS);
             q.xmax = in_slot; q.omax = out_slot;
           };
-          unsigned* const slot_tmp = x3 ? P.xslots + next_slot++ : nullptr;
-          unsigned* const slot_out = (x3 && d + 1 < m.n_rbd) ? P.xslots + next_slot++ : nullptr;   // the last step's output feeds no x3 conv
+          unsigned* const slot_tmp = x3 ? P.xslots + X3_SLOT_WORDS * next_slot++ : nullptr;
+          unsigned* const slot_out = (x3 && d + 1 < m.n_rbd) ? P.xslots + X3_SLOT_WORDS * next_slot++ : nullptr;   // the last step's output feeds no x3 conv
           ConvProb p = c.prob(m.rb[i][j][d][0], xin, tmp, Lo, cf.resblock_dilation_sizes[j][d]);
           p.pre_act = PRE_LRELU; p.slope = 0.1f;
           p.w6 = (x6 && m.rb[i][j][d][0].wx_off >= 0) ? reinterpret_cast<const uint16_t*>(c.W(m.rb[i][j][d][0].wx_off)) : nullptr;

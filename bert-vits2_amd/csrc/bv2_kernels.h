@@ -118,8 +118,8 @@ struct ConvProb {
   // All three set: the x3 form; any null: the three-plane bf16 form (w6).
   const uint16_t* w3;
   const float* w3inv;
-  const unsigned* xmax;
-  unsigned* omax;           // any LDS-tiled conv (conv_mfma.hip, conv_x6.hip): atomicMax of |out| over everything this problem stores, or null
+  const unsigned* xmax;     // X3_SLOT_WORDS words
+  unsigned* omax;           // any conv kernel: atomicMax of |out| over everything this problem stores into the slot (X3_SLOT_WORDS words), or null
 };
 
 #define BV2_MAX_PROBS 8
@@ -198,6 +198,12 @@ inline int64_t x3_w_index(int j, int ci, int co, int cin, int k, int plane) {
   return ((((int64_t)(co >> 5) * U + u) * 2 + plane) * 64 + lane) * 8 + (ci % 8);
 }
 inline int64_t x3_w_elems(int cin, int cout_pad, int k) { return (int64_t)(cout_pad / 32) * (cin / 16) * k * 2 * 512; }
+// A max |x| slot is one 128-byte line per XCD (X3_SLOT_WORDS words, 128-byte aligned; word 0 of line x belongs to XCD x).  A wave
+// publishes with an L2-LOCAL atomic (workgroup scope: executed in its XCD's L2, no trip to the memory side) into its own XCD's line —
+// only that XCD ever writes the line, the end-of-kernel write-back makes it visible — and the reader takes the max of the eight words.
+// (Device-scope atomics on one word: +12 us per launch of 1152 workgroups; a read of the word in front of the atomic: an exposed memory
+// round trip at the end of every workgroup.)
+constexpr int X3_LINE_WORDS = 32, X3_SLOT_WORDS = 8 * X3_LINE_WORDS;
 constexpr int X3_HDR_FLOATS = 64;     // the packed region starts with 1 / S_w (one float, 256-byte slot), the planes follow
 // biased fp32 exponent e of the tensor's largest magnitude, clamped so that S = 2^(141 - e) and 1 / S = 2^(e - 141) are normal floats:
 // max < 2^(e - 126)  =>  max * S < 2^15

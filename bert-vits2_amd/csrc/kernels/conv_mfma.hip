@@ -30,6 +30,18 @@ namespace bv2 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct defeats SROA here
 
+// ConvProb::omax: the wave's max |v| into its XCD's line of the slot (bv2_kernels.h).  |v| >= 0, so fp32 bit patterns order like the
+// values.  `seen`: the word as read at the start of the kernel (stale is fine: it only filters redundant atomics).
+__device__ __forceinline__ unsigned* x3_slot_word(unsigned* slot) {
+  return slot + X3_LINE_WORDS * (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);      // XCC_ID
+}
+__device__ __forceinline__ void x3_publish(unsigned* word, unsigned seen, float vmx, int lane) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, d));
+  const unsigned bits = __float_as_uint(vmx);
+  if (lane == 0 && bits > seen) __hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // load base[byte_off]: wave-uniform base (SGPR pair) + 32-bit per-lane BYTE offset -> the `global_load v, v_off, s[base]`
 // addressing form (one VGPR per address instead of a 64-bit pair)
 __device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
@@ -213,11 +225,17 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
     }
   };
 
+  // ConvProb::omax (max |out| for the x3 form of conv_x6.hip): this wave's word of the slot, read now so that its round trip lands
+  // under the prologue's loads (read in front of the atomic it was an exposed round trip at the end of every workgroup)
+  unsigned* const omax_w = P.omax ? x3_slot_word(P.omax) : nullptr;
+  unsigned omax_seen = 0xffffffffu;
+  if (omax_w) omax_seen = *reinterpret_cast<volatile unsigned*>(omax_w);
   // prologue: X chunk 0 first (its latency is the long one), then prime the ring
   issue_x(0);
 #pragma unroll
   for (int i = 0; i < GR; ++i) { load_unit(i, k == 1 ? (nchunks > 1 ? GR * 256 : 0) : 256); __builtin_amdgcn_sched_barrier(0); }
   store_x(0, 0);
+  omax_seen = __builtin_amdgcn_readfirstlane(omax_seen);
   __syncthreads();
   if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
@@ -306,8 +324,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
     const float* const b1p = biasp ? biasp : P.w;
     const float* const b2p = bias2p ? bias2p : P.w;
     const unsigned m_b1 = biasp ? 0xffffffffu : 0u, m_b2 = bias2p ? 0xffffffffu : 0u;
-    unsigned* const omaxp = P.omax;                // max |v| of everything stored, for the x3 form of conv_x6.hip that reads this tensor
-    float vmx = 0.f;
+    float vmx = 0.f;                               // max |v| of everything stored, for the x3 form of conv_x6.hip that reads this tensor
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int row0 = m0 + wm * (MI * 32) + mi * 32 + 4 * lh;       // this lane's rows: row0 + (r & 3) + 8 * (r >> 2)
@@ -367,12 +384,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvLaunch L, co
         }
       }
     }
-    if (omaxp) {                                   // one atomic per wave, only while the slot is below the wave's value (conv_x6.hip)
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, d));
-      const unsigned bits = __float_as_uint(vmx);
-      if (lane == 0 && bits > *reinterpret_cast<volatile unsigned*>(omaxp)) atomicMax(omaxp, bits);
-    }
+    if (omax_w) x3_publish(omax_w, omax_seen, vmx, lane);
   }
   if (L.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);                                  // the epilogue's stores have been issued and acknowledged
@@ -510,7 +522,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
   const float* const biasp = z == 0 ? P.bias : nullptr;
   const float* const bias2p = (z == 0 && P.bias2) ? P.bias2 + (int64_t)b * P.bias2_bstride : nullptr;
   const float om = (P.out_mask && colok) ? P.out_mask[(int64_t)b * P.out_mask_bstride + col] : 1.f;
-  unsigned* const omaxp = P.omax;
+  unsigned* const omaxp = P.omax ? x3_slot_word(P.omax) : nullptr;
   const unsigned coff = (unsigned)(colok ? col : 0) * o_ts + o_to;
   constexpr int RPP = 2 * NWV;                      // rows per pass (one element per thread per pass)
   float rvv[32 / RPP], bsv[32 / RPP], b2v[32 / RPP];
@@ -665,12 +677,7 @@ __global__ void __launch_bounds__(64 * NWV) conv1d_splitk_kernel(const ConvLaunc
         vmx = fmaxf(vmx, fabsf(vv));
       }
     }
-    if (omaxp) {                                    // ksplit == 1 only (host): max |v| of the stored tensor, see conv1d_mfma_kernel
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, d));
-      const unsigned bits = __float_as_uint(vmx);
-      if (lane == 0 && bits > *reinterpret_cast<volatile unsigned*>(omaxp)) atomicMax(omaxp, bits);
-    }
+    if (omaxp) x3_publish(omaxp, 0u, vmx, lane);    // ksplit == 1 only (host): max |v| of the stored tensor, see conv1d_mfma_kernel
   }
   if (L.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);

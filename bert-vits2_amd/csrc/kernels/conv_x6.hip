@@ -60,13 +60,16 @@ __device__ __forceinline__ float x6_lo(unsigned u) { return __uint_as_float(u <<
 __device__ __forceinline__ float x6_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 constexpr float X6_BF16_MAX = 3.38953139e38f;   // 0x7f7f0000
-// ConvProb::omax: the wave's max |v| into the slot.  |v| >= 0, so the fp32 bit patterns order like the values; one atomic per wave, and
-// only while the slot is still below the wave's value (a stale read only costs a redundant atomic).
-__device__ __forceinline__ void x6_absmax_publish(unsigned* slot, float vmx, int lane) {
+// ConvProb::omax: the wave's max |v| into its XCD's line of the slot (bv2_kernels.h).  |v| >= 0, so fp32 bit patterns order like the
+// values.  `seen`: the word as read at the start of the kernel (stale is fine: it only filters redundant atomics).
+__device__ __forceinline__ unsigned* x3_slot_word(unsigned* slot) {
+  return slot + X3_LINE_WORDS * (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);      // XCC_ID
+}
+__device__ __forceinline__ void x3_publish(unsigned* word, unsigned seen, float vmx, int lane) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, d));
   const unsigned bits = __float_as_uint(vmx);
-  if (lane == 0 && bits > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, bits);
+  if (lane == 0 && bits > seen) __hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ xf32x16 x6_mfma(xbf16x8 a, xbf16x8 b, xf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ xf32x16 x6_mfma(xf16x8 a, xf16x8 b, xf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -148,10 +151,17 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   const float slope = P.slope;
   float acc_scale = 1.f;                           // NP = 2: 1 / (S_w S_x), applied to the accumulators in the epilogue
   if constexpr (NP == 2) {
-    const unsigned ex = x3_scale_exp(*P.xmax);     // S_x from the input tensor's max |x| (wave-uniform: scalar loads)
+    unsigned mb = 0;                               // S_x from the input tensor's max |x|: the largest of the slot's eight words (scalar loads)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mb = P.xmax[X3_LINE_WORDS * i] > mb ? P.xmax[X3_LINE_WORDS * i] : mb;
+    const unsigned ex = x3_scale_exp(mb);
     in_scale *= x3_scale(ex);
     acc_scale = x3_scale_inv(ex) * *P.w3inv;
   }
+  // ConvProb::omax: this wave's word of the slot, read NOW (its round trip lands under the prologue's other loads)
+  unsigned* const omax_w = P.omax ? x3_slot_word(P.omax) : nullptr;
+  unsigned omax_seen = 0xffffffffu;
+  if (omax_w) omax_seen = *reinterpret_cast<volatile unsigned*>(omax_w);
   const bool lrelu = P.pre_act == PRE_LRELU;
   const float* const x0p = P.x[0] + (int64_t)b * P.x_bstride;
   const float* const maskp = P.in_mask ? P.in_mask + (int64_t)b * P.in_mask_bstride : nullptr;
@@ -300,6 +310,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     for (int g = 0; g < GR; ++g) { load_unit(g, 1, s1); __builtin_amdgcn_sched_barrier(0); }
   }
   if constexpr (NLD == 0) store_x(0);
+  omax_seen = __builtin_amdgcn_readfirstlane(omax_seen);          // into an SGPR here, where the wave waits for chunk 0 anyway
   __syncthreads();
   if (L.dbg) ts1 = __builtin_amdgcn_s_memtime();
 
@@ -462,7 +473,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
         }
       }
     }
-    if (P.omax) x6_absmax_publish(P.omax, vmx, lane);
+    if (omax_w) x3_publish(omax_w, omax_seen, vmx, lane);
   }
   if (L.dbg && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -481,7 +492,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, const int64_t n, unsigned* slot) {
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-  x6_absmax_publish(slot, m, threadIdx.x & 63);
+  x3_publish(x3_slot_word(slot), 0u, m, threadIdx.x & 63);
 }
 int launch_absmax(hipStream_t stream, const float* x, int64_t n, unsigned* slot) {
   if (!x || !slot || n < 1) return -1;
@@ -510,8 +521,6 @@ bool conv_x6_supported(const ConvLaunch& L) {
 
 // tuning experiments (tools/tune_x6.py through bv2_test_set_x6_tuning): forced tile per C_out class and chunk size; 0 = shipped choice
 static int g_x6_tile[3] = {0, 0, 0};
-static bool g_x3_off = false;                     // A/B: the three-plane form although the x3 operands are there
-void conv_x3_set_off(bool off) { g_x3_off = off; }
 void conv_x6_set_tuning(int t256, int t128, int t64, int) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; }
 
 template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD = 0, int NP = 3>
@@ -579,15 +588,18 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
       // few workgroups per CU (batch 1: 288 / 1152 on 256 CUs): the loader-wave form — Generator pass 2.045 -> 1.937 ms; with dozens per
       // CU (B = 8 x 512 frames) the third resident workgroup of the plain form is worth more: 18.80 against 18.89 ms
       // (tools/tune_x6.py, profiles/r03_tune_x6_loader_*.txt)
+      // The x3 form (119 / 131 registers, 41 / 20 KB): at 1152 workgroups (C = 128 at batch 1) three plain workgroups per CU beat two
+      // loader ones — Generator pass 1.194 against 1.235 ms — and only the 288-workgroup launches (one per CU) keep the loaders.
       const long wgs = (long)((L.L + 63) / 64) * (max_cout_pad / 128) * L.B * L.nprob;
-      tile = wgs <= 2048 ? TILE_X6_128x64_LD : TILE_X6_128x64;
+      const bool x3f = conv_x3_ready(L);
+      tile = wgs <= (x3f ? 512 : 2048) ? TILE_X6_128x64_LD : TILE_X6_128x64;
     } else tile = max_cout_pad % 64 == 0 ? TILE_X6_64x128 : TILE_X6_32x256;
   }
   // Both tiles: wave tile 32x64 (MI = 1, NI = 2), 32-channel chunks — 164 / 178 registers, 31 / 46 KB of LDS.  Measured and removed in
   // round 3 (tools/tune_x6.py, profiles/r03_tune_x6_*.txt): 64-channel chunks (229 registers, two workgroups per CU: Generator pass
   // 2.11 against 1.97 ms), wave tiles 64x64 as 128x128 / 256x64 / 64x256 workgroups and 32x128 (all within +-2 % at B = 8, slower at
   // B = 1), and an eight-wave form with K split over two wave sets for the 288-workgroup launches of the C = 256 stage (no change).
-  const bool x3 = !g_x3_off && conv_x3_ready(L);  // the two-plane fp16 form where the tile has one (the 128-row tiles)
+  const bool x3 = conv_x3_ready(L);  // the two-plane fp16 form where the tile has one (the 128-row tiles)
   switch (tile) {
     case TILE_X6_128x64:                          // all four waves on the same 64 columns, one 32-row block each
       if (variant_name) *variant_name = x3 ? "conv1d_x3<128x64>" : "conv1d_x6<128x64>";

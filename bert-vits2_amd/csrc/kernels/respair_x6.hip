@@ -384,9 +384,6 @@ respair_x6_kernel(const FusedLaunch L, const int per_xcd) {
   }
 }
 
-static bool g_pair_x3_off = false;                // A/B (tests): the three-plane form although the x3 planes are there
-void respair_x3_set_off(bool off) { g_pair_x3_off = off; }
-
 bool respair_x6_supported(int C, int k, int dil) {
   if ((C != 16 && C != 32 && C != 64 && C != 128) || k < 3 || k % 2 == 0 || dil < 1) return false;
   const int HT = C == 128 ? 128 : 256;
@@ -407,7 +404,7 @@ int launch_respair_x6(hipStream_t stream, const FusedLaunch& F) {
   }
   const int per_xcd = ntx >= 16 ? (ntx + 7) / 8 : 0;
   dim3 grid(per_xcd ? per_xcd * 8 : ntx, F.B, F.nprob);
-  bool x3 = !g_pair_x3_off;                       // the two-plane fp16 form: every problem carries its planes and their scales
+  bool x3 = true;                                 // the two-plane fp16 form: every problem carries its planes and their scales
   for (int i = 0; i < F.nprob; ++i) x3 = x3 && F.p[i].w31 && F.p[i].w32 && F.p[i].w3inv1 && F.p[i].w3inv2;
   if (x3) {
     const size_t lds3 = (size_t)2 * (HT + 64) * (F.C + 8) * 2 + 256;

@@ -29,7 +29,8 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
 
 /* tile 14 = the two-plane fp16 form of the same kernel ("x3", bv2_kernels.h): tile 8's choice with the scaled fp16 planes, max |x|
  * reduced into a slot by a launch in front.  For cin % 32 == 0 and ksplit <= 1 EVERY tile also publishes max |out| (ConvProb::omax)
- * as fp32 bits at float offset bv2_test_x3_omax_off(cin, cout, k) of wpack_dev. */
+ * as fp32 bits in a slot (eight words, 32 floats apart: one per XCD — the value is their max) at float offset
+ * bv2_test_x3_omax_off(cin, cout, k) of wpack_dev. */
 int64_t bv2_test_x3_omax_off(int cin, int cout, int k);
 
 /* v = h[0] + h[1] + h[2] exactly as bf16 bit patterns: the host-side split the packer applies to the x6 weight planes (host only) */

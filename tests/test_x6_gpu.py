@@ -293,7 +293,8 @@ X3_CASES = [
 def _omax(lib, wp, cin, cout, k):
     lib.bv2_test_x3_omax_off.restype = __import__("ctypes").c_int64
     lib.bv2_test_x3_omax_off.argtypes = [__import__("ctypes").c_int] * 3
-    return wp[lib.bv2_test_x3_omax_off(cin, cout, k)].item()
+    off = lib.bv2_test_x3_omax_off(cin, cout, k)
+    return wp[off:off + 256:32].contiguous().view(torch.int32).max().view(torch.float32).item()      # one 128-byte line per XCD: the largest of the eight words
 
 
 def _run_wp(lib, x, w, bias, tile, k, dil, **kw):
