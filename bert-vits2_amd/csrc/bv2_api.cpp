@@ -591,7 +591,7 @@ int bv2_test_conv1d(void* stream, const float* x, const float* w_host, const flo
       // every kernel's max |out| lands in the region's second slot (bv2_test_x3_omax_off); the x3 form reads max |x| from the first: the
       // product's producers publish it from their epilogues, here a reduction launch fills the (zeroed) slot
       float* reg = wpack_dev + t_x3_off(cin, cout, k);
-      if (hipMemsetAsync(reg, 0, sizeof(float) * 2 * X3_SLOT_WORDS, static_cast<hipStream_t>(stream)) != hipSuccess) return -6;
+      if (launch_x3_zero_slots(static_cast<hipStream_t>(stream), reinterpret_cast<unsigned*>(reg), 2)) return -6;
       p.omax = reinterpret_cast<unsigned*>(reg + X3_SLOT_WORDS);
       if (x3) {
         if (nsrc != 1 || launch_absmax(static_cast<hipStream_t>(stream), x, (int64_t)B * cin * L, reinterpret_cast<unsigned*>(reg))) return -2;

@@ -859,7 +859,7 @@ static void gen_core(Ctx& c, const PlanB& P, const float* z, int z_rstride, cons
   for (int i = 0; i < m.n_ups && !c.h->no_conv_x3 && !c.h->no_conv_x6; ++i)
     if (m.ups[i].cout % 128 == 0 && m.rb[i][0][0][0].wy_off >= 0) n_slots += 1 + 2 * m.n_rbk * m.n_rbd;
   const bool any_x3 = n_slots > 0;
-  if (any_x3 && !c.rc && hipMemsetAsync(P.xslots, 0, sizeof(unsigned) * X3_SLOT_WORDS * n_slots, c.s) != hipSuccess) c.chk(-1, "dec.x3_slots");
+  if (any_x3 && !c.rc) c.chk(launch_x3_zero_slots(c.s, P.xslots, n_slots), "dec.x3_slots");
   for (int i = 0; i < m.n_ups; ++i) {
     const UpW& U = m.ups[i];
     float* const* S = P.set[i & 1];

@@ -220,6 +220,7 @@ BV2_HD inline float x3_scale(unsigned e) { const uint32_t u = (268u - e) << 23; 
 BV2_HD inline float x3_scale_inv(unsigned e) { const uint32_t u = (e - 14u) << 23; float f; __builtin_memcpy(&f, &u, 4); return f; }
 // max |x| of a tensor into a slot (fp32 bits; the slot is zeroed by the caller): for inputs whose producer is not a conv launch
 int launch_absmax(hipStream_t stream, const float* x, int64_t n, unsigned* slot);
+int launch_x3_zero_slots(hipStream_t stream, unsigned* slots, int n_slots);   // n_slots x X3_SLOT_WORDS words, by a launch (not a memset node: conv_x6.hip)
 bool conv_x6_supported(const ConvLaunch& L);        // every problem carries w6 and fits the staged tile
 int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const char** variant_name);
 void conv_x6_occupancy(int out[4]);                              // workgroups per CU granted to {128x64, 128x64 + loaders, 64x128, 32x256}

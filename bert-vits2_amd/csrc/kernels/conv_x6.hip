@@ -494,6 +494,19 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
   x3_publish(x3_slot_word(slot), 0u, m, threadIdx.x & 63);
 }
+// The slots of one decode are zeroed by a LAUNCH, i.e. by ordinary stores under the ordinary kernel-to-kernel visibility rules: inside a
+// replayed hipGraph a memset node's zeros were not seen by an XCD whose L2 still held the slot's line from the previous replay (its
+// producers read the old maximum, found nothing larger to publish, and the consumer scaled by a maximum of 0: NaN on the second replay).
+__global__ void __launch_bounds__(256) x3_zero_slots_kernel(unsigned* slots, const int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) slots[i] = 0u;
+}
+int launch_x3_zero_slots(hipStream_t stream, unsigned* slots, int n_slots) {
+  if (!slots || n_slots < 1) return -1;
+  const int n = n_slots * X3_SLOT_WORDS;
+  hipLaunchKernelGGL(x3_zero_slots_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, slots, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_absmax(hipStream_t stream, const float* x, int64_t n, unsigned* slot) {
   if (!x || !slot || n < 1) return -1;
   const int64_t blocks = (n + 255) / 256;

@@ -40,6 +40,10 @@ def test_graph_replay_is_bit_identical_to_eager(name):
     first = _run(m, batch, nw, nz, kw)            # captures both phases, then replays
     assert len(m._graphs) == 2 and all(m._lib.bv2_graph_num_nodes(g["graph"]) > 50 for g in m._graphs.values())
     again = _run(m, batch, nw, nz, kw)            # pure replay
+    # ... and again on the SAME inputs: state a replay leaves behind (the x3 convs' max |x| slots, conv_x6.hip) must not leak into the next
+    for _ in range(2):
+        rep = _run(m, batch, nw, nz, kw)
+        assert torch.equal(rep["o"], eager["o"])
     other = _run(m, batch2, nw2, nz2, kw)         # replay with new data (same shapes only if the durations agree)
     for k, v in eager.items():
         assert torch.equal(first[k], v), k
