@@ -90,9 +90,14 @@ __device__ __forceinline__ xf32x2 x3_unpack(unsigned u) { return __builtin_conve
 // 31 KB buffer (two workgroups per CU instead of three; with the loaders still 12 waves per CU).
 // NP = 3: three bf16 planes per operand, six products.  NP = 2: two scaled fp16 planes, three products (the "x3" form, bv2_kernels.h):
 // the same kernel with a third less LDS / ring registers and half the matrix instructions per unit.
-template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD, int NP = 3>
+// RD: taps per group in the weight ring.  2: the ring described above.  4 (x3 form, every problem's k = 3 mod 4, i.e. the 3 / 7 / 11 ResBlock
+// kernels): with three products a unit is 192 matrix cycles and two taps ahead is 576 cycles — less than an L2 round trip (PMC: the C = 256
+// launches' waves waited on s_waitcnt 43 % of their life); four taps ahead restores the distance in TIME.  The slot of tap j of chunk c is
+// (c k + j) mod 4, so a chunk starts at phase 0, 3, 2, 1, 0 ... and the chunk loop unrolls by four.
+template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD, int NP = 3, int RD = 2>
 __global__ void __launch_bounds__(64 * (WM * WN + NLD), WM * WN > 4 ? 2 : ((NLD > 0 || (MI * NI <= 2 && CK == 32 && XR <= 128)) ? 3 : 2))
 conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const int snake_n) {
+  static_assert(RD == 2 || RD == 4, "ring depth");
   constexpr int X6_UNIT = NP * 512;                // elements of one (group, tap) unit of one m-tile: NP planes x 64 lanes x 8
   constexpr int BM = WM * MI * 32;
   constexpr int BN = WN * NI * 32;
@@ -185,7 +190,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   // unit = 384 cycles ahead here) a workgroup alone on its CU (C = 256 at batch 1: 288 workgroups) spent 980 cycles per 384-cycle unit.
   typedef typename std::conditional<NP == 2, xf16x8, xbf16x8>::type frag_t;
   typedef __attribute__((address_space(1))) frag_t GlobalFragT;
-  frag_t ar[GR][2][MI][NP];
+  frag_t ar[GR][RD][MI][NP];
   const uint16_t* wq[GR][MI];
   const unsigned wlane = 16u * (unsigned)lane;
 #pragma unroll
@@ -300,7 +305,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
   }
   // prologue: X chunk 0 first (the long latency), then prime the ring with the first two units of every group's stream
   if constexpr (NLD == 0) issue_x(0);
-  {
+  if constexpr (RD == 2) {
     const int s0 = step_after(0, 0);
     const int j1 = k > 1 ? 1 : 0, c1 = k > 1 ? 0 : (nchunks > 1 ? 1 : 0);
     const int s1 = step_after(j1, c1);
@@ -308,6 +313,16 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     for (int g = 0; g < GR; ++g) { load_unit(g, 0, s0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int g = 0; g < GR; ++g) { load_unit(g, 1, s1); __builtin_amdgcn_sched_barrier(0); }
+  } else {
+    // the first four units of every group's stream (k >= 3: the fourth is tap 0 of chunk 1 when k = 3), slot n for unit n
+    int jl = 0, cl = 0;
+#pragma unroll
+    for (int n = 0; n < RD; ++n) {
+      const int st = step_after(jl, cl < nchunks ? cl : 0);
+#pragma unroll
+      for (int g = 0; g < GR; ++g) { load_unit(g, n, st); __builtin_amdgcn_sched_barrier(0); }
+      if (++jl == k) { jl = 0; if (++cl >= nchunks) cl = 0; }
+    }
   }
   if constexpr (NLD == 0) store_x(0);
   omax_seen = __builtin_amdgcn_readfirstlane(omax_seen);          // into an SGPR here, where the wave waits for chunk 0 anyway
@@ -332,7 +347,7 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     // one tap: the GR units (g, j) from ring slots [g][SL]; each slot is refilled with the unit two taps further down its stream
     auto tap = [&](int j, int SL) __attribute__((always_inline)) {               // SL: a literal at every (inlined) call site
       const unsigned short* xnext = (j + 1 < k) ? xrow + tap_step : xrow;   // the chunk's last unit re-reads itself (unused)
-      int jl = j + 2, cl = c;                     // the unit loaded during this tap: tap jl of chunk cl (branch-free wrap; k = 1: twice)
+      int jl = j + RD, cl = c;                    // the unit loaded during this tap: tap jl of chunk cl (branch-free wrap; RD = 2, k = 1 / RD = 4, k = 3: twice)
       if (jl >= k) { jl -= k; ++cl; }
       if (jl >= k) { jl -= k; ++cl; }
       if (cl >= nchunks) cl -= nchunks;
@@ -342,10 +357,12 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
       for (int g = 0; g < GR; ++g) {
         {
           const unsigned short* xn = (g + 1 < GR) ? xrow + (g + 1) * 16 : xnext;
+          // in the order the next unit's products use them (plane-major: X6_PROD(.., 0) on both column blocks first): the wait in front
+          // of an MFMA then covers the OLDEST outstanding read instead of one issued two reads later
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
+          for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int ni = 0; ni < NI; ++ni)
               bb[(g & 1) ^ 1][ni][p] = *reinterpret_cast<const frag_t*>(xn + ni * 32 * PITCH + p * PLANE);
         }
         // the six products, smallest first; consecutive MFMAs go to different accumulators
@@ -377,8 +394,14 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
       }
       xrow = xnext;
     };
-    for (int j = 0; j + 1 < k; j += 2) { tap(j, PAR); tap(j + 1, PAR ^ 1); }
-    tap(k - 1, PAR);
+    if constexpr (RD == 2) {
+      for (int j = 0; j + 1 < k; j += 2) { tap(j, PAR); tap(j + 1, PAR ^ 1); }
+      tap(k - 1, PAR);
+    } else {                                      // k = 3 mod 4 (launcher): whole rounds of four slots, then three taps
+      int j = 0;
+      for (; j + 3 < k; j += 4) { tap(j, PAR); tap(j + 1, (PAR + 1) & 3); tap(j + 2, (PAR + 2) & 3); tap(j + 3, (PAR + 3) & 3); }
+      tap(j, PAR); tap(j + 1, (PAR + 1) & 3); tap(j + 2, (PAR + 2) & 3);
+    }
     if constexpr (NLD > 0) {
       unsigned long long ta = 0;
       if (L.dbg) ta = __builtin_amdgcn_s_memtime();
@@ -394,8 +417,15 @@ conv1d_x6_kernel(const ConvLaunch L, const int mtiles, const int per_xcd, const 
     }
   };
   int c = 0;
-  for (; c + 1 < nchunks; c += 2) { chunk(c, 0); chunk(c + 1, 1); }
-  if (c < nchunks) chunk(c, 0);
+  if constexpr (RD == 2) {
+    for (; c + 1 < nchunks; c += 2) { chunk(c, 0); chunk(c + 1, 1); }
+    if (c < nchunks) chunk(c, 0);
+  } else {                                        // a chunk advances the phase by k = 3 (mod 4)
+    for (; c + 3 < nchunks; c += 4) { chunk(c, 0); chunk(c + 1, 3); chunk(c + 2, 2); chunk(c + 3, 1); }
+    if (c < nchunks) chunk(c, 0);
+    if (c + 1 < nchunks) chunk(c + 1, 3);
+    if (c + 2 < nchunks) chunk(c + 2, 2);
+  }
   if (L.dbg) ts2 = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: v = relu?(acc + bias + bias2) * mask_pre, (+ res | res - v), * mask_post.  Branch-free and in ONE memory round trip:
@@ -534,9 +564,10 @@ bool conv_x6_supported(const ConvLaunch& L) {
 
 // tuning experiments (tools/tune_x6.py through bv2_test_set_x6_tuning): forced tile per C_out class and chunk size; 0 = shipped choice
 static int g_x6_tile[3] = {0, 0, 0};
-void conv_x6_set_tuning(int t256, int t128, int t64, int) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; }
+static int g_x3_ring = 0;                         // conv_x6_set_tuning's fourth argument (A/B): 2 = the x3 form on the two-tap ring, 3 = four-tap ring with TWO loader waves
+void conv_x6_set_tuning(int t256, int t128, int t64, int ring) { g_x6_tile[0] = t256; g_x6_tile[1] = t128; g_x6_tile[2] = t64; g_x3_ring = ring; }
 
-template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD = 0, int NP = 3>
+template <int WM, int WN, int MI, int NI, int CK, int XR, int NLD = 0, int NP = 3, int RD = 2>
 static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_cout_pad) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   const int mtiles = (max_cout_pad + BM - 1) / BM;
@@ -565,7 +596,7 @@ static int launch_x6_variant(hipStream_t stream, const ConvLaunch& L0, int max_c
     Ls.dbg = timeline_slice(grid.x, grid.y, grid.z, 6000000 + BM * 1000 + BN, ks, Ls.p[0].cin, Ls.L);
   }
   const size_t lds = (size_t)(NLD > 0 ? 2 : 1) * NP * XR * (CK + 8) * 2;
-  auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR, NLD, NP>;
+  auto kern = conv1d_x6_kernel<WM, WN, MI, NI, CK, XR, NLD, NP, RD>;
   ensure_dyn_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + NLD)), lds, stream, Ls, mtiles, per_xcd, snake_n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -613,13 +644,25 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
   // 2.11 against 1.97 ms), wave tiles 64x64 as 128x128 / 256x64 / 64x256 workgroups and 32x128 (all within +-2 % at B = 8, slower at
   // B = 1), and an eight-wave form with K split over two wave sets for the 288-workgroup launches of the C = 256 stage (no change).
   const bool x3 = conv_x3_ready(L);  // the two-plane fp16 form where the tile has one (the 128-row tiles)
+  bool rd4 = x3 && g_x3_ring != 2;   // its four-tap weight ring: every problem's k = 3 mod 4
+  for (int i = 0; i < L.nprob; ++i) rd4 = rd4 && (L.p[i].k & 3) == 3;
   switch (tile) {
     case TILE_X6_128x64:                          // all four waves on the same 64 columns, one 32-row block each
       if (variant_name) *variant_name = x3 ? "conv1d_x3<128x64>" : "conv1d_x6<128x64>";
+      if (x3 && rd4) return launch_x6_variant<4, 1, 1, 2, 32, 128, 0, 2, 4>(stream, L, max_cout_pad);
       if (x3) return launch_x6_variant<4, 1, 1, 2, 32, 128, 0, 2>(stream, L, max_cout_pad);
       return launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
     case TILE_X6_128x64_LD:                       // the same tile with two loader waves and two X buffers
+      if (x3 && rd4 && g_x3_ring != 3) {
+        // x3 with the four-tap ring: FOUR loader waves, one per SIMD (a chunk's split is 1 300 VALU cycles for one of two loaders against
+        // 1 150 matrix cycles of a k = 3 chunk: those workgroups were loader-bound, and the two SIMDs that carried a loader ran their MFMA
+        // wave behind it) — Generator pass 1.183 / 1.181 -> 1.173 ms for the C = 256 launches, slower for 1 152-workgroup ones (which take
+        // the plain tile anyway)
+        if (variant_name) *variant_name = "conv1d_x3<128x64,ld4>";
+        return launch_x6_variant<4, 1, 1, 2, 32, 128, 4, 2, 4>(stream, L, max_cout_pad);
+      }
       if (variant_name) *variant_name = x3 ? "conv1d_x3<128x64,ld>" : "conv1d_x6<128x64,ld>";
+      if (x3 && rd4) return launch_x6_variant<4, 1, 1, 2, 32, 128, 2, 2, 4>(stream, L, max_cout_pad);
       if (x3) return launch_x6_variant<4, 1, 1, 2, 32, 128, 2, 2>(stream, L, max_cout_pad);
       return launch_x6_variant<4, 1, 1, 2, 32, 128, 2>(stream, L, max_cout_pad);
     case TILE_X6_64x128:                          // 2 x 2 waves

@@ -50,15 +50,19 @@ def test_pmc_family_names_match_the_names_the_launcher_reports():
     sys.path.insert(0, os.path.join(root, "tools"))
     from collect_traffic import family
     src = open(os.path.join(root, "bert-vits2_amd", "csrc", "kernels", "conv_x6.hip")).read()
-    # the symbol carries <WM, WN, MI, NI, CK, XR, NLD, NP>: NP = 3 the six-product bf16 form, NP = 2 the two-plane fp16 form ("x3")
-    cases = {"<4, 1, 1, 2, 32, 128, 0, 3>": "conv1d_x6<128x64>", "<4, 1, 1, 2, 32, 128, 2, 3>": "conv1d_x6<128x64,ld>",
-             "<2, 2, 1, 2, 32, 192, 0, 3>": "conv1d_x6<64x128>", "<1, 4, 1, 2, 32, 320, 0, 3>": "conv1d_x6<32x256>",
-             "<4, 1, 1, 2, 32, 128, 0, 2>": "conv1d_x3<128x64>", "<4, 1, 1, 2, 32, 128, 2, 2>": "conv1d_x3<128x64,ld>"}
+    # the symbol carries <WM, WN, MI, NI, CK, XR, NLD, NP, RD>: NP = 3 the six-product bf16 form, NP = 2 the two-plane fp16 form ("x3"), RD the ring depth
+    cases = {"<4, 1, 1, 2, 32, 128, 0, 3, 2>": "conv1d_x6<128x64>", "<4, 1, 1, 2, 32, 128, 2, 3, 2>": "conv1d_x6<128x64,ld>",
+             "<2, 2, 1, 2, 32, 192, 0, 3, 2>": "conv1d_x6<64x128>", "<1, 4, 1, 2, 32, 320, 0, 3, 2>": "conv1d_x6<32x256>",
+             "<4, 1, 1, 2, 32, 128, 0, 2, 2>": "conv1d_x3<128x64>", "<4, 1, 1, 2, 32, 128, 2, 2, 2>": "conv1d_x3<128x64,ld>",
+             "<4, 1, 1, 2, 32, 128, 0, 2, 4>": "conv1d_x3<128x64>", "<4, 1, 1, 2, 32, 128, 4, 2, 4>": "conv1d_x3<128x64,ld4>"}
     for targs, name in cases.items():
         assert family(f"void bv2::conv1d_x6_kernel{targs}(bv2::ConvLaunch, int, int, int)") == name
         assert f'"{name}"' in src, name
         a = [v.strip() for v in targs.strip("<>").split(",")]
-        tail = [] if (a[6], a[7]) == ("0", "3") else ([a[6]] if a[7] == "3" else [a[6], a[7]])      # trailing defaults are left out in the source
+        tail = a[6:]                                                                  # trailing defaults (NLD 0, NP 3, RD 2) are left out in the source
+        for dflt in ("2", "3", "0"):
+            if tail and tail[-1] == dflt and len(tail) == {"2": 3, "3": 2, "0": 1}[dflt]:
+                tail = tail[:-1]
         inst = f"launch_x6_variant<{', '.join(a[:6] + tail)}>"
         assert inst in src, inst
     assert family("void bv2::respair_x6_kernel<64, 4, 2>(bv2::FusedLaunch, int)") == "respair_x3<64>"

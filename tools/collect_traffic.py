@@ -24,7 +24,7 @@ def family(kname):
     if "conv1d_x6_kernel<" in kname:            # <WM, WN, MI, NI, CK, XR, NLD, NP> -> the name bench.py / launch_conv1d_x6 report
         a = [int(v) for v in kname.split("conv1d_x6_kernel<")[1].split(">")[0].split(",")]
         form = "x3" if len(a) > 7 and a[7] == 2 else "x6"           # NP = 2: the two-plane fp16 form
-        return f"conv1d_{form}<{a[0] * a[2] * 32}x{a[1] * a[3] * 32}{',ld' if len(a) > 6 and a[6] > 0 else ''}>"
+        return f"conv1d_{form}<{a[0] * a[2] * 32}x{a[1] * a[3] * 32}{(',ld4' if a[6] == 4 else ',ld') if len(a) > 6 and a[6] > 0 else ''}>"
     if "respair_x6_kernel<" in kname:           # <C, WNT> -> the name bv2_exec.cpp reports
         a = [int(v) for v in kname.split("respair_x6_kernel<")[1].split(">")[0].split(",")]          # <C, WNT, NP>
         return f"respair_{'x3' if len(a) > 2 and a[2] == 2 else 'x6'}<{a[0]}>"
