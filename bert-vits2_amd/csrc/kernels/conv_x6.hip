@@ -649,7 +649,8 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
   switch (tile) {
     case TILE_X6_128x64:                          // all four waves on the same 64 columns, one 32-row block each
       if (variant_name) *variant_name = x3 ? "conv1d_x3<128x64>" : "conv1d_x6<128x64>";
-      if (x3 && rd4) return launch_x6_variant<4, 1, 1, 2, 32, 128, 0, 2, 4>(stream, L, max_cout_pad);
+      // (the four-tap ring on THIS tile — 168 registers, three workgroups per CU already hiding the distance — measured slower: Generator
+      //  pass 1.192 -> 1.200 ms, rocprofv3 59.6 -> 64.2 us per launch; it stays on the two-tap ring)
       if (x3) return launch_x6_variant<4, 1, 1, 2, 32, 128, 0, 2>(stream, L, max_cout_pad);
       return launch_x6_variant<4, 1, 1, 2, 32, 128>(stream, L, max_cout_pad);
     case TILE_X6_128x64_LD:                       // the same tile with two loader waves and two X buffers

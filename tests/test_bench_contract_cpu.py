@@ -54,7 +54,7 @@ def test_pmc_family_names_match_the_names_the_launcher_reports():
     cases = {"<4, 1, 1, 2, 32, 128, 0, 3, 2>": "conv1d_x6<128x64>", "<4, 1, 1, 2, 32, 128, 2, 3, 2>": "conv1d_x6<128x64,ld>",
              "<2, 2, 1, 2, 32, 192, 0, 3, 2>": "conv1d_x6<64x128>", "<1, 4, 1, 2, 32, 320, 0, 3, 2>": "conv1d_x6<32x256>",
              "<4, 1, 1, 2, 32, 128, 0, 2, 2>": "conv1d_x3<128x64>", "<4, 1, 1, 2, 32, 128, 2, 2, 2>": "conv1d_x3<128x64,ld>",
-             "<4, 1, 1, 2, 32, 128, 0, 2, 4>": "conv1d_x3<128x64>", "<4, 1, 1, 2, 32, 128, 4, 2, 4>": "conv1d_x3<128x64,ld4>"}
+             "<4, 1, 1, 2, 32, 128, 4, 2, 4>": "conv1d_x3<128x64,ld4>"}
     for targs, name in cases.items():
         assert family(f"void bv2::conv1d_x6_kernel{targs}(bv2::ConvLaunch, int, int, int)") == name
         assert f'"{name}"' in src, name
