@@ -30,6 +30,13 @@
 //     are row shifts of the same tile.  The next chunk's global loads fly under this chunk's MFMAs; two barriers per chunk (one, and
 //     the staging off the MFMA waves altogether, with loader waves).
 //   * per unit (16 channels x 1 tap): NI*3 ds_read_b128 + MI*3 global_load_dwordx4 feed MI*NI*6 MFMAs (12 for the 32x64 wave tile).
+//
+// Round 6, the two-plane fp16 form (NP = 2, "x3"; bv2_kernels.h has the arithmetic): the same kernel on two SCALED fp16 planes per operand and
+// three products — w S_w = g0 + g1, x S_x = h0 + h1 (fp16 halves, round-to-nearest), acc += g1 h0 + g0 h1 + g0 h0, result = acc / (S_w S_x) —
+// i.e. a third less LDS and ring registers and half the matrix instructions per unit.  S_w comes with the packed planes; S_x from the max |x|
+// of the input tensor, which the launch that WROTE that tensor published from its epilogue (ConvProb::omax -> ::xmax: one 128-byte line per
+// XCD, L2-local atomics, x3_publish below).  Shipped tiles of the form: 128x64 plain (two-tap ring, three workgroups per CU) for launches of
+// > 512 workgroups, 128x64 with FOUR loader waves and a four-tap ring (RD = 4) for the one-workgroup-per-CU launches.
 // Tiles and what was measured around them: launch_conv1d_x6 at the end of the file; DESIGN.md 3 / 5.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
@@ -649,6 +656,8 @@ int launch_conv1d_x6(hipStream_t stream, const ConvLaunch& L, int tile, const ch
   switch (tile) {
     case TILE_X6_128x64:                          // all four waves on the same 64 columns, one 32-row block each
       if (variant_name) *variant_name = x3 ? "conv1d_x3<128x64>" : "conv1d_x6<128x64>";
+      // (four workgroups per CU instead of three — 128 registers without the input-mask path, no spills — measured slower too: 0.375 ->
+      //  0.386 ms for the six launches, same-box A/B of builds)
       // (the four-tap ring on THIS tile — 168 registers, three workgroups per CU already hiding the distance — measured slower: Generator
       //  pass 1.192 -> 1.200 ms, rocprofv3 59.6 -> 64.2 us per launch; it stays on the two-tap ring)
       if (x3) return launch_x6_variant<4, 1, 1, 2, 32, 128, 0, 2>(stream, L, max_cout_pad);

@@ -14,6 +14,10 @@
 // is held to the fp32-MFMA pair kernel at fp32 round-off.  Measured (same-box A/Bs, config 2): C = 32 3.769 -> 3.681 ms per step,
 // C = 64 3.72 -> 3.64, C = 16 3.640 -> 3.541; C = 128 no gain against the loader-wave kernel (profiles/r04_ab_x6_pair*.txt).
 // out must not alias x (a tile's halo columns are another tile's outputs): the host ping-pongs between two buffers per branch.
+// Round 6: the two-plane fp16 form (NP = 2, "x3", default; bv2_kernels.h has the arithmetic): both convs on three products of scaled fp16
+// halves, the activation scales taken from the workgroup's own tiles (max |x| staged, max |h| computed) — C = 64 / 32 / 16: 94.4 / 53.7 / 48.9
+// -> 61.8 / 36.2 / 32.7 us per launch at batch 1.  NP = 3 (the text above) stays as "conv_x3" = 0 and is the form that is bit-identical to
+// the layer-wise launches.
 #include <hip/hip_runtime.h>
 #include "../bv2_kernels.h"
 
