@@ -278,6 +278,10 @@ def run_config3_unpinned(hp, dev, n_cold=20, n_steady=40):
     lives or dies by its T_y buckets (models.enable_graphs ty_bucket, 32 frames).  `cold`: the first n_cold distinct batches, captures inside
     the clock.  `steady`: n_steady further distinct batches.  `eager`: those same n_steady batches with graphs off.  value = VALID audio seconds
     (sum of y_lengths) per second; padded_value counts B x T_y (what the pinned config 3 figure counts, where every utterance is T_y long)."""
+    # infer() draws its duration noise from torch's generators: seeded, so that the T_y sequence — which buckets the steady pass meets, and
+    # whether one of them was never captured in the cold pass — is the same in every run of this leg (an unseeded run once met a fourth
+    # bucket inside the steady pass: one capture in the clock, 18.8 instead of 13.4 ms per step)
+    torch.manual_seed(20260930)
     sd = synth.synthetic_state_dict(hp, seed=0)
     m = models.from_hparams(hp)
     m.load_state_dict(sd, strict=False)
