@@ -527,6 +527,21 @@ int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_flo
         for (int e = 0; e < 2; ++e) add(m.rb[i][j][d][e]);
   return n;
 }
+int bv2_test_x3_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_floats, int max_regions) {
+  if (!h || !off_floats || !n_floats) return -1;
+  const Model& m = h->model;
+  int n = 0;
+  for (int i = 0; i < m.n_ups; ++i)
+    for (int j = 0; j < m.n_rbk; ++j)
+      for (int d = 0; d < m.n_rbd; ++d)
+        for (int e = 0; e < 2; ++e) {
+          const ConvW& w = m.rb[i][j][d][e];
+          if (w.wy_off < 0 || w.wx_off < 0) continue;
+          if (n < max_regions) { off_floats[n] = w.wy_off; n_floats[n] = X3_HDR_FLOATS + (x3_w_elems(w.cin, w.cout_pad, w.k) + 1) / 2; }
+          ++n;
+        }
+  return n;
+}
 static int64_t t_x6_off(int cin, int cout, int k) {
   return ((int64_t)k * t_round_up(cin, 16) * t_round_up(cout, 128) + t_round_up(cout, 32) + 2048 + 63) / 64 * 64;
 }

@@ -38,6 +38,9 @@ void bv2_test_x6_split(float v, uint16_t* h3);
 /* where the packed blob holds x6 weight planes: float offset / float count of every region ([unit][plane 3][64 lanes][8] uint16); returns
  * the number of regions (host only; layout is known after bv2_create) */
 int bv2_test_x6_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_floats, int max_regions);
+/* ... and its scaled fp16 planes of the x3 form, in the same conv order: a region = 64 floats (the first = 1 / S_w) followed by
+ * [unit][plane 2][64 lanes][8] fp16 — unit / lane / element order as in the x6 region of the same conv */
+int bv2_test_x3_regions(const bv2_handle* h, int64_t* off_floats, int64_t* n_floats, int max_regions);
 
 /* fused ResBlock1 pair (kernels/resblock_fused.hip): out = x + conv2(lrelu(conv1(lrelu(x), k, dil) + b1), k, 1) + b2 on
  * [B][C][L]; w*_host [C][C][k], b*_host [C] are HOST pointers; wpack_dev needs 2 * bv2_test_conv_pack_floats(C, C, k) floats */

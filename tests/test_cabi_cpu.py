@@ -1,5 +1,6 @@
 """CPU: the C-ABI library loads, exports every symbol include/*.h declares, and its host-only entry points
 (create / load_tensor / pack_weights / workspace_bytes) behave — no compute calls (there is no GPU here)."""
+import math
 import ctypes as C
 import os
 import re
@@ -134,6 +135,26 @@ def test_pack_weights_fold_equivalence_and_missing_keys():
         assert w1.abs().sum() > 0 and (w1 - w2).abs().max().item() <= 2e-6 * w1.abs().max().item()
         f1[sl] = 0
         f2[sl] = 0
+    # the x3 regions (two fp16 planes of w * S_w behind 1 / S_w; kernels/conv_x6.hip NP = 2) encode the SAME weights as the x6 regions of the
+    # same convs: (g0 + g1) / S_w == h1 + h2 + h3 up to 2^-23 of the tensor's largest weight (fp16 halves of a value below 2^15 leave <= 2^-24 of
+    # it, or 2^-25 absolute in scaled units), S_w a power of two that puts that largest weight in [2^14, 2^15)
+    lib.bv2_test_x3_regions.restype = C.c_int
+    lib.bv2_test_x3_regions.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]
+    o3, c3 = (C.c_int64 * 256)(), (C.c_int64 * 256)()
+    assert lib.bv2_test_x3_regions(h, o3, c3, 256) == nreg
+    g1 = blob1.view(torch.float32)
+    for i in range(nreg):
+        w6 = (g1[offs[i]:offs[i] + cnts[i]].view(torch.int16).to(torch.int32) << 16).view(torch.float32).view(-1, 3, 512).double().sum(1)
+        reg = g1[o3[i]:o3[i] + c3[i]]
+        inv = float(reg[0])
+        assert inv > 0 and math.log2(inv) == round(math.log2(inv))
+        w3 = reg[64:].view(torch.float16).view(-1, 2, 512).double().sum(1)
+        assert w3.shape == w6.shape
+        wmax = w6.abs().max().item()
+        assert 2.0 ** 14 <= wmax / inv < 2.0 ** 15
+        assert (w3 * inv - w6).abs().max().item() <= 2.0 ** -23 * wmax
+        f1[o3[i]:o3[i] + c3[i]] = 0
+        f2[o3[i]:o3[i] + c3[i]] = 0
     a, b = f1[64:], f2[64:]
     assert a.abs().sum() > 0
     # fp32 regions agree to fold round-off; in the bf16 regions of the blob (two bf16 per 32-bit word) a fold difference
